@@ -1,0 +1,87 @@
+"""ctypes binding of include/dvpari.h.  No torch types cross this boundary: pointers and sizes only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvpari_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  dv-pari_amd has no CPU fallback."
+    )
+lib = C.CDLL(LIB_PATH)
+
+vp, u32, u64p, u8p, sz = C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t
+
+_SIGS = {
+    "dvp_strerror": (C.c_char_p, [C.c_int]),
+    "dvp_version": (C.c_int, []),
+    "dvp_device_count": (C.c_int, []),
+    "dvp_set_device": (C.c_int, [C.c_int]),
+    "dvp_last_error_index": (C.c_int64, []),
+    "dvp_ecfft_create": (C.c_int, [u32, C.c_int, u32, C.POINTER(vp)]),
+    "dvp_ecfft_destroy": (None, [vp]),
+    "dvp_ecfft_log2_leaves": (u32, [vp]),
+    "dvp_ecfft_leaves": (C.c_int, [vp, u64p]),
+    "dvp_ecfft_extend": (C.c_int, [vp, u64p, u32, u64p]),
+    "dvp_ecfft_extend_dev": (C.c_int, [vp, vp, u32, vp, vp]),
+    "dvp_ecfft_enter": (C.c_int, [vp, u64p, u64p]),
+    "dvp_ecfft_exit": (C.c_int, [vp, u64p, u64p]),
+    "dvp_ecfft_enter_dev": (C.c_int, [vp, vp, vp, vp]),
+    "dvp_ecfft_exit_dev": (C.c_int, [vp, vp, vp, vp]),
+    "dvp_ecfft_vanish_at": (C.c_int, [vp, C.c_int, u64p, u64p]),
+    "dvp_fr_batch_inverse": (C.c_int, [u64p, sz]),
+    "dvp_fr_batch_inverse_dev": (C.c_int, [vp, sz, vp]),
+    "dvp_barycentric_eval": (C.c_int, [u64p, u64p, u64p, u64p, sz, u64p, u64p]),
+    "dvp_msm_affine": (C.c_int, [u64p, u64p, u8p, sz, u64p, C.POINTER(C.c_int)]),
+    "dvp_msm_affine_dev": (C.c_int, [vp, vp, vp, sz, vp, vp, vp]),
+    "dvp_msm_xsk233": (C.c_int, [u8p, u8p, sz, u8p]),
+    "dvp_mulgen_batch": (C.c_int, [u64p, sz, u8p]),
+    "dvp_mulgen_batch_affine": (C.c_int, [u64p, sz, u64p, u8p]),
+    "dvp_points_encode": (C.c_int, [u64p, u8p, sz, u8p]),
+    "dvp_points_decode": (C.c_int, [u8p, sz, u64p, u8p]),
+}
+EXPORTED = []
+for _name, (_res, _args) in _SIGS.items():
+    try:
+        _f = getattr(lib, _name)
+    except AttributeError:
+        continue
+    _f.restype, _f.argtypes = _res, _args
+    EXPORTED.append(_name)
+
+
+class DvpError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        self.index = lib.dvp_last_error_index()
+        super().__init__(f"{where}: {lib.dvp_strerror(status).decode()} (status {status}, index {self.index})")
+
+
+def check(status, where=""):
+    if status != 0:
+        raise DvpError(status, where)
+
+
+# ---- int <-> limb helpers (canonical little-endian 4 x u64) ----------------------------------------
+def ints_to_limbs(vals, words=4) -> np.ndarray:
+    out = np.empty((len(vals), words), dtype=np.uint64)
+    buf = b"".join(int(v).to_bytes(8 * words, "little") for v in vals)
+    out[:] = np.frombuffer(buf, dtype="<u8").reshape(len(vals), words)
+    return out
+
+
+def limbs_to_ints(arr) -> list:
+    a = np.ascontiguousarray(arr, dtype="<u8")
+    a = a.reshape(-1, a.shape[-1])
+    w = a.shape[1] * 8
+    raw = a.tobytes()
+    return [int.from_bytes(raw[i * w:(i + 1) * w], "little") for i in range(a.shape[0])]
+
+
+def ptr(a: np.ndarray):
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

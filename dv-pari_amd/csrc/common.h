@@ -1,0 +1,64 @@
+// Shared host-side plumbing for libdvpari_hip.so: status codes, HIP error capture, scoped buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/dvpari.h"
+
+namespace dvp {
+
+extern thread_local int64_t g_last_error_index;
+extern thread_local hipError_t g_last_hip_error;
+
+inline int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  g_last_hip_error = e;
+  fprintf(stderr, "[dvpari] HIP error %d (%s) at %s:%d: %s\n", (int)e, hipGetErrorString(e), file, line, what);
+  return DVP_EHIP;
+}
+
+#define DVP_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) return ::dvp::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define DVP_TRY(call)        \
+  do {                       \
+    int _s = (call);         \
+    if (_s != DVP_OK) return _s; \
+  } while (0)
+
+// RAII device buffer (host-side convenience for the host-pointer flavours of the ABI)
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  int alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    }
+    bytes = n;
+    return DVP_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <class T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace dvp
