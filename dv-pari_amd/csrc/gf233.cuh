@@ -1,0 +1,180 @@
+// GF(2^233) = GF(2)[z]/(z^233 + z^74 + 1): the base field of sect233k1 (the arithmetic the
+// reference reaches through xs233-sys, src/curve.rs:13).  8 x 32-bit words, polynomial basis,
+// bit i of the 256-bit little-endian value = coefficient of z^i; bits 233..255 are zero.
+//
+// gfx950 has no carry-less multiply (v_clmul_* does not assemble for this target), so the
+// product is built on the integer VALU: a is scanned bit-serially (v_bfe_i32 turns a bit into a
+// 0/-1 mask), and each mask gates one word of b into the accumulator with a single
+// v_bitop3_b32 ((m & b) ^ acc, truth table 0x6a); the accumulator is shifted by one bit per
+// scanned bit position with v_alignbit_b32.  One 233x233 product = 32 x (15 shifts + 8 masks +
+// 64 and-xor) ~ 2.8k VALU lane-ops; a squaring is a bit spread (~0.2k).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dvp {
+
+struct Gf {
+  uint32_t w[8];
+};
+
+#define GF_DEV __device__ __forceinline__
+
+GF_DEV Gf gf_zero() {
+  Gf r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = 0;
+  return r;
+}
+GF_DEV Gf gf_one() {
+  Gf r = gf_zero();
+  r.w[0] = 1;
+  return r;
+}
+GF_DEV Gf gf_add(const Gf& a, const Gf& b) {
+  Gf r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = a.w[i] ^ b.w[i];
+  return r;
+}
+GF_DEV bool gf_is_zero(const Gf& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o |= a.w[i];
+  return o == 0;
+}
+GF_DEV bool gf_eq(const Gf& a, const Gf& b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o |= a.w[i] ^ b.w[i];
+  return o == 0;
+}
+// c ? a : b
+GF_DEV Gf gf_select(bool c, const Gf& a, const Gf& b) {
+  Gf r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = c ? a.w[i] : b.w[i];
+  return r;
+}
+
+GF_DEV uint32_t gf_andxor(uint32_t m, uint32_t b, uint32_t acc) {
+  return __builtin_amdgcn_bitop3_b32(m, b, acc, 0x6a);  // (m & b) ^ acc
+}
+
+// c[0..15] (466 significant bits) -> reduced element.  z^233 = z^74 + 1:
+// word j >= 8 sits at bit 32j = 233 + (32(j-8)+23), so it folds into bit offsets 32(j-8)+23 and
+// 32(j-8)+97 = 32(j-5)+1.
+GF_DEV Gf gf_reduce16(uint32_t* c) {
+#pragma unroll
+  for (int j = 15; j >= 8; --j) {
+    uint32_t t = c[j];
+    c[j - 8] ^= t << 23;
+    c[j - 7] ^= t >> 9;
+    c[j - 5] ^= t << 1;
+    c[j - 4] ^= t >> 31;
+  }
+  uint32_t t = c[7] >> 9;
+  c[0] ^= t;
+  c[2] ^= t << 10;
+  c[3] ^= t >> 22;
+  c[7] &= 0x1FFu;
+  Gf r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = c[i];
+  return r;
+}
+
+GF_DEV Gf gf_mul(const Gf& a, const Gf& b) {
+  uint32_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0;
+  // bits 9..31: a.w[7] has only 9 significant bits, so its rows are skipped here
+#pragma unroll 1
+  for (int k = 31; k >= 9; --k) {
+#pragma unroll
+    for (int i = 14; i > 0; --i) acc[i] = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], 31);
+    acc[0] <<= 1;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)a.w[j], k, 1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i + j] = gf_andxor(m, b.w[i], acc[i + j]);
+    }
+  }
+#pragma unroll 1
+  for (int k = 8; k >= 0; --k) {
+#pragma unroll
+    for (int i = 14; i > 0; --i) acc[i] = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], 31);
+    acc[0] <<= 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)a.w[j], k, 1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i + j < 15) acc[i + j] = gf_andxor(m, b.w[i], acc[i + j]);
+      }
+    }
+  }
+  return gf_reduce16(acc);
+}
+
+// 16 bits -> 32 bits with zeros interleaved
+GF_DEV uint32_t gf_spread16(uint32_t x) {
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
+GF_DEV Gf gf_sqr(const Gf& a) {
+  uint32_t c[16];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    c[2 * i] = gf_spread16(a.w[i] & 0xFFFFu);
+    c[2 * i + 1] = gf_spread16(a.w[i] >> 16);
+  }
+  c[14] = gf_spread16(a.w[7] & 0xFFFFu);
+  c[15] = 0;
+  return gf_reduce16(c);
+}
+
+GF_DEV Gf gf_sqr_n(Gf a, int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) a = gf_sqr(a);
+  return a;
+}
+
+// Itoh-Tsujii inversion a^(2^233 - 2): 10 multiplications + 232 squarings.  a == 0 -> 0.
+GF_DEV Gf gf_inv(const Gf& a) {
+  Gf b1 = a;
+  Gf b2 = gf_mul(gf_sqr(b1), b1);
+  Gf b3 = gf_mul(gf_sqr(b2), b1);
+  Gf b6 = gf_mul(gf_sqr_n(b3, 3), b3);
+  Gf b7 = gf_mul(gf_sqr(b6), b1);
+  Gf b14 = gf_mul(gf_sqr_n(b7, 7), b7);
+  Gf b28 = gf_mul(gf_sqr_n(b14, 14), b14);
+  Gf b29 = gf_mul(gf_sqr(b28), b1);
+  Gf b58 = gf_mul(gf_sqr_n(b29, 29), b29);
+  Gf b116 = gf_mul(gf_sqr_n(b58, 58), b58);
+  Gf b232 = gf_mul(gf_sqr_n(b116, 116), b116);
+  return gf_sqr(b232);
+}
+
+GF_DEV Gf gf_sqrt(const Gf& a) { return gf_sqr_n(a, 232); }
+
+// Tr(a): for z^233+z^74+1, Tr(z^i) = 1 exactly for i in {0, 159}
+GF_DEV uint32_t gf_trace(const Gf& a) { return (a.w[0] ^ (a.w[4] >> 31)) & 1u; }
+
+// half-trace H(c) = sum_{i=0}^{116} c^(4^i): a root of z^2 + z = c when Tr(c) = 0
+GF_DEV Gf gf_halftrace(const Gf& c) {
+  Gf h = c, x = c;
+#pragma unroll 1
+  for (int i = 0; i < 116; ++i) {
+    x = gf_sqr(gf_sqr(x));
+    h = gf_add(h, x);
+  }
+  return h;
+}
+
+}  // namespace dvp

@@ -1,0 +1,130 @@
+// sect233k1 (K-233): y^2 + xy = x^3 + 1 over GF(2^233), prime-order subgroup E[r].
+//
+// The reference reaches this curve through xs233's prime-order group xsk233 = { P + N : P in E[r] }
+// with N = (0,1) the point of order 2 (src/curve.rs:13,72-158).  P -> P + N is a group isomorphism
+// E[r] -> xsk233, so every linear operation of the reference (multi_scalar_mul, point_scalar_mul,
+// add) is carried out here on the E[r] representative and only the 30-byte codec moves between the
+// two views (codec.hip).
+//
+// Coordinates: affine (x,y) in HBM for bases; Lopez-Dahab projective (X,Y,Z), x = X/Z, y = Y/Z^2,
+// for accumulators.  Z == 0 encodes the point at infinity.  Formula costs (a = 0, b = 1):
+//   doubling 3M+5S, mixed addition 8M+5S, full addition 13M+5S, Frobenius 3S.
+#pragma once
+#include "gf233.cuh"
+
+namespace dvp {
+
+struct Aff {
+  Gf x, y;
+};
+struct Ld {
+  Gf X, Y, Z;
+};
+
+GF_DEV Ld ld_infinity() {
+  Ld r;
+  r.X = gf_one();
+  r.Y = gf_zero();
+  r.Z = gf_zero();
+  return r;
+}
+GF_DEV bool ld_is_inf(const Ld& p) { return gf_is_zero(p.Z); }
+GF_DEV Ld ld_from_aff(const Aff& a) {
+  Ld r;
+  r.X = a.x;
+  r.Y = a.y;
+  r.Z = gf_one();
+  return r;
+}
+GF_DEV Aff aff_neg(const Aff& a) {
+  Aff r;
+  r.x = a.x;
+  r.y = gf_add(a.x, a.y);
+  return r;
+}
+
+GF_DEV Ld ld_dbl(const Ld& p) {
+  Gf z1s = gf_sqr(p.Z), x1s = gf_sqr(p.X);
+  Ld r;
+  r.Z = gf_mul(x1s, z1s);
+  Gf z1q = gf_sqr(z1s);
+  r.X = gf_add(gf_sqr(x1s), z1q);
+  r.Y = gf_add(gf_mul(z1q, r.Z), gf_mul(r.X, gf_add(gf_sqr(p.Y), z1q)));
+  return r;  // Z1 == 0 -> Z3 == 0; X1 == 0 (the point N, never in E[r]) -> Z3 == 0
+}
+
+// p + q, q affine and not infinity.
+GF_DEV Ld ld_madd(const Ld& p, const Aff& q) {
+  if (ld_is_inf(p)) return ld_from_aff(q);
+  Gf z1s = gf_sqr(p.Z);
+  Gf A = gf_add(p.Y, gf_mul(q.y, z1s));
+  Gf B = gf_add(p.X, gf_mul(q.x, p.Z));
+  if (gf_is_zero(B)) {
+    if (gf_is_zero(A)) return ld_dbl(ld_from_aff(q));  // p == q
+    return ld_infinity();                              // p == -q
+  }
+  Gf C = gf_mul(p.Z, B);
+  Gf D = gf_mul(gf_sqr(B), C);
+  Ld r;
+  r.Z = gf_sqr(C);
+  Gf E = gf_mul(A, C);
+  r.X = gf_add(gf_add(gf_sqr(A), D), E);
+  Gf F = gf_add(r.X, gf_mul(q.x, r.Z));
+  Gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(r.Z));
+  r.Y = gf_add(gf_mul(gf_add(E, r.Z), F), G);
+  return r;
+}
+
+// p + q, both projective
+GF_DEV Ld ld_add(const Ld& p, const Ld& q) {
+  if (ld_is_inf(p)) return q;
+  if (ld_is_inf(q)) return p;
+  Gf A1 = gf_mul(q.Y, gf_sqr(p.Z));
+  Gf A2 = gf_mul(p.Y, gf_sqr(q.Z));
+  Gf B1 = gf_mul(q.X, p.Z);
+  Gf B2 = gf_mul(p.X, q.Z);
+  Gf C = gf_add(A1, A2);
+  Gf D = gf_add(B1, B2);
+  if (gf_is_zero(D)) {
+    if (gf_is_zero(C)) return ld_dbl(p);
+    return ld_infinity();
+  }
+  Gf E = gf_mul(p.Z, q.Z);
+  Gf F = gf_mul(D, E);
+  Ld r;
+  r.Z = gf_sqr(F);
+  Gf Ds = gf_sqr(D);
+  Gf G = gf_mul(Ds, F);
+  Gf H = gf_mul(C, F);
+  r.X = gf_add(gf_add(gf_sqr(C), H), G);
+  Gf I = gf_add(gf_mul(gf_mul(Ds, B1), E), r.X);
+  Gf J = gf_add(gf_mul(Ds, A1), r.X);
+  r.Y = gf_add(gf_mul(H, I), gf_mul(r.Z, J));
+  return r;
+}
+
+// Frobenius tau(x,y) = (x^2,y^2), applied k times
+GF_DEV Ld ld_frob_n(Ld p, int k) {
+#pragma unroll 1
+  for (int i = 0; i < k; ++i) {
+    p.X = gf_sqr(p.X);
+    p.Y = gf_sqr(p.Y);
+    p.Z = gf_sqr(p.Z);
+  }
+  return p;
+}
+
+// projective -> affine; returns false for infinity
+GF_DEV bool ld_to_aff(const Ld& p, Aff* out) {
+  if (ld_is_inf(p)) {
+    out->x = gf_zero();
+    out->y = gf_zero();
+    return false;
+  }
+  Gf zi = gf_inv(p.Z);
+  out->x = gf_mul(p.X, zi);
+  out->y = gf_mul(p.Y, gf_sqr(zi));
+  return true;
+}
+
+}  // namespace dvp

@@ -1,0 +1,569 @@
+// Multi-scalar multiplication on sect233k1 for gfx950 -- replaces multi_scalar_mul
+// (src/curve.rs:141-158; call sites src/proving.rs:463,512,680), which in the reference is n
+// independent xsk233_mul_frob calls plus an add tree.  Here: a Koblitz-aware bucket method.
+//
+//  1. recode   each scalar s (mod r) is reduced modulo delta = (tau^233-1)/(tau-1) in Z[tau]
+//              (Solinas partial reduction) and expanded in base tau with digits {0,1}
+//              (tau^2 + tau + 2 = 0 is a canonical number system), <= 240 digits.  A window is c
+//              consecutive digits; window w, pattern d  <->  bucket key w*2^c + d.
+//              Because the window multipliers are powers of tau, the final combination uses the
+//              Frobenius (3 squarings) where an integer-window Pippenger needs doublings -- on a
+//              GPU that turns a ~230-step serial doubling chain into a log-depth tree.
+//  2. sort     counting sort of (key, point index): histogram (atomics) -> scan -> scatter.
+//  3. reduce   segmented sum per key by fixed fan-in K: level 1 gathers affine bases and does mixed
+//              Lopez-Dahab additions; further levels add projective partials.  Tasks never span
+//              keys, so skewed scalars (many equal digits) stay load-balanced.
+//  4. merge    per window, D_t = sum of buckets whose pattern has bit t, by a pruned
+//              sum-over-subsets tree (2*2^c additions per window, depth c).
+//  5. tail     result = sum_j tau^j(D_j): per-point Frobenius powers, then a pairwise add tree.
+//
+// All of it runs on the VALU (no MFMA: there is no dense contraction in this algorithm, and
+// gfx950 has no carry-less multiplier -- see gf233.cuh).
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "k233.cuh"
+
+namespace dvp {
+
+// ---- tau-adic recoding constants (derived in oracle/pyref.py: tau_constants()) ------------------
+// delta = D0 + D1*tau, N(delta) = r;  conj(delta) = (D0 - D1) - D1*tau;  A_i = floor(|conj_i| 2^256 / r)
+__constant__ uint32_t TAU_D0[4] = {0xba75bb3bu, 0xda32c0f4u, 0x2dcb0ed1u, 0x00032540u};
+__constant__ uint32_t TAU_D1[4] = {0xcb36bee6u, 0x16aa143cu, 0x2d7ae36eu, 0x000882d7u};
+__constant__ uint32_t TAU_C0M[4] = {0x10c103abu, 0x3c775348u, 0xffafd49cu, 0x00055d96u};  // D1 - D0
+__constant__ uint32_t TAU_A0[5] = {0x55720891u, 0x90218207u, 0x3878eea6u, 0x2dff5fa9u, 0x00000abbu};
+__constant__ uint32_t TAU_A1[5] = {0xcb1ecea9u, 0x79966d7du, 0xdc2d5428u, 0xae5af5c6u, 0x00001105u};
+constexpr int TAU_DIGITS = 240;  // observed maximum over 1e5 random scalars + edge cases: 236
+
+// out[0..no) = low `no` limbs of a[0..na) * b[0..nb)
+template <int NA, int NB, int NO>
+__device__ __forceinline__ void mp_mul_lo(const uint32_t* a, const uint32_t* b, uint32_t* out) {
+#pragma unroll
+  for (int i = 0; i < NO; ++i) out[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (i + j < NO) {
+        c += (uint64_t)a[i] * b[j] + out[i + j];
+        out[i + j] = (uint32_t)c;
+        c >>= 32;
+      }
+    }
+    if (i + NB < NO) out[i + NB] = (uint32_t)c;
+  }
+}
+
+// Q = round(s * A / 2^256), s: 8 limbs, A: 5 limbs -> 4 limbs (value < 2^117)
+__device__ __forceinline__ void tau_round_mul(const uint32_t* s, const uint32_t* A, uint32_t* Q) {
+  uint32_t t[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      c += (uint64_t)s[i] * A[j] + t[i + j];
+      t[i + j] = (uint32_t)c;
+      c >>= 32;
+    }
+    t[i + 5] = (uint32_t)c;
+  }
+  // + 2^255, then >> 256
+  uint64_t c = (uint64_t)t[7] + 0x80000000u;
+  c >>= 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c += t[8 + i];
+    Q[i] = (uint32_t)c;
+    c >>= 32;
+  }
+}
+
+// One thread per scalar: digits[w][i] (c-bit patterns) + bucket histogram.
+// Scalars >= r are rejected (flag); points flagged infinite contribute nothing.
+__global__ void __launch_bounds__(256)
+k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W,
+         uint16_t* __restrict__ digits, uint32_t* __restrict__ hist, unsigned long long* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
+  bool skip = inf && inf[i];
+  {
+    // canonical check: s < r  (r == Fr modulus)
+    const uint32_t p[8] = {0xf173abdfu, 0x6efb1ad5u, 0xb915bcd4u, 0x00069d5bu, 0, 0, 0, 0x00000080u};
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      uint64_t t = (uint64_t)s[k] - p[k] - borrow;
+      borrow = (t >> 63) & 1;
+    }
+    if (!borrow) {
+      atomicMin(err, (unsigned long long)i);
+      skip = true;
+    }
+  }
+  uint32_t Q0[4], Q1[4];
+  tau_round_mul(s, TAU_A0, Q0);
+  tau_round_mul(s, TAU_A1, Q1);
+  // rho0 = s + Q0*D0 - 2*Q1*D1 ; rho1 = Q0*D1 - Q1*(D1-D0)      (mod 2^160, two's complement)
+  uint32_t r0[5], r1[5], t0[5], t1[5];
+  mp_mul_lo<4, 4, 5>(Q0, TAU_D0, t0);
+  mp_mul_lo<4, 4, 5>(Q1, TAU_D1, t1);
+  {
+    uint64_t cy = 0;
+    int64_t bw = 0;
+    uint32_t acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {  // s + t0
+      cy += (uint64_t)s[k] + t0[k];
+      acc[k] = (uint32_t)cy;
+      cy >>= 32;
+    }
+    uint32_t prev = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {  // - 2*t1
+      uint32_t d = (t1[k] << 1) | prev;
+      prev = t1[k] >> 31;
+      int64_t v = (int64_t)acc[k] - d + bw;
+      r0[k] = (uint32_t)v;
+      bw = v >> 32;
+    }
+  }
+  mp_mul_lo<4, 4, 5>(Q0, TAU_D1, t0);
+  mp_mul_lo<4, 4, 5>(Q1, TAU_C0M, t1);
+  {
+    int64_t bw = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      int64_t v = (int64_t)t0[k] - t1[k] + bw;
+      r1[k] = (uint32_t)v;
+      bw = v >> 32;
+    }
+  }
+  if (skip) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
+  }
+  // expansion: u = r0 & 1; r0 -= u; h = r0 >> 1 (arithmetic); (r0, r1) = (r1 - h, -h)
+  uint32_t dig = 0;
+  int bitpos = 0, w = 0;
+  for (int step = 0; step < W * c; ++step) {
+    uint32_t u = r0[0] & 1u;
+    dig |= u << bitpos;
+    uint32_t h[5];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = (r0[k] >> 1) | (r0[k + 1] << 31);
+    h[4] = (uint32_t)((int32_t)r0[4] >> 1);
+    int64_t b1 = 0, b2 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      int64_t v = (int64_t)r1[k] - h[k] + b1;
+      r0[k] = (uint32_t)v;
+      b1 = v >> 32;
+      int64_t z = (int64_t)0 - h[k] + b2;
+      r1[k] = (uint32_t)z;
+      b2 = z >> 32;
+    }
+    if (++bitpos == c) {
+      digits[(size_t)w * n + i] = (uint16_t)dig;
+      if (dig) atomicAdd(&hist[((uint32_t)w << c) + dig], 1u);
+      dig = 0;
+      bitpos = 0;
+      ++w;
+    }
+  }
+  uint32_t rest = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
+  if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than W*c digits
+}
+
+// ---- exclusive scan of u32 (3 kernels; up to 4096*1024 elements) ---------------------------------
+constexpr int SCAN_TPB = 256, SCAN_EPT = 4, SCAN_BLK = SCAN_TPB * SCAN_EPT;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* sh) {
+  // sh: 256 entries
+  int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 1; o < SCAN_TPB; o <<= 1) {
+    uint32_t x = (t >= o) ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  uint32_t incl = sh[t];
+  *total = sh[SCAN_TPB - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_local(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                         uint32_t* __restrict__ bsum, uint32_t m) {
+  __shared__ uint32_t sh[SCAN_TPB];
+  uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
+  uint32_t v[SCAN_EPT], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k) {
+    v[k] = (base + k < m) ? in[base + k] : 0;
+    s += v[k];
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot, sh);
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k) {
+    if (base + k < m) out[base + k] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_bsums(uint32_t* __restrict__ bsum, uint32_t nb, uint32_t* total_out) {
+  __shared__ uint32_t sh[SCAN_TPB];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += SCAN_TPB) {
+    uint32_t idx = base + threadIdx.x;
+    uint32_t v = idx < nb ? bsum[idx] : 0;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(v, &tot, sh);
+    if (idx < nb) bsum[idx] = ex + carry;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_add(uint32_t* __restrict__ out, const uint32_t* __restrict__ bsum, uint32_t m) {
+  uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
+  uint32_t add = bsum[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k)
+    if (base + k < m) out[base + k] += add;
+}
+
+// out[0..m) = exclusive scan of in[0..m); out[m] = total
+static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st) {
+  uint32_t nb = cdiv(m, SCAN_BLK);
+  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
+  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+
+// ---- scatter -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_scatter(const uint16_t* __restrict__ digits, uint32_t n, int c, int W, const uint32_t* __restrict__ off,
+          uint32_t* __restrict__ cursor, uint32_t* __restrict__ items) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  int w = blockIdx.y;
+  if (i >= n) return;
+  uint32_t d = digits[(size_t)w * n + i];
+  if (!d) return;
+  uint32_t key = ((uint32_t)w << c) + d;
+  uint32_t pos = off[key] + atomicAdd(&cursor[key], 1u);
+  items[pos] = i;
+}
+
+// ---- segmented reduction by fan-in K ----------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ntask(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ ntask, uint32_t nkeys, uint32_t K) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nkeys) ntask[k] = (cnt[k] + K - 1) / K;
+}
+
+// largest key with toff[key] <= tid (toff has nkeys+1 entries, toff[nkeys] = total > tid)
+__device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t tid) {
+  uint32_t lo = 0, hi = nkeys;  // invariant: toff[lo] <= tid < toff[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (toff[mid] <= tid) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(256)
+k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
+               const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
+               Ld* __restrict__ out) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= toff[nkeys]) return;
+  uint32_t key = find_key(toff, nkeys, tid);
+  uint32_t j = tid - toff[key];
+  uint32_t start = off[key] + j * K;
+  uint32_t len = min(K, cnt[key] - j * K);
+  Ld acc = ld_from_aff(bases[items[start]]);
+#pragma unroll 1
+  for (uint32_t t = 1; t < len; ++t) acc = ld_madd(acc, bases[items[start + t]]);
+  out[tid] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+             const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K, Ld* __restrict__ out) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= toff[nkeys]) return;
+  uint32_t key = find_key(toff, nkeys, tid);
+  uint32_t j = tid - toff[key];
+  uint32_t start = off[key] + j * K;
+  uint32_t len = min(K, cnt[key] - j * K);
+  Ld acc = in[start];
+#pragma unroll 1
+  for (uint32_t t = 1; t < len; ++t) acc = ld_add(acc, in[start + t]);
+  out[tid] = acc;
+}
+
+// dense bucket array: A[key] = the single remaining item of key, or infinity
+__global__ void __launch_bounds__(256)
+k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                uint32_t nkeys, Ld* __restrict__ A) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nkeys) return;
+  A[k] = cnt[k] ? in[off[k]] : ld_infinity();
+}
+
+// ---- pruned sum-over-subsets merge (see file header, step 4) ---------------------------------------
+// level j: blocks of 2^(j+1) buckets; slot s <= j: A[base+s] += A[base+2^j+s]; slot j+1 <- T_right
+__global__ void __launch_bounds__(256) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  uint32_t blk = tid / (uint32_t)(j + 1), s = tid - blk * (uint32_t)(j + 1);
+  size_t base = (size_t)blk << (j + 1);
+  Ld l = A[base + s], r = A[base + ((size_t)1 << j) + s];
+  if (s == 0 && j >= 2) A[base + 1 + j] = r;
+  A[base + s] = ld_add(l, r);
+}
+
+// E[w*c+t] = tau^(w*c+t)( A[w*2^c + 1 + t] )
+__global__ void __launch_bounds__(64) k_frob(const Ld* __restrict__ A, int c, int W, Ld* __restrict__ E) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (uint32_t)(W * c)) return;
+  uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
+  E[tid] = ld_frob_n(A[((size_t)w << c) + 1 + t], (int)tid);
+}
+
+// out[i] = in[2i] + in[2i+1]   (in[count] treated as infinity when count is odd)
+__global__ void __launch_bounds__(64) k_pair_add(const Ld* __restrict__ in, uint32_t count, Ld* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * i >= count) return;
+  Ld a = in[2 * i];
+  if (2 * i + 1 < count) a = ld_add(a, in[2 * i + 1]);
+  out[i] = a;
+}
+
+__global__ void k_finalize(const Ld* __restrict__ in, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Aff a;
+  bool fin = ld_to_aff(in[0], &a);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    out_xy[k] = a.x.w[k];
+    out_xy[8 + k] = a.y.w[k];
+  }
+  *out_inf = fin ? 0u : 1u;
+}
+
+// ---- workspace -----------------------------------------------------------------------------------
+struct MsmWorkspace {
+  std::mutex mu;
+  void* p = nullptr;
+  size_t bytes = 0;
+  int device = -1;
+  int ensure(size_t need) {
+    int dev;
+    DVP_HIP(hipGetDevice(&dev));
+    if (p && (dev != device || bytes < need)) {
+      (void)hipFree(p);
+      p = nullptr;
+      bytes = 0;
+    }
+    if (!p) {
+      DVP_HIP(hipMalloc(&p, need));
+      bytes = need;
+      device = dev;
+    }
+    return DVP_OK;
+  }
+};
+static MsmWorkspace g_ws;
+
+struct MsmPlan {
+  uint32_t n;
+  int c, W;
+  uint32_t K, nkeys, levels;
+  size_t e_max, t1_max, t2_max;
+};
+
+static MsmPlan msm_plan(size_t n) {
+  MsmPlan p;
+  p.n = (uint32_t)n;
+  // cost model: ceil(240/c) * (8.4 n + 28 * 2^c) field multiplications
+  double best = 1e300;
+  p.c = 4;
+  for (int c = 4; c <= 16; ++c) {
+    int W = (TAU_DIGITS + c - 1) / c;
+    double cost = W * (8.4 * (double)n + 28.0 * (double)(1u << c));
+    if (cost < best) { best = cost; p.c = c; }
+  }
+  if (const char* e = getenv("DVP_MSM_C")) { int c = atoi(e); if (c >= 2 && c <= 16) p.c = c; }
+  p.W = (TAU_DIGITS + p.c - 1) / p.c;
+  p.nkeys = (uint32_t)p.W << p.c;
+  p.e_max = n * (size_t)p.W;
+  // fan-in: keep >= ~256k level-1 tasks in flight when the input allows it
+  uint32_t K = (uint32_t)(p.e_max / 262144);
+  if (K < 2) K = 2;
+  if (K > 16) K = 16;
+  if (const char* e = getenv("DVP_MSM_K")) { int k = atoi(e); if (k >= 2 && k <= 64) K = (uint32_t)k; }
+  p.K = K;
+  p.t1_max = p.e_max / K + p.nkeys + 1;
+  p.t2_max = p.t1_max / K + p.nkeys + 1;
+  // levels needed so that K^levels >= n (worst case: every point in one bucket)
+  p.levels = 1;
+  for (double cap = K; cap < (double)n; cap *= K) ++p.levels;
+  return p;
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy,
+                   void* d_out_inf, hipStream_t st) {
+  if (n == 0) {
+    DVP_HIP(hipMemsetAsync(d_out_xy, 0, 64, st));
+    uint32_t one = 1;
+    DVP_HIP(hipMemcpyAsync(d_out_inf, &one, 4, hipMemcpyHostToDevice, st));
+    DVP_HIP(hipStreamSynchronize(st));
+    return DVP_OK;
+  }
+  if (n > (1u << 27)) return DVP_EINVAL;
+  MsmPlan p = msm_plan(n);
+  std::lock_guard<std::mutex> g(g_ws.mu);
+  // carve the workspace
+  size_t o = 0;
+  auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
+  size_t o_err = carve(16);
+  size_t o_digits = carve((size_t)p.W * n * 2);
+  size_t o_cnt = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_off = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_cursor = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_ntask = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_toff = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_cnt2 = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_off2 = carve(((size_t)p.nkeys + 1) * 4);
+  size_t o_bsum = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);
+  size_t o_items = carve(p.e_max * 4);
+  size_t o_bufA = carve(p.t1_max * sizeof(Ld));
+  size_t o_bufB = carve(p.t2_max * sizeof(Ld));
+  size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
+  size_t o_tail = carve((size_t)2 * p.W * p.c * sizeof(Ld));
+  DVP_TRY(g_ws.ensure(o));
+  char* base = (char*)g_ws.p;
+  auto* err = (unsigned long long*)(base + o_err);
+  auto* digits = (uint16_t*)(base + o_digits);
+  auto* cnt = (uint32_t*)(base + o_cnt);
+  auto* off = (uint32_t*)(base + o_off);
+  auto* cursor = (uint32_t*)(base + o_cursor);
+  auto* ntask = (uint32_t*)(base + o_ntask);
+  auto* toff = (uint32_t*)(base + o_toff);
+  auto* cnt2 = (uint32_t*)(base + o_cnt2);
+  auto* off2 = (uint32_t*)(base + o_off2);
+  auto* bsum = (uint32_t*)(base + o_bsum);
+  auto* items = (uint32_t*)(base + o_items);
+  Ld* bufA = (Ld*)(base + o_bufA);
+  Ld* bufB = (Ld*)(base + o_bufB);
+  Ld* bkt = (Ld*)(base + o_bkt);
+  Ld* tail = (Ld*)(base + o_tail);
+  const uint32_t nk = p.nkeys;
+
+  DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
+  DVP_HIP(hipMemsetAsync(cnt, 0, ((size_t)nk + 1) * 4, st));
+  DVP_HIP(hipMemsetAsync(cursor, 0, ((size_t)nk + 1) * 4, st));
+  hipLaunchKernelGGL(k_recode, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
+                     (uint32_t)n, p.c, p.W, digits, cnt, err);
+  DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
+  hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, 256), p.W), dim3(256), 0, st, digits, (uint32_t)n, p.c, p.W, off, cursor, items);
+  // level 1: affine gather
+  hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, cnt, ntask, nk, p.K);
+  DVP_TRY(scan_exclusive(ntask, toff, nk, bsum, st));
+  hipLaunchKernelGGL(k_accum_affine, dim3(cdiv(p.t1_max, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, toff,
+                     nk, p.K, bufA);
+  // further levels: (cnt, off) <- (ntask, toff)
+  uint32_t *c_cnt = ntask, *c_off = toff, *n_cnt = cnt2, *n_off = off2;
+  Ld *in = bufA, *outb = bufB;
+  size_t cap = p.t1_max;
+  for (uint32_t lvl = 1; lvl < p.levels; ++lvl) {
+    hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, c_cnt, n_cnt, nk, p.K);
+    DVP_TRY(scan_exclusive(n_cnt, n_off, nk, bsum, st));
+    size_t tmax = cap / p.K + nk + 1;
+    hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, 256)), dim3(256), 0, st, in, c_cnt, c_off, n_off, nk, p.K, outb);
+    cap = tmax;
+    // rotate: the (cnt,off) arrays of two levels ago are free again
+    uint32_t* f_cnt = c_cnt; uint32_t* f_off = c_off;
+    c_cnt = n_cnt; c_off = n_off;
+    if (f_cnt == ntask) { n_cnt = cnt; n_off = off; } else { n_cnt = f_cnt; n_off = f_off; }
+    Ld* t = in; in = outb; outb = t;
+  }
+  hipLaunchKernelGGL(k_bucket_gather, dim3(cdiv(nk, 256)), dim3(256), 0, st, in, c_cnt, c_off, nk, bkt);
+  for (int j = 0; j < p.c; ++j) {
+    uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
+    hipLaunchKernelGGL(k_merge, dim3(cdiv(total, 256)), dim3(256), 0, st, bkt, j, total);
+  }
+  uint32_t cntT = (uint32_t)(p.W * p.c);
+  Ld* ta = tail;
+  Ld* tb = tail + cntT;
+  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, p.W, ta);
+  while (cntT > 1) {
+    uint32_t half = (cntT + 1) / 2;
+    hipLaunchKernelGGL(k_pair_add, dim3(cdiv(half, 64)), dim3(64), 0, st, ta, cntT, tb);
+    Ld* t = ta; ta = tb; tb = t;
+    cntT = half;
+  }
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  DVP_HIP(hipGetLastError());
+  // the scalar-range flag is the only thing that needs the host
+  unsigned long long e;
+  DVP_HIP(hipMemcpyAsync(&e, err, 8, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  if (e != ~0ull) {
+    g_last_error_index = (int64_t)(e & 0xffffffffull);
+    return DVP_EINVAL;
+  }
+  return DVP_OK;
+}
+
+}  // namespace dvp
+
+using namespace dvp;
+
+extern "C" int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void* d_bases_inf, size_t n,
+                                  void* d_out_xy, void* d_out_inf, void* stream) {
+  if ((n && (!d_scalars || !d_bases_xy)) || !d_out_xy || !d_out_inf) return DVP_EINVAL;
+  return msm_affine_dev(d_scalars, d_bases_xy, d_bases_inf, n, d_out_xy, d_out_inf, (hipStream_t)stream);
+}
+
+extern "C" int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n,
+                              uint64_t out_xy[8], int* out_is_infinity) {
+  if ((n && (!scalars || !bases_xy)) || !out_xy || !out_is_infinity) return DVP_EINVAL;
+  DevBuf ds, db, di, dout;
+  DVP_TRY(ds.alloc(n * 32));
+  DVP_TRY(db.alloc(n * 64));
+  DVP_TRY(dout.alloc(64 + 16));
+  if (n) {
+    DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+    DVP_HIP(hipMemcpy(db.p, bases_xy, n * 64, hipMemcpyHostToDevice));
+  }
+  if (bases_inf && n) {
+    DVP_TRY(di.alloc(n));
+    DVP_HIP(hipMemcpy(di.p, bases_inf, n, hipMemcpyHostToDevice));
+  }
+  DVP_TRY(msm_affine_dev(ds.p, db.p, di.p, n, dout.p, (char*)dout.p + 64, 0));
+  uint32_t inf;
+  DVP_HIP(hipMemcpy(out_xy, dout.p, 64, hipMemcpyDeviceToHost));
+  DVP_HIP(hipMemcpy(&inf, (char*)dout.p + 64, 4, hipMemcpyDeviceToHost));
+  *out_is_infinity = (int)inf;
+  return DVP_OK;
+}
