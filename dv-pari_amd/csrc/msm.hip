@@ -25,64 +25,9 @@
 
 #include "common.h"
 #include "k233.cuh"
+#include "tau.cuh"
 
 namespace dvp {
-
-// ---- tau-adic recoding constants (derived in oracle/pyref.py: tau_constants()) ------------------
-// delta = D0 + D1*tau, N(delta) = r;  conj(delta) = (D0 - D1) - D1*tau;  A_i = floor(|conj_i| 2^256 / r)
-__constant__ uint32_t TAU_D0[4] = {0xba75bb3bu, 0xda32c0f4u, 0x2dcb0ed1u, 0x00032540u};
-__constant__ uint32_t TAU_D1[4] = {0xcb36bee6u, 0x16aa143cu, 0x2d7ae36eu, 0x000882d7u};
-__constant__ uint32_t TAU_C0M[4] = {0x10c103abu, 0x3c775348u, 0xffafd49cu, 0x00055d96u};  // D1 - D0
-__constant__ uint32_t TAU_A0[5] = {0x55720891u, 0x90218207u, 0x3878eea6u, 0x2dff5fa9u, 0x00000abbu};
-__constant__ uint32_t TAU_A1[5] = {0xcb1ecea9u, 0x79966d7du, 0xdc2d5428u, 0xae5af5c6u, 0x00001105u};
-constexpr int TAU_DIGITS = 240;  // observed maximum over 1e5 random scalars + edge cases: 236
-
-// out[0..no) = low `no` limbs of a[0..na) * b[0..nb)
-template <int NA, int NB, int NO>
-__device__ __forceinline__ void mp_mul_lo(const uint32_t* a, const uint32_t* b, uint32_t* out) {
-#pragma unroll
-  for (int i = 0; i < NO; ++i) out[i] = 0;
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      if (i + j < NO) {
-        c += (uint64_t)a[i] * b[j] + out[i + j];
-        out[i + j] = (uint32_t)c;
-        c >>= 32;
-      }
-    }
-    if (i + NB < NO) out[i + NB] = (uint32_t)c;
-  }
-}
-
-// Q = round(s * A / 2^256), s: 8 limbs, A: 5 limbs -> 4 limbs (value < 2^117)
-__device__ __forceinline__ void tau_round_mul(const uint32_t* s, const uint32_t* A, uint32_t* Q) {
-  uint32_t t[13];
-#pragma unroll
-  for (int i = 0; i < 13; ++i) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      c += (uint64_t)s[i] * A[j] + t[i + j];
-      t[i + j] = (uint32_t)c;
-      c >>= 32;
-    }
-    t[i + 5] = (uint32_t)c;
-  }
-  // + 2^255, then >> 256
-  uint64_t c = (uint64_t)t[7] + 0x80000000u;
-  c >>= 32;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    c += t[8 + i];
-    Q[i] = (uint32_t)c;
-    c >>= 32;
-  }
-}
 
 // One thread per scalar: digits[w][i] (c-bit patterns) + bucket histogram.
 // Scalars >= r are rejected (flag); points flagged infinite contribute nothing.
@@ -95,58 +40,12 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
 #pragma unroll
   for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
   bool skip = inf && inf[i];
-  {
-    // canonical check: s < r  (r == Fr modulus)
-    const uint32_t p[8] = {0xf173abdfu, 0x6efb1ad5u, 0xb915bcd4u, 0x00069d5bu, 0, 0, 0, 0x00000080u};
-    uint64_t borrow = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint64_t t = (uint64_t)s[k] - p[k] - borrow;
-      borrow = (t >> 63) & 1;
-    }
-    if (!borrow) {
-      atomicMin(err, (unsigned long long)i);
-      skip = true;
-    }
+  if (!tau_scalar_is_canonical(s)) {
+    atomicMin(err, (unsigned long long)i);
+    skip = true;
   }
-  uint32_t Q0[4], Q1[4];
-  tau_round_mul(s, TAU_A0, Q0);
-  tau_round_mul(s, TAU_A1, Q1);
-  // rho0 = s + Q0*D0 - 2*Q1*D1 ; rho1 = Q0*D1 - Q1*(D1-D0)      (mod 2^160, two's complement)
-  uint32_t r0[5], r1[5], t0[5], t1[5];
-  mp_mul_lo<4, 4, 5>(Q0, TAU_D0, t0);
-  mp_mul_lo<4, 4, 5>(Q1, TAU_D1, t1);
-  {
-    uint64_t cy = 0;
-    int64_t bw = 0;
-    uint32_t acc[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {  // s + t0
-      cy += (uint64_t)s[k] + t0[k];
-      acc[k] = (uint32_t)cy;
-      cy >>= 32;
-    }
-    uint32_t prev = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {  // - 2*t1
-      uint32_t d = (t1[k] << 1) | prev;
-      prev = t1[k] >> 31;
-      int64_t v = (int64_t)acc[k] - d + bw;
-      r0[k] = (uint32_t)v;
-      bw = v >> 32;
-    }
-  }
-  mp_mul_lo<4, 4, 5>(Q0, TAU_D1, t0);
-  mp_mul_lo<4, 4, 5>(Q1, TAU_C0M, t1);
-  {
-    int64_t bw = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      int64_t v = (int64_t)t0[k] - t1[k] + bw;
-      r1[k] = (uint32_t)v;
-      bw = v >> 32;
-    }
-  }
+  uint32_t r0[5], r1[5];
+  tau_partial_reduce(s, r0, r1);
   if (skip) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
@@ -155,22 +54,7 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
   uint32_t dig = 0;
   int bitpos = 0, w = 0;
   for (int step = 0; step < W * c; ++step) {
-    uint32_t u = r0[0] & 1u;
-    dig |= u << bitpos;
-    uint32_t h[5];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) h[k] = (r0[k] >> 1) | (r0[k + 1] << 31);
-    h[4] = (uint32_t)((int32_t)r0[4] >> 1);
-    int64_t b1 = 0, b2 = 0;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      int64_t v = (int64_t)r1[k] - h[k] + b1;
-      r0[k] = (uint32_t)v;
-      b1 = v >> 32;
-      int64_t z = (int64_t)0 - h[k] + b2;
-      r1[k] = (uint32_t)z;
-      b2 = z >> 32;
-    }
+    dig |= tau_step(r0, r1) << bitpos;
     if (++bitpos == c) {
       digits[(size_t)w * n + i] = (uint16_t)dig;
       if (dig) atomicAdd(&hist[((uint32_t)w << c) + dig], 1u);

@@ -31,3 +31,55 @@ def multi_scalar_mul(scalars: np.ndarray, points_xy: np.ndarray, points_inf: np.
 
 def multi_scalar_mul_dev(d_scalars: int, d_bases: int, d_inf: int, n: int, d_out_xy: int, d_out_inf: int, stream: int = 0):
     check(lib.dvp_msm_affine_dev(d_scalars, d_bases, d_inf, n, d_out_xy, d_out_inf, stream), "dvp_msm_affine_dev")
+
+
+def point_scalar_mul_gen_batch(scalars: np.ndarray):
+    """point_scalar_mul_gen over a vector (src/curve.rs:129-137, loops at src/srs.rs:130-160).
+    Returns (xy [n,8], inf [n])."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = s.shape[0]
+    xy = np.zeros((n, 8), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    check(lib.dvp_mulgen_batch_affine(ptr(s), n, ptr(xy), ptr(inf)), "dvp_mulgen_batch_affine")
+    return xy, inf
+
+
+def point_scalar_mul_gen_batch_bytes(scalars: np.ndarray) -> np.ndarray:
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = s.shape[0]
+    out = np.zeros((n, 30), dtype=np.uint8)
+    check(lib.dvp_mulgen_batch(ptr(s), n, ptr(out)), "dvp_mulgen_batch")
+    return out
+
+
+def to_bytes(points_xy: np.ndarray, points_inf: np.ndarray = None) -> np.ndarray:
+    """CurvePoint::to_bytes over a vector, src/curve.rs:93-100."""
+    b = np.ascontiguousarray(points_xy, dtype=np.uint64).reshape(-1, 8)
+    n = b.shape[0]
+    inf_p = None
+    if points_inf is not None:
+        pi = np.ascontiguousarray(points_inf, dtype=np.uint8)
+        inf_p = ptr(pi)
+    out = np.zeros((n, 30), dtype=np.uint8)
+    check(lib.dvp_points_encode(ptr(b), inf_p, n, ptr(out)), "dvp_points_encode")
+    return out
+
+
+def from_bytes(enc: np.ndarray):
+    """CurvePoint::from_bytes over a vector, src/curve.rs:103-109; raises DvpError(DVP_EDECODE)
+    on an invalid encoding (the reference asserts, src/io_utils.rs:223)."""
+    e = np.ascontiguousarray(enc, dtype=np.uint8).reshape(-1, 30)
+    n = e.shape[0]
+    xy = np.zeros((n, 8), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    check(lib.dvp_points_decode(ptr(e), n, ptr(xy), ptr(inf)), "dvp_points_decode")
+    return xy, inf
+
+
+def multi_scalar_mul_bytes(scalars32: np.ndarray, bases30: np.ndarray) -> bytes:
+    s = np.ascontiguousarray(scalars32, dtype=np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(bases30, dtype=np.uint8).reshape(-1, 30)
+    assert s.shape[0] == b.shape[0]
+    out = np.zeros(30, dtype=np.uint8)
+    check(lib.dvp_msm_xsk233(ptr(s), ptr(b), s.shape[0], ptr(out)), "dvp_msm_xsk233")
+    return out.tobytes()
