@@ -21,6 +21,7 @@
 #include <vector>
 #include <map>
 #include <mutex>
+#include <cstring>
 
 #include "common.h"
 #include "fr.cuh"
@@ -220,7 +221,9 @@ struct dvp_ecfft {
   std::vector<Fr> x0, t;        // per layer, Montgomery (host copies)
   std::map<int, MatSet> mats;   // key = sl*2 + to_even
   std::map<int, Fr*> xnn;       // key = sl ; (N>>sl) entries: leaf^((N>>sl)/2)
-  Fr* scratch = nullptr;        // 2 x N Fr work space for enter/exit
+  Fr* scratch = nullptr;        // 6 x N Fr work space for enter/exit
+  Fr* d_x0 = nullptr;           // device copies of x0/t (Montgomery)
+  Fr* d_t = nullptr;
   std::mutex mu;
 
   Fr* layer(int d) const { return layers + layer_off[d]; }
@@ -374,6 +377,7 @@ extern "C" int dvp_ecfft_create(uint32_t log_n, int shifted, uint32_t base_log, 
   return DVP_OK;
 }
 
+static void free_exit_tables(dvp_ecfft* c);
 extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   if (!c) return;
   (void)hipFree(c->layers);
@@ -383,6 +387,9 @@ extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   }
   for (auto& kv : c->xnn) (void)hipFree(kv.second);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->d_x0) (void)hipFree(c->d_x0);
+  if (c->d_t) (void)hipFree(c->d_t);
+  free_exit_tables(c);
   delete c;
 }
 
@@ -435,43 +442,314 @@ extern "C" int dvp_ecfft_extend(dvp_ecfft* c, const uint64_t* evals, uint32_t ba
   return DVP_OK;
 }
 
+// ---- enter / exit on the stride-2^sl0 subtree (M = N >> sl0 leaves) ------------------------------------
+static int ensure_scratch(dvp_ecfft* c) {
+  if (!c->scratch) DVP_HIP(hipMalloc((void**)&c->scratch, (size_t)6 * c->n_leaves * sizeof(Fr)));
+  return DVP_OK;
+}
+
 // enter: bottom-up over recursion depth k (sub-problem size sz = N>>k on the stride-2^k subtree).
-// All 2^k sub-problems of a depth share the subtree, so each depth is ONE batched extend
-// (batch 2^(k+1), vectors of sz/2) plus one combine kernel.
-extern "C" int dvp_ecfft_enter_dev(dvp_ecfft* c, const void* d_coeffs, void* d_out, void* stream) {
-  if (!c || !d_coeffs || !d_out) return DVP_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
-  const uint32_t N = c->n_leaves;
-  if (!c->scratch) DVP_HIP(hipMalloc((void**)&c->scratch, (size_t)2 * N * sizeof(Fr)));
-  Fr* even = c->scratch;      // evaluations on the even leaves (inputs of this depth)
-  Fr* odd = c->scratch + N;   // their extension to the odd leaves
-  // depth log_n: N sub-problems of size 1: evaluation == coefficient
-  DVP_HIP(hipMemcpyAsync(even, d_coeffs, (size_t)N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-  for (int k = c->log_n - 1; k >= 0; --k) {
-    uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << k;
-    DVP_HIP(hipMemcpyAsync(odd, even, (size_t)N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+// All sub-problems of a depth share the subtree, so each depth is ONE batched extend
+// (batch 2*nsub, vectors of sz/2) plus one combine kernel.
+static int enter_core(dvp_ecfft* c, int sl0, const Fr* d_coeffs, Fr* d_out, hipStream_t st) {
+  const uint32_t N = c->n_leaves, M = N >> sl0;
+  DVP_TRY(ensure_scratch(c));
+  Fr* even = c->scratch;
+  Fr* odd = c->scratch + M;
+  Fr* tmp = c->scratch + 2 * (size_t)M;
+  DVP_HIP(hipMemcpyAsync(even, d_coeffs, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  for (int k = c->log_n - 1; k >= sl0; --k) {
+    uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0);
+    DVP_HIP(hipMemcpyAsync(odd, even, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     DVP_TRY(extend_inplace(c, k, 0, odd, 2 * nsub, st));
     Fr* xnn;
     DVP_TRY(get_xnn(c, k, &xnn, st));
-    Fr* dst = (k == 0) ? (Fr*)d_out : even;
-    // combine reads even/odd and writes `dst`; when dst == even we go through d_out as a bounce
-    Fr* tmp = (Fr*)d_out;
-    hipLaunchKernelGGL(k_enter_combine, dim3(cdiv(nsub * h, TPB)), dim3(TPB), 0, st, even, odd, xnn, tmp, h, nsub * h);
+    Fr* dst = (k == sl0) ? d_out : tmp;
+    hipLaunchKernelGGL(k_enter_combine, dim3(cdiv(nsub * h, TPB)), dim3(TPB), 0, st, even, odd, xnn, dst, h, nsub * h);
     DVP_HIP(hipGetLastError());
-    if (dst != tmp) DVP_HIP(hipMemcpyAsync(dst, tmp, (size_t)N * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    if (k != sl0) { Fr* t = even; even = tmp; tmp = t; }
+  }
+  if (c->log_n == sl0) DVP_HIP(hipMemcpyAsync(d_out, even, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  return DVP_OK;
+}
+
+namespace dvp {
+// Z_0(x) = U - c0 V through the first kk isogenies (x Montgomery in, Montgomery out)
+__device__ __forceinline__ Fr vanish_chain(Fr x, const Fr* __restrict__ x0s, const Fr* __restrict__ ts, int kk, Fr c0) {
+  Fr u = x, v = fr_one_mont();
+  for (int d = 0; d < kk; ++d) {
+    Fr x0 = x0s[d], t = ts[d];
+    Fr uv = fr_mul(u, v), vv = fr_sqr(v);
+    Fr nu = fr_add(fr_sub(fr_sqr(u), fr_mul(x0, uv)), fr_mul(t, vv));
+    Fr nv = fr_sub(uv, fr_mul(x0, vv));
+    u = nu;
+    v = nv;
+  }
+  return fr_sub(u, fr_mul(c0, v));
+}
+
+// exit tables of the stride-2^sl subtree: xinv[i] = 1/xnn[2i], z0inv[i] = 1/Z_0(leaf 2i+1)
+__global__ void __launch_bounds__(256)
+k_exit_tables(const Fr* __restrict__ L0, int sl, uint32_t h, const Fr* __restrict__ xnn, const Fr* __restrict__ x0s,
+              const Fr* __restrict__ ts, int kk, const Fr* __restrict__ c0p, Fr* __restrict__ xinv, Fr* __restrict__ z0inv) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h) return;
+  xinv[i] = fr_inv(xnn[2 * i]);
+  Fr leaf = L0[(size_t)(2 * i + 1) << sl];
+  z0inv[i] = fr_inv(vanish_chain(leaf, x0s, ts, kk, *c0p));
+}
+
+// t0[c*h+i] = ev[c*sz+2i] * xinv[i]
+__global__ void __launch_bounds__(256)
+k_exit_pre(const Fr* __restrict__ ev, const Fr* __restrict__ xinv, Fr* __restrict__ t0, uint32_t h, uint32_t total) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  uint32_t c = tid / h, i = tid - c * h;
+  t0[tid] = fr_mul(xinv[i], ev[(size_t)c * 2 * h + 2 * i]);
+}
+// h1[c*h+i] = (ev[c*sz+2i+1] - g1[c*h+i]*xnn[2i+1]) * z0inv[i]
+__global__ void __launch_bounds__(256)
+k_exit_mid(const Fr* __restrict__ ev, const Fr* __restrict__ g1, const Fr* __restrict__ xnn, const Fr* __restrict__ z0inv,
+           Fr* __restrict__ h1, uint32_t h, uint32_t total) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  uint32_t c = tid / h, i = tid - c * h;
+  Fr d = fr_sub(ev[(size_t)c * 2 * h + 2 * i + 1], fr_mul(xnn[2 * i + 1], g1[tid]));
+  h1[tid] = fr_mul(z0inv[i], d);
+}
+// out[c*sz+2i] = h0*ctab[2i], out[c*sz+2i+1] = h1*ctab[2i+1]
+__global__ void __launch_bounds__(256)
+k_exit_mulc(const Fr* __restrict__ h0, const Fr* __restrict__ h1, const Fr* __restrict__ ctab, Fr* __restrict__ out,
+            uint32_t h, uint32_t total) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  uint32_t c = tid / h, i = tid - c * h;
+  size_t o = (size_t)c * 2 * h + 2 * i;
+  out[o] = fr_mul(ctab[2 * i], h0[tid]);
+  out[o + 1] = fr_mul(ctab[2 * i + 1], h1[tid]);
+}
+// next[(2c)*h+i] = u0 ; next[(2c+1)*h+i] = (ev[c*sz+2i] - u0) * xinv[i]
+__global__ void __launch_bounds__(256)
+k_exit_post(const Fr* __restrict__ ev, const Fr* __restrict__ u0, const Fr* __restrict__ xinv, Fr* __restrict__ next,
+            uint32_t h, uint32_t total) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= total) return;
+  uint32_t c = tid / h, i = tid - c * h;
+  Fr u = u0[tid];
+  next[(size_t)(2 * c) * h + i] = u;
+  next[(size_t)(2 * c + 1) * h + i] = fr_mul(xinv[i], fr_sub(ev[(size_t)c * 2 * h + 2 * i], u));
+}
+
+// helpers for the z0z0 bootstrap
+__global__ void __launch_bounds__(256) k_neg_from_mont_even(const Fr* __restrict__ xnn, Fr* __restrict__ out, uint32_t h) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < h) out[i] = fr_neg(fr_from_mont(xnn[2 * i]));
+}
+__global__ void __launch_bounds__(256) k_mul_canon(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ out, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fr_mul(fr_to_mont(a[i]), b[i]);  // canonical product
+}
+// rho[j] = A[j] + (j >= h/2 ? 2*B[j-h/2] : 0), j < h ; rho[h..2h) = 0
+__global__ void __launch_bounds__(256) k_rho(const Fr* __restrict__ A, const Fr* __restrict__ B, Fr* __restrict__ rho, uint32_t h) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * h) return;
+  Fr r = fr_zero();
+  if (j < h) {
+    r = A[j];
+    if (j >= h / 2) r = fr_add(r, fr_dbl(B[j - h / 2]));
+  }
+  rho[j] = r;
+}
+__global__ void __launch_bounds__(256) k_to_mont(const Fr* __restrict__ in, Fr* __restrict__ out, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fr_to_mont(in[i]);
+}
+// h == 1: c[0] = c[1] = s0^2 (Montgomery)
+__global__ void k_c_base(const Fr* __restrict__ L0, Fr* __restrict__ ctab) {
+  Fr s = fr_sqr(L0[0]);
+  ctab[0] = s;
+  ctab[1] = s;
+}
+}  // namespace dvp
+
+struct ExitTab {
+  Fr* xinv = nullptr;   // h
+  Fr* z0inv = nullptr;  // h
+  Fr* ctab = nullptr;   // sz, <Z_0^2 mod X^h> on the subtree (Montgomery)
+};
+static std::map<dvp_ecfft*, std::map<int, ExitTab>> g_exit_tabs;  // per ctx, per stride level
+static std::mutex g_exit_mu;
+
+static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStream_t st);
+
+// Build (once) the exit tables of every stride level >= sl, deepest first.
+static int ensure_exit_tables(dvp_ecfft* c, int sl_min, hipStream_t st) {
+  const uint32_t N = c->n_leaves;
+  if (!c->d_x0) {
+    DVP_HIP(hipMalloc((void**)&c->d_x0, c->log_n * sizeof(Fr)));
+    DVP_HIP(hipMalloc((void**)&c->d_t, c->log_n * sizeof(Fr)));
+    DVP_HIP(hipMemcpy(c->d_x0, c->x0.data(), c->log_n * sizeof(Fr), hipMemcpyHostToDevice));
+    DVP_HIP(hipMemcpy(c->d_t, c->t.data(), c->log_n * sizeof(Fr), hipMemcpyHostToDevice));
+  }
+  for (int sl = c->log_n - 1; sl >= sl_min; --sl) {
+    {
+      std::lock_guard<std::mutex> g(g_exit_mu);
+      if (g_exit_tabs[c].count(sl)) continue;
+    }
+    uint32_t sz = N >> sl, h = sz >> 1;
+    int kk = 31 - __builtin_clz(h);  // h = 2^kk even leaves -> kk isogenies collapse them
+    ExitTab tb;
+    DVP_HIP(hipMalloc((void**)&tb.xinv, (size_t)h * sizeof(Fr)));
+    DVP_HIP(hipMalloc((void**)&tb.z0inv, (size_t)h * sizeof(Fr)));
+    DVP_HIP(hipMalloc((void**)&tb.ctab, (size_t)sz * sizeof(Fr)));
+    Fr* xnn;
+    DVP_TRY(get_xnn(c, sl, &xnn, st));
+    // the even leaves of the stride-2^sl tree all map to layer-kk leaf 0 of the strided tree = layers[kk][0]
+    hipLaunchKernelGGL(k_exit_tables, dim3(cdiv(h, TPB)), dim3(TPB), 0, st, c->layer(0), sl, h, xnn, c->d_x0, c->d_t, kk,
+                       c->layer(kk), tb.xinv, tb.z0inv);
+    if (h == 1) {
+      hipLaunchKernelGGL(k_c_base, dim3(1), dim3(1), 0, st, c->layer(0), tb.ctab);
+    } else {
+      // (1) z = Z_0 - X^h in coefficient form: exit on the even subtree of the evaluations -leaf^h
+      DevBuf zlow, lo, hi, A, B, rho;
+      DVP_TRY(zlow.alloc((size_t)h * sizeof(Fr)));
+      DVP_TRY(lo.alloc((size_t)h * sizeof(Fr)));
+      DVP_TRY(hi.alloc((size_t)h * sizeof(Fr)));
+      DVP_TRY(A.alloc((size_t)h * sizeof(Fr)));
+      DVP_TRY(B.alloc((size_t)h * sizeof(Fr)));
+      DVP_TRY(rho.alloc((size_t)sz * sizeof(Fr)));
+      hipLaunchKernelGGL(k_neg_from_mont_even, dim3(cdiv(h, TPB)), dim3(TPB), 0, st, xnn, lo.as<Fr>(), h);
+      DVP_TRY(exit_core(c, sl + 1, lo.as<Fr>(), zlow.as<Fr>(), st));
+      // (2) z = z_lo + X^(h/2) z_hi;  Z_0^2 mod X^h = z_lo^2 + 2 X^(h/2) (z_lo z_hi mod X^(h/2))
+      DVP_HIP(hipMemsetAsync(lo.p, 0, (size_t)h * sizeof(Fr), st));
+      DVP_HIP(hipMemsetAsync(hi.p, 0, (size_t)h * sizeof(Fr), st));
+      DVP_HIP(hipMemcpyAsync(lo.p, zlow.p, (size_t)(h / 2) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+      DVP_HIP(hipMemcpyAsync(hi.p, zlow.as<Fr>() + h / 2, (size_t)(h / 2) * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+      DVP_TRY(enter_core(c, sl + 1, lo.as<Fr>(), A.as<Fr>(), st));  // <z_lo> on the even subtree
+      DVP_TRY(enter_core(c, sl + 1, hi.as<Fr>(), B.as<Fr>(), st));  // <z_hi>
+      hipLaunchKernelGGL(k_mul_canon, dim3(cdiv(h, TPB)), dim3(TPB), 0, st, A.as<Fr>(), B.as<Fr>(), hi.as<Fr>(), h);  // <z_lo z_hi>
+      hipLaunchKernelGGL(k_mul_canon, dim3(cdiv(h, TPB)), dim3(TPB), 0, st, A.as<Fr>(), A.as<Fr>(), lo.as<Fr>(), h);  // <z_lo^2>
+      DVP_TRY(exit_core(c, sl + 1, lo.as<Fr>(), A.as<Fr>(), st));
+      DVP_TRY(exit_core(c, sl + 1, hi.as<Fr>(), B.as<Fr>(), st));
+      hipLaunchKernelGGL(k_rho, dim3(cdiv(sz, TPB)), dim3(TPB), 0, st, A.as<Fr>(), B.as<Fr>(), rho.as<Fr>(), h);
+      // (3) evaluate on the whole subtree, keep in Montgomery form
+      DevBuf ev;
+      DVP_TRY(ev.alloc((size_t)sz * sizeof(Fr)));
+      DVP_TRY(enter_core(c, sl, rho.as<Fr>(), ev.as<Fr>(), st));
+      hipLaunchKernelGGL(k_to_mont, dim3(cdiv(sz, TPB)), dim3(TPB), 0, st, ev.as<Fr>(), tb.ctab, sz);
+      DVP_HIP(hipGetLastError());
+      DVP_HIP(hipStreamSynchronize(st));  // DevBufs go out of scope
+    }
+    DVP_HIP(hipGetLastError());
+    std::lock_guard<std::mutex> g(g_exit_mu);
+    g_exit_tabs[c][sl] = tb;
   }
   return DVP_OK;
 }
 
-extern "C" int dvp_ecfft_enter(dvp_ecfft* c, const uint64_t* coeffs, uint64_t* out) {
-  if (!c || !coeffs || !out) return DVP_EINVAL;
+// exit: top-down.  At depth k every sub-problem (sz evaluations on the stride-2^k subtree) is split into
+// the evaluations of its low and high coefficient halves on the even subtree:
+//   u = <P mod X^h> = redc(redc(P) * <Z_0^2 mod X^h>),   redc(P) = <P Z_0^-1 mod X^h>  (Montgomery-style)
+//   lo <- u|even,   hi <- (P|even - u|even) / X^h|even
+static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStream_t st) {
+  const uint32_t N = c->n_leaves, M = N >> sl0;
+  if (M == 1) {
+    DVP_HIP(hipMemcpyAsync(d_out, d_evals, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    return DVP_OK;
+  }
+  DVP_TRY(ensure_exit_tables(c, sl0, st));
+  DVP_TRY(ensure_scratch(c));
+  Fr* S = c->scratch;
+  Fr* cur = S;                        // M
+  Fr* t0 = S + (size_t)M;             // M/2  (also g1)
+  Fr* h1 = S + (size_t)M + M / 2;     // M/2
+  Fr* h0 = S + 2 * (size_t)M;         // M/2
+  Fr* r1 = S + 3 * (size_t)M;         // M
+  Fr* nxt = S + 4 * (size_t)M;        // M
+  DVP_HIP(hipMemcpyAsync(cur, d_evals, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  for (int k = sl0; k < c->log_n; ++k) {
+    uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0), total = nsub * h;
+    ExitTab tb;
+    {
+      std::lock_guard<std::mutex> g(g_exit_mu);
+      tb = g_exit_tabs[c][k];
+    }
+    Fr* xnn;
+    DVP_TRY(get_xnn(c, k, &xnn, st));
+    dim3 grid(cdiv(total, TPB)), blk(TPB);
+    auto redc = [&](const Fr* ev) -> int {  // leaves h0 (even part) and h1 (odd part)
+      hipLaunchKernelGGL(k_exit_pre, grid, blk, 0, st, ev, tb.xinv, t0, h, total);
+      DVP_TRY(extend_inplace(c, k, 0, t0, nsub, st));
+      hipLaunchKernelGGL(k_exit_mid, grid, blk, 0, st, ev, t0, xnn, tb.z0inv, h1, h, total);
+      DVP_HIP(hipMemcpyAsync(h0, h1, (size_t)total * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+      DVP_TRY(extend_inplace(c, k, 1, h0, nsub, st));
+      return DVP_OK;
+    };
+    DVP_TRY(redc(cur));
+    hipLaunchKernelGGL(k_exit_mulc, grid, blk, 0, st, h0, h1, tb.ctab, r1, h, total);
+    DVP_TRY(redc(r1));
+    hipLaunchKernelGGL(k_exit_post, grid, blk, 0, st, cur, h0, tb.xinv, nxt, h, total);
+    DVP_HIP(hipGetLastError());
+    Fr* t = cur; cur = nxt; nxt = t;
+  }
+  DVP_HIP(hipMemcpyAsync(d_out, cur, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  return DVP_OK;
+}
+
+extern "C" int dvp_ecfft_enter_dev(dvp_ecfft* c, const void* d_coeffs, void* d_out, void* stream) {
+  if (!c || !d_coeffs || !d_out) return DVP_EINVAL;
+  return enter_core(c, 0, (const Fr*)d_coeffs, (Fr*)d_out, (hipStream_t)stream);
+}
+extern "C" int dvp_ecfft_exit_dev(dvp_ecfft* c, const void* d_evals, void* d_out, void* stream) {
+  if (!c || !d_evals || !d_out) return DVP_EINVAL;
+  return exit_core(c, 0, (const Fr*)d_evals, (Fr*)d_out, (hipStream_t)stream);
+}
+
+static int host_roundtrip(dvp_ecfft* c, const uint64_t* in, uint64_t* out, bool is_exit) {
+  if (!c || !in || !out) return DVP_EINVAL;
   size_t bytes = (size_t)c->n_leaves * sizeof(Fr);
-  DevBuf in, o;
-  DVP_TRY(in.alloc(bytes));
+  DevBuf i, o;
+  DVP_TRY(i.alloc(bytes));
   DVP_TRY(o.alloc(bytes));
-  DVP_HIP(hipMemcpy(in.p, coeffs, bytes, hipMemcpyHostToDevice));
-  DVP_TRY(check_canonical_dev(in.as<Fr>(), c->n_leaves, 0));
-  DVP_TRY(dvp_ecfft_enter_dev(c, in.p, o.p, 0));
+  DVP_HIP(hipMemcpy(i.p, in, bytes, hipMemcpyHostToDevice));
+  DVP_TRY(check_canonical_dev(i.as<Fr>(), c->n_leaves, 0));
+  DVP_TRY(is_exit ? exit_core(c, 0, i.as<Fr>(), o.as<Fr>(), 0) : enter_core(c, 0, i.as<Fr>(), o.as<Fr>(), 0));
   DVP_HIP(hipMemcpy(out, o.p, bytes, hipMemcpyDeviceToHost));
   return DVP_OK;
+}
+extern "C" int dvp_ecfft_enter(dvp_ecfft* c, const uint64_t* coeffs, uint64_t* out) { return host_roundtrip(c, coeffs, out, false); }
+extern "C" int dvp_ecfft_exit(dvp_ecfft* c, const uint64_t* evals, uint64_t* out) { return host_roundtrip(c, evals, out, true); }
+
+// Z_D(x) (which = 0: even leaves) or Z_D'(x) (which = 1: odd leaves); host-side chain, O(log N) field ops
+extern "C" int dvp_ecfft_vanish_at(const dvp_ecfft* c, int which, const uint64_t x[4], uint64_t out[4]) {
+  if (!c || !x || !out || (which != 0 && which != 1)) return DVP_EINVAL;
+  Fr xc;
+  memcpy(xc.v, x, 32);
+  if (!fr_is_canonical(xc)) return DVP_EINVAL;
+  int kk = c->log_n - 1;
+  Fr cpt[2];  // the two leaves of layer kk (Montgomery): even leaves collapse to [0], odd leaves to [1]
+  DVP_HIP(hipMemcpy(cpt, c->layer(kk), 2 * sizeof(Fr), hipMemcpyDeviceToHost));
+  Fr u = fr_to_mont(xc), v = fr_one_mont();
+  for (int d = 0; d < kk; ++d) {
+    Fr uv = fr_mul(u, v), vv = fr_sqr(v);
+    Fr nu = fr_add(fr_sub(fr_sqr(u), fr_mul(c->x0[d], uv)), fr_mul(c->t[d], vv));
+    Fr nv = fr_sub(uv, fr_mul(c->x0[d], vv));
+    u = nu;
+    v = nv;
+  }
+  Fr z = fr_from_mont(fr_sub(u, fr_mul(cpt[which], v)));
+  memcpy(out, z.v, 32);
+  return DVP_OK;
+}
+
+static void free_exit_tables(dvp_ecfft* c) {
+  std::lock_guard<std::mutex> g(g_exit_mu);
+  auto it = g_exit_tabs.find(c);
+  if (it == g_exit_tabs.end()) return;
+  for (auto& kv : it->second) {
+    (void)hipFree(kv.second.xinv);
+    (void)hipFree(kv.second.z0inv);
+    (void)hipFree(kv.second.ctab);
+  }
+  g_exit_tabs.erase(it);
 }

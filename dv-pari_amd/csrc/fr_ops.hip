@@ -1,0 +1,157 @@
+// Fr vector kernels of the prover (HBM-bound scans over m-length vectors):
+//   ark_ff::batch_inversion                              src/proving.rs:604,614; src/ec_fft.rs:482
+//   evaluate_poly_at_alpha_using_barycentric_weights     src/ec_fft.rs:455-491 (called 3x, src/proving.rs:571-591)
+// Algorithmic bytes: batch inverse 64 B/element (read + write); barycentric 96 B/element.
+#include <cstring>
+
+#include "common.h"
+#include "fr.cuh"
+
+namespace dvp {
+
+constexpr int INV_CHUNK = 16;  // elements per thread sharing one Fermat inversion
+
+// in-place element-wise inverse of canonical values; zeros stay zero (ark semantics).
+// Each thread owns INV_CHUNK strided elements (coalesced across the wave): prefix products,
+// one inversion, back-substitution -> 3 multiplications + 1/16 inversion per element (+2 conversions).
+__global__ void __launch_bounds__(256) k_batch_inverse(Fr* __restrict__ v, size_t n) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  Fr x[INV_CHUNK], pre[INV_CHUNK];
+  Fr acc = fr_one_mont();
+#pragma unroll
+  for (int k = 0; k < INV_CHUNK; ++k) {
+    size_t i = t + (size_t)k * stride;
+    Fr e = (i < n) ? v[i] : fr_zero();
+    bool z = fr_is_zero(e);
+    x[k] = z ? fr_one_mont() : fr_to_mont(e);
+    pre[k] = acc;
+    acc = fr_mul(acc, x[k]);
+    if (z) x[k] = fr_zero();  // marker: output zero
+  }
+  Fr inv = fr_inv(acc);
+#pragma unroll
+  for (int k = INV_CHUNK - 1; k >= 0; --k) {
+    size_t i = t + (size_t)k * stride;
+    bool z = fr_is_zero(x[k]);
+    Fr xi = z ? fr_one_mont() : x[k];
+    Fr r = fr_mul(inv, pre[k]);
+    inv = fr_mul(inv, xi);
+    if (i < n) v[i] = z ? fr_zero() : fr_from_mont(r);
+  }
+}
+
+// partial[b] = sum over the block's elements of y_i * w_i / (alpha - s_i)   (Montgomery partials)
+// domain / weights canonical or Montgomery per flags; evals canonical.
+__global__ void __launch_bounds__(256)
+k_bary_partial(const Fr* __restrict__ dom, const Fr* __restrict__ wts, const Fr* __restrict__ ev, size_t n, Fr alpha_m,
+               int tables_mont, Fr* __restrict__ partial) {
+  __shared__ Fr sh[256];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  Fr d[INV_CHUNK], pre[INV_CHUNK];
+  Fr acc = fr_one_mont();
+#pragma unroll
+  for (int k = 0; k < INV_CHUNK; ++k) {
+    size_t i = t + (size_t)k * stride;
+    Fr s = fr_zero();
+    if (i < n) s = tables_mont ? dom[i] : fr_to_mont(dom[i]);
+    d[k] = (i < n) ? fr_sub(alpha_m, s) : fr_one_mont();
+    pre[k] = acc;
+    acc = fr_mul(acc, d[k]);
+  }
+  Fr inv = fr_inv(acc);
+  Fr sum = fr_zero();
+#pragma unroll
+  for (int k = INV_CHUNK - 1; k >= 0; --k) {
+    size_t i = t + (size_t)k * stride;
+    Fr di = fr_mul(inv, pre[k]);  // 1/(alpha - s_i), Montgomery
+    inv = fr_mul(inv, d[k]);
+    if (i < n) {
+      Fr w = tables_mont ? wts[i] : fr_to_mont(wts[i]);
+      Fr term = fr_mul(fr_mul(w, di), fr_to_mont(ev[i]));
+      sum = fr_add(sum, term);
+    }
+  }
+  sh[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// out = z_alpha * sum(partials), canonical
+__global__ void __launch_bounds__(256) k_bary_final(const Fr* __restrict__ partial, uint32_t nb, Fr z_alpha_m, Fr* __restrict__ out) {
+  __shared__ Fr sh[256];
+  Fr s = fr_zero();
+  for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = fr_from_mont(fr_mul(sh[0], z_alpha_m));
+}
+
+int batch_inverse_dev(Fr* d, size_t n, hipStream_t st) {
+  if (!n) return DVP_OK;
+  size_t threads = (n + INV_CHUNK - 1) / INV_CHUNK;
+  hipLaunchKernelGGL(k_batch_inverse, dim3(cdiv(threads, 256)), dim3(256), 0, st, d, n);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+
+// d_out: one Fr (canonical).  d_partial: >= cdiv(n,256*INV_CHUNK) Fr of scratch.
+int barycentric_dev(const Fr* dom, const Fr* wts, const Fr* ev, size_t n, Fr alpha_m, Fr z_alpha_m, int tables_mont,
+                    Fr* d_partial, Fr* d_out, hipStream_t st) {
+  size_t threads = (n + INV_CHUNK - 1) / INV_CHUNK;
+  uint32_t nb = cdiv(threads, 256);
+  hipLaunchKernelGGL(k_bary_partial, dim3(nb), dim3(256), 0, st, dom, wts, ev, n, alpha_m, tables_mont, d_partial);
+  hipLaunchKernelGGL(k_bary_final, dim3(1), dim3(256), 0, st, d_partial, nb, z_alpha_m, d_out);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+
+}  // namespace dvp
+
+using namespace dvp;
+
+extern "C" int dvp_fr_batch_inverse_dev(void* d_vals, size_t n, void* stream) {
+  if (n && !d_vals) return DVP_EINVAL;
+  return batch_inverse_dev((Fr*)d_vals, n, (hipStream_t)stream);
+}
+
+extern "C" int dvp_fr_batch_inverse(uint64_t* vals, size_t n) {
+  if (!n) return DVP_OK;
+  if (!vals) return DVP_EINVAL;
+  DevBuf b;
+  DVP_TRY(b.alloc(n * sizeof(Fr)));
+  DVP_HIP(hipMemcpy(b.p, vals, n * sizeof(Fr), hipMemcpyHostToDevice));
+  DVP_TRY(batch_inverse_dev(b.as<Fr>(), n, 0));
+  DVP_HIP(hipMemcpy(vals, b.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+
+extern "C" int dvp_barycentric_eval(const uint64_t* domain, const uint64_t* bar_weights, const uint64_t z_at_alpha[4],
+                                    const uint64_t* evals, size_t n, const uint64_t alpha[4], uint64_t out[4]) {
+  if (!domain || !bar_weights || !z_at_alpha || !evals || !alpha || !out || !n) return DVP_EINVAL;
+  DevBuf d, w, e, part, o;
+  DVP_TRY(d.alloc(n * sizeof(Fr)));
+  DVP_TRY(w.alloc(n * sizeof(Fr)));
+  DVP_TRY(e.alloc(n * sizeof(Fr)));
+  DVP_TRY(part.alloc((n / (256 * INV_CHUNK) + 2) * sizeof(Fr)));
+  DVP_TRY(o.alloc(sizeof(Fr)));
+  DVP_HIP(hipMemcpy(d.p, domain, n * sizeof(Fr), hipMemcpyHostToDevice));
+  DVP_HIP(hipMemcpy(w.p, bar_weights, n * sizeof(Fr), hipMemcpyHostToDevice));
+  DVP_HIP(hipMemcpy(e.p, evals, n * sizeof(Fr), hipMemcpyHostToDevice));
+  Fr a, z;
+  memcpy(a.v, alpha, 32);
+  memcpy(z.v, z_at_alpha, 32);
+  if (!fr_is_canonical(a) || !fr_is_canonical(z)) return DVP_EINVAL;
+  DVP_TRY(barycentric_dev(d.as<Fr>(), w.as<Fr>(), e.as<Fr>(), n, fr_to_mont(a), fr_to_mont(z), 0, part.as<Fr>(), o.as<Fr>(), 0));
+  DVP_HIP(hipMemcpy(out, o.p, sizeof(Fr), hipMemcpyDeviceToHost));
+  return DVP_OK;
+}

@@ -1,0 +1,133 @@
+"""ctypes loader for the C oracle (oracle/dvp_oracle.c).  ORACLE = test infrastructure: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libdvp_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "dvp_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libdvp_oracle.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        _lib.dvo_msm.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]
+        _lib.dvo_msm.restype = C.c_int
+        _lib.dvo_k233_mul.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
+        _lib.dvo_k233_mulgen.argtypes = [vp, vp, C.POINTER(C.c_int)]
+        _lib.dvo_k233_add.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
+        _lib.dvo_tau_digits.argtypes = [vp, vp]
+        _lib.dvo_tau_digits.restype = C.c_int
+        _lib.dvo_xsk233_encode.argtypes = [vp, C.c_int, vp]
+        _lib.dvo_xsk233_decode.argtypes = [vp, vp, C.POINTER(C.c_int)]
+        _lib.dvo_xsk233_decode.restype = C.c_int
+        for f in ("dvo_gf_mul",):
+            getattr(_lib, f).argtypes = [vp, vp, vp]
+        for f in ("dvo_gf_sqr", "dvo_gf_inv"):
+            getattr(_lib, f).argtypes = [vp, vp]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _limbs(v, n=4):
+    return np.frombuffer(int(v).to_bytes(8 * n, "little"), dtype="<u8").copy()
+
+
+def _int(a):
+    return int.from_bytes(np.ascontiguousarray(a, dtype="<u8").tobytes(), "little")
+
+
+def gf_mul(a, b):
+    o = np.zeros(4, dtype=np.uint64)
+    lib().dvo_gf_mul(_p(_limbs(a)), _p(_limbs(b)), _p(o))
+    return _int(o)
+
+
+def gf_sqr(a):
+    o = np.zeros(4, dtype=np.uint64)
+    lib().dvo_gf_sqr(_p(_limbs(a)), _p(o))
+    return _int(o)
+
+
+def gf_inv(a):
+    o = np.zeros(4, dtype=np.uint64)
+    lib().dvo_gf_inv(_p(_limbs(a)), _p(o))
+    return _int(o)
+
+
+def _pt_out(o, inf):
+    return None if inf.value else (_int(o[:4]), _int(o[4:]))
+
+
+def _pt_in(pt):
+    if pt is None:
+        return np.zeros(8, dtype=np.uint64), 1
+    return np.concatenate([_limbs(pt[0]), _limbs(pt[1])]), 0
+
+
+def k233_mul(k, pt, frob=True):
+    a, inf = _pt_in(pt)
+    o = np.zeros(8, dtype=np.uint64)
+    oi = C.c_int(0)
+    lib().dvo_k233_mul(_p(_limbs(k)), _p(a), inf, 1 if frob else 0, _p(o), C.byref(oi))
+    return _pt_out(o, oi)
+
+
+def k233_mulgen(k):
+    o = np.zeros(8, dtype=np.uint64)
+    oi = C.c_int(0)
+    lib().dvo_k233_mulgen(_p(_limbs(k)), _p(o), C.byref(oi))
+    return _pt_out(o, oi)
+
+
+def tau_digits(k):
+    d = np.zeros(260, dtype=np.uint8)
+    n = lib().dvo_tau_digits(_p(_limbs(k)), _p(d))
+    return [int(x) for x in d[:n]]
+
+
+def msm(scalars: np.ndarray, bases: np.ndarray, inf: np.ndarray = None, threads: int = 1):
+    """scalars [n,4] u64, bases [n,8] u64 -> (point or None).  Reference shape: src/curve.rs:141-158."""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    b = np.ascontiguousarray(bases, dtype=np.uint64)
+    ip = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        ip = _p(inf)
+    o = np.zeros(8, dtype=np.uint64)
+    oi = C.c_int(0)
+    lib().dvo_msm(_p(s), _p(b), ip, s.shape[0], threads, _p(o), C.byref(oi))
+    return _pt_out(o, oi)
+
+
+def xsk233_encode(pt) -> bytes:
+    a, inf = _pt_in(pt)
+    o = np.zeros(30, dtype=np.uint8)
+    lib().dvo_xsk233_encode(_p(a), inf, _p(o))
+    return o.tobytes()
+
+
+def xsk233_decode(buf: bytes):
+    i = np.frombuffer(buf, dtype=np.uint8).copy()
+    o = np.zeros(8, dtype=np.uint64)
+    oi = C.c_int(0)
+    ok = lib().dvo_xsk233_decode(_p(i), _p(o), C.byref(oi))
+    return (_pt_out(o, oi) if ok else None), bool(ok)

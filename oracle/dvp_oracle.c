@@ -1,0 +1,426 @@
+/*
+ * ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C CPU restatement of the DV-Pari curve hot path with the REFERENCE'S ALGORITHMIC SHAPE:
+ * multi_scalar_mul = one independent Frobenius-based scalar multiplication per (scalar, point)
+ * followed by an add tree (src/curve.rs:141-158: "For now we just compute individual point scalar
+ * multiplications and sum up the result").  The per-point arithmetic of the reference lives in
+ * xs233-sys =0.2.0 (xsk233_mul_frob, src/curve.rs:118-123), which is not in the tree; it is restated
+ * here from the mathematics (K-233 Lopez-Dahab formulas, tau-adic windowed multiplication,
+ * PCLMULQDQ field arithmetic) and pinned against OpenSSL vectors (tests/golden/k233_openssl.json)
+ * and the Python big-int oracle (oracle/pyref.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * It is the "port" CPU baseline -- labelled a restatement, not the Rust binary.
+ *
+ * Build: gcc -O3 -mpclmul -msse4.1 -fPIC -shared -pthread dvp_oracle.c -o _build/libdvp_oracle.so
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <wmmintrin.h>
+#include <smmintrin.h>
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+typedef struct { u64 w[4]; } gf;
+
+/* ------------------------------------------------------------------------------------------- */
+/* GF(2^233) = GF(2)[z]/(z^233+z^74+1), 4 x u64 little-endian                                   */
+/* ------------------------------------------------------------------------------------------- */
+static inline gf gf_zero(void) { gf r = {{0, 0, 0, 0}}; return r; }
+static inline gf gf_one(void) { gf r = {{1, 0, 0, 0}}; return r; }
+static inline gf gf_add(gf a, gf b) { gf r; for (int i = 0; i < 4; ++i) r.w[i] = a.w[i] ^ b.w[i]; return r; }
+static inline int gf_is_zero(gf a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+static inline int gf_eq(gf a, gf b) { return gf_is_zero(gf_add(a, b)); }
+
+static inline gf gf_reduce8(u64 c[8]) {
+  for (int j = 7; j >= 4; --j) {
+    u64 t = c[j];
+    c[j - 4] ^= t << 23;
+    c[j - 3] ^= (t >> 41) ^ (t << 33);
+    c[j - 2] ^= t >> 31;
+  }
+  u64 t = c[3] >> 41;
+  c[0] ^= t;
+  c[1] ^= t << 10;
+  c[3] &= ((u64)1 << 41) - 1;
+  gf r = {{c[0], c[1], c[2], c[3]}};
+  return r;
+}
+
+static inline gf gf_mul(gf a, gf b) {
+  u64 c[8] = {0};
+  for (int i = 0; i < 4; ++i) {
+    __m128i ai = _mm_cvtsi64_si128((long long)a.w[i]);
+    for (int j = 0; j < 4; ++j) {
+      __m128i r = _mm_clmulepi64_si128(ai, _mm_cvtsi64_si128((long long)b.w[j]), 0);
+      c[i + j] ^= (u64)_mm_cvtsi128_si64(r);
+      c[i + j + 1] ^= (u64)_mm_extract_epi64(r, 1);
+    }
+  }
+  return gf_reduce8(c);
+}
+
+static inline gf gf_sqr(gf a) {
+  u64 c[8];
+  for (int i = 0; i < 4; ++i) {
+    __m128i ai = _mm_cvtsi64_si128((long long)a.w[i]);
+    __m128i r = _mm_clmulepi64_si128(ai, ai, 0);
+    c[2 * i] = (u64)_mm_cvtsi128_si64(r);
+    c[2 * i + 1] = (u64)_mm_extract_epi64(r, 1);
+  }
+  return gf_reduce8(c);
+}
+
+static gf gf_sqr_n(gf a, int n) { while (n-- > 0) a = gf_sqr(a); return a; }
+
+static gf gf_inv(gf a) { /* Itoh-Tsujii, a^(2^233-2) */
+  gf b1 = a;
+  gf b2 = gf_mul(gf_sqr(b1), b1);
+  gf b3 = gf_mul(gf_sqr(b2), b1);
+  gf b6 = gf_mul(gf_sqr_n(b3, 3), b3);
+  gf b7 = gf_mul(gf_sqr(b6), b1);
+  gf b14 = gf_mul(gf_sqr_n(b7, 7), b7);
+  gf b28 = gf_mul(gf_sqr_n(b14, 14), b14);
+  gf b29 = gf_mul(gf_sqr(b28), b1);
+  gf b58 = gf_mul(gf_sqr_n(b29, 29), b29);
+  gf b116 = gf_mul(gf_sqr_n(b58, 58), b58);
+  gf b232 = gf_mul(gf_sqr_n(b116, 116), b116);
+  return gf_sqr(b232);
+}
+static gf gf_sqrt(gf a) { return gf_sqr_n(a, 232); }
+static inline int gf_trace(gf a) { return (int)((a.w[0] ^ (a.w[2] >> 31)) & 1); } /* bits 0 and 159 */
+static gf gf_halftrace(gf c) {
+  gf h = c, x = c;
+  for (int i = 0; i < 116; ++i) { x = gf_sqr(gf_sqr(x)); h = gf_add(h, x); }
+  return h;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* K-233: y^2+xy = x^3+1.  Lopez-Dahab projective (x=X/Z, y=Y/Z^2), Z==0 is infinity.           */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct { gf x, y; int inf; } aff;
+typedef struct { gf X, Y, Z; } ld;
+
+static ld ld_inf(void) { ld r = {gf_one(), gf_zero(), gf_zero()}; return r; }
+static ld ld_from_aff(aff a) { ld r; if (a.inf) return ld_inf(); r.X = a.x; r.Y = a.y; r.Z = gf_one(); return r; }
+static ld ld_dbl(ld p) {
+  gf z1s = gf_sqr(p.Z), x1s = gf_sqr(p.X);
+  ld r;
+  r.Z = gf_mul(x1s, z1s);
+  gf z1q = gf_sqr(z1s);
+  r.X = gf_add(gf_sqr(x1s), z1q);
+  r.Y = gf_add(gf_mul(z1q, r.Z), gf_mul(r.X, gf_add(gf_sqr(p.Y), z1q)));
+  return r;
+}
+static ld ld_madd(ld p, aff q) {
+  if (q.inf) return p;
+  if (gf_is_zero(p.Z)) return ld_from_aff(q);
+  gf z1s = gf_sqr(p.Z);
+  gf A = gf_add(p.Y, gf_mul(q.y, z1s));
+  gf B = gf_add(p.X, gf_mul(q.x, p.Z));
+  if (gf_is_zero(B)) return gf_is_zero(A) ? ld_dbl(ld_from_aff(q)) : ld_inf();
+  gf C = gf_mul(p.Z, B);
+  gf D = gf_mul(gf_sqr(B), C);
+  ld r;
+  r.Z = gf_sqr(C);
+  gf E = gf_mul(A, C);
+  r.X = gf_add(gf_add(gf_sqr(A), D), E);
+  gf F = gf_add(r.X, gf_mul(q.x, r.Z));
+  gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(r.Z));
+  r.Y = gf_add(gf_mul(gf_add(E, r.Z), F), G);
+  return r;
+}
+static ld ld_add(ld p, ld q) {
+  if (gf_is_zero(p.Z)) return q;
+  if (gf_is_zero(q.Z)) return p;
+  gf A1 = gf_mul(q.Y, gf_sqr(p.Z)), A2 = gf_mul(p.Y, gf_sqr(q.Z));
+  gf B1 = gf_mul(q.X, p.Z), B2 = gf_mul(p.X, q.Z);
+  gf C = gf_add(A1, A2), D = gf_add(B1, B2);
+  if (gf_is_zero(D)) return gf_is_zero(C) ? ld_dbl(p) : ld_inf();
+  gf E = gf_mul(p.Z, q.Z), F = gf_mul(D, E);
+  ld r;
+  r.Z = gf_sqr(F);
+  gf Ds = gf_sqr(D), G = gf_mul(Ds, F), H = gf_mul(C, F);
+  r.X = gf_add(gf_add(gf_sqr(C), H), G);
+  gf I = gf_add(gf_mul(gf_mul(Ds, B1), E), r.X);
+  gf J = gf_add(gf_mul(Ds, A1), r.X);
+  r.Y = gf_add(gf_mul(H, I), gf_mul(r.Z, J));
+  return r;
+}
+static aff ld_to_aff(ld p) {
+  aff r;
+  if (gf_is_zero(p.Z)) { r.x = gf_zero(); r.y = gf_zero(); r.inf = 1; return r; }
+  gf zi = gf_inv(p.Z);
+  r.x = gf_mul(p.X, zi);
+  r.y = gf_mul(p.Y, gf_sqr(zi));
+  r.inf = 0;
+  return r;
+}
+static ld ld_frob(ld p) { p.X = gf_sqr(p.X); p.Y = gf_sqr(p.Y); p.Z = gf_sqr(p.Z); return p; }
+
+static const aff K233_G = {
+    {{0x0a4c9d6eefad6126ull, 0x149563a419c26bf5ull, 0x7e731af129f22ff4ull, 0x0000017232ba853aull}},
+    {{0x56e0c11056fae6a3ull, 0x27a8cd9bf18aeb9bull, 0x19b7f70f555a67c4ull, 0x000001db537dece8ull}},
+    0};
+
+/* ---- (1) integer-window double-and-add: the independent cross-check --------------------------- */
+static ld k233_mul_dbl(const u64 k[4], aff p) {
+  /* 4-bit fixed windows, table 1..15 */
+  ld tab[16];
+  tab[0] = ld_inf();
+  tab[1] = ld_from_aff(p);
+  for (int i = 2; i < 16; ++i) tab[i] = ld_madd(tab[i - 1], p);
+  ld acc = ld_inf();
+  for (int i = 63; i >= 0; --i) {
+    for (int d = 0; d < 4; ++d) acc = ld_dbl(acc);
+    unsigned nib = (unsigned)((k[i >> 4] >> ((i & 15) * 4)) & 15);
+    if (nib) acc = ld_add(acc, tab[nib]);
+  }
+  return acc;
+}
+
+/* ---- (2) tau-adic (Frobenius) multiplication: the reference-shaped path ------------------------ */
+/* tau^2 + tau + 2 = 0 (mu = -1).  delta = (tau^233-1)/(tau-1) = D0 + D1 tau, N(delta) = r.
+ * rho = s - round(s*conj(delta)/r)*delta, rounded with 128-bit-limb exact integer arithmetic.       */
+typedef struct { u64 lo, hi; int neg; } s128; /* sign-magnitude 128-bit */
+
+static const u64 R_ORDER[4] = {0x6efb1ad5f173abdfull, 0x00069d5bb915bcd4ull, 0x0000000000000000ull, 0x0000008000000000ull};
+static const u64 TAU_D0[2] = {0xda32c0f4ba75bb3bull, 0x000325402dcb0ed1ull};
+static const u64 TAU_D1[2] = {0x16aa143ccb36bee6ull, 0x000882d72d7ae36eull};
+static const u64 TAU_C0M[2] = {0x3c77534810c103abull, 0x00055d96ffafd49cull}; /* D1 - D0 */
+
+/* small multi-precision helpers on little-endian u64 arrays */
+static void mp_mul(const u64* a, int na, const u64* b, int nb, u64* out) {
+  memset(out, 0, sizeof(u64) * (size_t)(na + nb));
+  for (int i = 0; i < na; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < nb; ++j) {
+      c += (u128)a[i] * b[j] + out[i + j];
+      out[i + j] = (u64)c;
+      c >>= 64;
+    }
+    out[i + nb] = (u64)c;
+  }
+}
+static int mp_cmp(const u64* a, const u64* b, int n) {
+  for (int i = n - 1; i >= 0; --i) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return 0;
+}
+static void mp_sub(u64* a, const u64* b, int n) { /* a -= b */
+  u64 br = 0;
+  for (int i = 0; i < n; ++i) {
+    u128 t = (u128)a[i] - b[i] - br;
+    a[i] = (u64)t;
+    br = (u64)(t >> 64) & 1;
+  }
+}
+/* q = round(num / r), num has 6 limbs (< 2^350), r = R_ORDER (4 limbs); q < 2^120 -> 2 limbs.
+ * Bitwise restoring division (oracle: clarity over speed is fine, it is ~120 steps). */
+static void div_round_r(const u64 num6[6], u64 q[2]) {
+  /* compute floor((2*num + r) / (2r)) */
+  u64 n7[7] = {0}, d5[5] = {0};
+  for (int i = 0; i < 6; ++i) { n7[i] |= num6[i] << 1; n7[i + 1] |= num6[i] >> 63; }
+  { u128 c = 0; for (int i = 0; i < 7; ++i) { c += (u128)n7[i] + (i < 4 ? R_ORDER[i] : 0); n7[i] = (u64)c; c >>= 64; } }
+  for (int i = 0; i < 4; ++i) { d5[i] |= R_ORDER[i] << 1; d5[i + 1] |= R_ORDER[i] >> 63; }
+  q[0] = q[1] = 0;
+  /* quotient < 2^121: try bits 127..0 of shifted divisor */
+  for (int bit = 127; bit >= 0; --bit) {
+    /* sh = d5 << bit, 7+ limbs */
+    u64 sh[8] = {0};
+    int ws = bit >> 6, bs = bit & 63;
+    for (int i = 0; i < 5; ++i) {
+      if (i + ws < 8) sh[i + ws] |= d5[i] << bs;
+      if (bs && i + ws + 1 < 8) sh[i + ws + 1] |= d5[i] >> (64 - bs);
+    }
+    if (sh[7]) continue;
+    if (mp_cmp(n7, sh, 7) >= 0) { mp_sub(n7, sh, 7); q[bit >> 6] |= (u64)1 << (bit & 63); }
+  }
+}
+
+/* signed 192-bit two's complement helpers for the digit expansion */
+typedef struct { u64 w[3]; } i192;
+static i192 i192_from_mag(const u64* m, int n, int neg) {
+  i192 r = {{0, 0, 0}};
+  for (int i = 0; i < n && i < 3; ++i) r.w[i] = m[i];
+  if (neg) { u128 c = 1; for (int i = 0; i < 3; ++i) { c += (u64)~r.w[i]; r.w[i] = (u64)c; c >>= 64; } }
+  return r;
+}
+static i192 i192_add(i192 a, i192 b) { i192 r; u128 c = 0; for (int i = 0; i < 3; ++i) { c += (u128)a.w[i] + b.w[i]; r.w[i] = (u64)c; c >>= 64; } return r; }
+static i192 i192_neg(i192 a) { i192 r; u128 c = 1; for (int i = 0; i < 3; ++i) { c += (u64)~a.w[i]; r.w[i] = (u64)c; c >>= 64; } return r; }
+static i192 i192_sub(i192 a, i192 b) { return i192_add(a, i192_neg(b)); }
+static i192 i192_sar1(i192 a) { i192 r; r.w[0] = (a.w[0] >> 1) | (a.w[1] << 63); r.w[1] = (a.w[1] >> 1) | (a.w[2] << 63); r.w[2] = (u64)((int64_t)a.w[2] >> 1); return r; }
+static int i192_is_zero(i192 a) { return (a.w[0] | a.w[1] | a.w[2]) == 0; }
+
+/* tau-adic {0,1} digits of s (mod r); returns the number of digits (<= 256) */
+static int tau_digits(const u64 s[4], unsigned char* dig) {
+  /* Q0 = round(s*|c0|/r), Q1 = round(s*|c1|/r); conj(delta) = (D0-D1) - D1 tau, both negative */
+  u64 n0[6], n1[6], Q0[2], Q1[2];
+  mp_mul(s, 4, TAU_C0M, 2, n0);
+  mp_mul(s, 4, TAU_D1, 2, n1);
+  div_round_r(n0, Q0);
+  div_round_r(n1, Q1);
+  /* rho0 = s + Q0*D0 - 2*Q1*D1 ; rho1 = Q0*D1 - Q1*(D1-D0)   (mod 2^192) */
+  u64 a[4], b[4], c[4], d[4];
+  mp_mul(Q0, 2, TAU_D0, 2, a);
+  mp_mul(Q1, 2, TAU_D1, 2, b);
+  mp_mul(Q0, 2, TAU_D1, 2, c);
+  mp_mul(Q1, 2, TAU_C0M, 2, d);
+  i192 S = i192_from_mag(s, 3, 0), A = i192_from_mag(a, 3, 0), B = i192_from_mag(b, 3, 0);
+  i192 C = i192_from_mag(c, 3, 0), D = i192_from_mag(d, 3, 0);
+  i192 r0 = i192_sub(i192_add(S, A), i192_add(B, B));
+  i192 r1 = i192_sub(C, D);
+  int n = 0;
+  while (!(i192_is_zero(r0) && i192_is_zero(r1)) && n < 256) {
+    unsigned u = (unsigned)(r0.w[0] & 1);
+    dig[n++] = (unsigned char)u;
+    i192 h = i192_sar1(r0);
+    r0 = i192_sub(r1, h);
+    r1 = i192_neg(h);
+  }
+  return n;
+}
+
+/* s*P by width-4 windows over the tau-adic digits, Frobenius between windows */
+static ld k233_mul_frob(const u64 k[4], aff p) {
+  unsigned char dig[260];
+  memset(dig, 0, sizeof dig);
+  int n = tau_digits(k, dig);
+  if (n == 0 || p.inf) return ld_inf();
+  /* table T[d] = sum_t d_t tau^t(P), d = 1..15 */
+  aff f[4];
+  f[0] = p;
+  for (int t = 1; t < 4; ++t) { f[t].x = gf_sqr(f[t - 1].x); f[t].y = gf_sqr(f[t - 1].y); f[t].inf = 0; }
+  ld tab[16];
+  tab[0] = ld_inf();
+  for (int d = 1; d < 16; ++d) {
+    int t = 31 - __builtin_clz((unsigned)d);
+    tab[d] = ld_madd(tab[d ^ (1 << t)], f[t]);
+  }
+  int nw = (n + 3) / 4;
+  ld acc = ld_inf();
+  for (int w = nw - 1; w >= 0; --w) {
+    for (int t = 0; t < 4; ++t) acc = ld_frob(acc);
+    unsigned d = dig[4 * w] | (dig[4 * w + 1] << 1) | (dig[4 * w + 2] << 2) | (dig[4 * w + 3] << 3);
+    if (d) acc = ld_add(acc, tab[d]);
+  }
+  return acc;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* exported API (ctypes): points are x||y as 8 x u64 + an int/byte infinity flag               */
+/* ------------------------------------------------------------------------------------------- */
+static aff aff_load(const u64* xy, int inf) {
+  aff a;
+  memcpy(a.x.w, xy, 32);
+  memcpy(a.y.w, xy + 4, 32);
+  a.inf = inf;
+  return a;
+}
+static void aff_store(aff a, u64* xy, int* inf) {
+  memcpy(xy, a.x.w, 32);
+  memcpy(xy + 4, a.y.w, 32);
+  if (inf) *inf = a.inf;
+}
+
+void dvo_gf_mul(const u64 a[4], const u64 b[4], u64 out[4]) { gf x, y; memcpy(x.w, a, 32); memcpy(y.w, b, 32); gf r = gf_mul(x, y); memcpy(out, r.w, 32); }
+void dvo_gf_sqr(const u64 a[4], u64 out[4]) { gf x; memcpy(x.w, a, 32); gf r = gf_sqr(x); memcpy(out, r.w, 32); }
+void dvo_gf_inv(const u64 a[4], u64 out[4]) { gf x; memcpy(x.w, a, 32); gf r = gf_inv(x); memcpy(out, r.w, 32); }
+
+/* which: 0 = integer double-and-add, 1 = tau-adic */
+void dvo_k233_mul(const u64 k[4], const u64 pxy[8], int pinf, int which, u64 out[8], int* out_inf) {
+  aff p = aff_load(pxy, pinf);
+  ld r = which ? k233_mul_frob(k, p) : (p.inf ? ld_inf() : k233_mul_dbl(k, p));
+  aff_store(ld_to_aff(r), out, out_inf);
+}
+void dvo_k233_mulgen(const u64 k[4], u64 out[8], int* out_inf) {
+  ld r = k233_mul_frob(k, K233_G);
+  aff_store(ld_to_aff(r), out, out_inf);
+}
+void dvo_k233_add(const u64 a[8], int ainf, const u64 b[8], int binf, u64 out[8], int* out_inf) {
+  ld r = ld_madd(ld_from_aff(aff_load(a, ainf)), aff_load(b, binf));
+  aff_store(ld_to_aff(r), out, out_inf);
+}
+int dvo_tau_digits(const u64 k[4], unsigned char* dig) { return tau_digits(k, dig); }
+
+/* multi_scalar_mul, src/curve.rs:141-158: independent scalar multiplications + add tree */
+typedef struct {
+  const u64 *scalars, *bases;
+  const unsigned char* inf;
+  size_t lo, hi;
+  ld partial;
+} msm_job;
+
+static void* msm_worker(void* arg) {
+  msm_job* j = (msm_job*)arg;
+  ld acc = ld_inf();
+  for (size_t i = j->lo; i < j->hi; ++i) {
+    aff p = aff_load(j->bases + 8 * i, j->inf ? j->inf[i] : 0);
+    ld t = k233_mul_frob(j->scalars + 4 * i, p); /* point_scalar_mul, src/curve.rs:113-126 */
+    acc = ld_add(acc, t);                        /* reduce(xsk233_add), src/curve.rs:150-157 */
+  }
+  j->partial = acc;
+  return NULL;
+}
+
+int dvo_msm(const u64* scalars, const u64* bases, const unsigned char* inf, size_t n, int threads, u64 out[8], int* out_inf) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  msm_job jobs[256];
+  pthread_t th[256];
+  size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].scalars = scalars; jobs[t].bases = bases; jobs[t].inf = inf;
+    jobs[t].lo = (size_t)t * per < n ? (size_t)t * per : n;
+    jobs[t].hi = (size_t)(t + 1) * per < n ? (size_t)(t + 1) * per : n;
+    pthread_create(&th[t], NULL, msm_worker, &jobs[t]);
+  }
+  ld acc = ld_inf();
+  for (int t = 0; t < threads; ++t) { pthread_join(th[t], NULL); acc = ld_add(acc, jobs[t].partial); }
+  aff_store(ld_to_aff(acc), out, out_inf);
+  return 0;
+}
+
+/* ---- xsk233 codec candidate (same rule as oracle/pyref.py; PARITY UNPINNED) -------------------- */
+static int k233_in_subgroup(aff p) {
+  if (p.inf) return 1;
+  if (gf_is_zero(p.x) || gf_trace(p.x)) return 0;
+  gf lam = gf_halftrace(p.x);
+  gf u2 = gf_add(p.y, gf_mul(gf_add(lam, gf_one()), p.x));
+  return gf_trace(u2) == 0;
+}
+void dvo_xsk233_encode(const u64 xy[8], int inf, unsigned char out[30]) {
+  gf w = gf_zero();
+  if (!inf) {
+    aff p = aff_load(xy, 0);
+    w = gf_sqrt(gf_add(gf_add(p.x, gf_mul(p.y, gf_inv(p.x))), gf_one()));
+  }
+  unsigned char buf[32];
+  memcpy(buf, w.w, 32);
+  memcpy(out, buf, 30);
+}
+int dvo_xsk233_decode(const unsigned char in[30], u64 xy[8], int* inf) {
+  unsigned char buf[32] = {0};
+  memcpy(buf, in, 30);
+  gf w;
+  memcpy(w.w, buf, 32);
+  memset(xy, 0, 64);
+  *inf = 1;
+  if (w.w[3] >> 41) return 0;
+  if (gf_is_zero(w)) return 1;
+  gf w2 = gf_sqr(w), e = gf_add(w2, w);
+  if (gf_is_zero(e)) return 0;
+  gf cst = gf_sqr(gf_inv(e));
+  if (gf_trace(cst)) return 0;
+  gf z = gf_halftrace(cst), lam = gf_add(w2, gf_one());
+  for (int k = 0; k < 2; ++k) {
+    aff c;
+    c.x = gf_mul(e, k ? gf_add(z, gf_one()) : z);
+    c.y = gf_mul(c.x, gf_add(lam, c.x));
+    c.inf = 0;
+    if (k233_in_subgroup(c)) { aff_store(c, xy, inf); return 1; }
+  }
+  return 0;
+}

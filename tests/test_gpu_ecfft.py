@@ -1,0 +1,158 @@
+"""GPU parity tests (-m gpu): ECFFT extend / enter / exit and the Fr vector kernels through the C ABI,
+bit-exact against the oracle at small sizes, and through size-independent identities at the
+BASELINE sizes (config #3: 2^20 coefficients; the prover's extend at m = 2^20)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyref as o
+from util import to_limbs, from_limbs, rand_fr_np
+
+pytestmark = pytest.mark.gpu
+VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+
+
+def H(s):
+    return int(s, 16)
+
+
+@pytest.fixture(scope="module")
+def big_tree(dvp):
+    return dvp.ec_fft.FFTree(1 << 21)
+
+
+def test_leaves_and_golden(dvp):
+    for key in ("4", "6"):
+        g = VEC["ecfft"][key]
+        t = dvp.ec_fft.FFTree(1 << int(key))
+        assert [hex(x) for x in from_limbs(t.leaves())] == g["leaves"]
+        out = t.extend(to_limbs([H(x) for x in g["extend_in"]]))
+        assert [hex(x) for x in from_limbs(out)] == g["extend_out"]
+        ent = t.enter(to_limbs([H(x) for x in g["coeffs"]]))
+        assert [hex(x) for x in from_limbs(ent)] == g["enter_out"]
+        assert [hex(x) for x in from_limbs(t.exit(ent))] == g["coeffs"]
+    ts = dvp.ec_fft.FFTree(16, True, 5)
+    assert [hex(x) for x in from_limbs(ts.leaves())] == VEC["ecfft"]["4_shifted_base5"]["leaves"]
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 5, 8])
+def test_extend_enter_exit_vs_oracle(dvp, log_n):
+    rnd = random.Random(log_n)
+    t = dvp.ec_fft.FFTree(1 << log_n)
+    ot = o.FFTree(log_n)
+    assert from_limbs(t.leaves()) == ot.leaves()
+    m = (1 << log_n) // 2
+    for batch in (1, 3, 4):
+        ev = [rnd.randrange(o.P) for _ in range(batch * m)]
+        out = t.extend(to_limbs(ev).reshape(batch, m, 4))
+        for b in range(batch):
+            assert from_limbs(out[b]) == ot.extend(ev[b * m:(b + 1) * m])
+    c = [rnd.randrange(o.P) for _ in range(1 << log_n)]
+    e = t.enter(to_limbs(c))
+    assert from_limbs(e) == ot.enter(c)
+    assert from_limbs(t.exit(e)) == c
+    ev = [rnd.randrange(o.P) for _ in range(1 << log_n)]
+    assert from_limbs(t.exit(to_limbs(ev))) == ot.exit(ev)
+
+
+def test_edge_vectors(dvp):
+    t = dvp.ec_fft.FFTree(64)
+    z = np.zeros((32, 4), dtype=np.uint64)
+    assert not t.extend(z).any()
+    top = to_limbs([o.P - 1] * 32)
+    assert from_limbs(t.extend(top)) == [o.P - 1] * 32  # constant polynomial
+    bad = to_limbs([o.P] + [0] * 31)  # non-canonical input is rejected, with its index
+    with pytest.raises(dvp.DvpError) as ei:
+        t.extend(bad)
+    assert ei.value.status == -1 and ei.value.index == 0
+
+
+def test_vanish_at(dvp, nat):
+    import ctypes as C
+    t = dvp.ec_fft.FFTree(64)
+    ot = o.FFTree(6)
+    d, d2 = ot.both_domains()
+    for which, dom in ((0, d), (1, d2)):
+        z = o.poly_from_roots(dom)
+        for x in (5, dom[3], o.P - 2):
+            out = np.zeros(4, dtype=np.uint64)
+            dvp.check(dvp.lib.dvp_ecfft_vanish_at(t._h, which, nat.ptr(to_limbs([x])), nat.ptr(out)))
+            assert from_limbs(out[None])[0] == o.poly_eval(z, x)
+
+
+def test_batch_inverse_and_barycentric(dvp, nat):
+    rnd = random.Random(9)
+    vals = [rnd.randrange(o.P) for _ in range(1000)]
+    vals[7] = 0
+    vals[999] = 0
+    a = to_limbs(vals)
+    dvp.check(dvp.lib.dvp_fr_batch_inverse(nat.ptr(a), len(vals)))
+    assert from_limbs(a) == o.fr_batch_inverse(vals)
+    ot = o.FFTree(6)
+    tb = o.domain_tables(ot)
+    ev = [rnd.randrange(o.P) for _ in range(tb["m"])]
+    alpha = rnd.randrange(o.P)
+    z_alpha = o.poly_eval(tb["z_poly"], alpha)
+    out = np.zeros(4, dtype=np.uint64)
+    dvp.check(dvp.lib.dvp_barycentric_eval(nat.ptr(to_limbs(tb["D"])), nat.ptr(to_limbs(tb["bar_wts"])), nat.ptr(to_limbs([z_alpha])),
+                                           nat.ptr(to_limbs(ev)), tb["m"], nat.ptr(to_limbs([alpha])), nat.ptr(out)))
+    exp = o.barycentric_eval(tb["D"], tb["bar_wts"], z_alpha, ev, alpha)
+    assert from_limbs(out[None])[0] == exp == o.lagrange_eval(tb["D"], ev, alpha)
+
+
+def test_extend_full_size_properties(dvp, big_tree):
+    """m = 2^20 (the prover's extend, src/proving.rs:410-422): degree-1 polynomial, linearity."""
+    m = 1 << 20
+    leaves = big_tree.leaves()
+    d, d2 = from_limbs(leaves[0:64:2]), from_limbs(leaves[1:64:2])
+    all_d = leaves[0::2]
+    # P(x) = a + b x on D  ->  must come out as a + b x on D'
+    a, b = 1234567, 7654321
+    # evaluate a + b*d_i with numpy object ints only on a sample; build the full vector on the GPU side by
+    # linearity: extend(const a) + b * extend(d)  ==  extend(a + b d)
+    x = np.ascontiguousarray(all_d)
+    ext_d = big_tree.extend(x)  # extend of the identity polynomial P(x) = x
+    assert from_limbs(ext_d[:32]) == d2
+    assert from_limbs(ext_d[-3:]) == from_limbs(leaves[-5::2])
+    r1, r2 = rand_fr_np(m, 1), rand_fr_np(m, 2)
+    s = to_limbs([(p + q) % o.P for p, q in zip(from_limbs(r1[:4096]), from_limbs(r2[:4096]))])
+    both = big_tree.extend(np.stack([r1, r2]))
+    # linearity on a prefix is not meaningful (extend is global), so check it on full vectors of a smaller tree
+    t = dvp.ec_fft.FFTree(1 << 13)
+    e = t.extend(np.stack([r1[:4096], r2[:4096], s]))
+    assert from_limbs(e[2]) == [(p + q) % o.P for p, q in zip(from_limbs(e[0]), from_limbs(e[1]))]
+    assert both.shape == (2, m, 4)
+
+
+def test_enter_exit_roundtrip_2_20(dvp):
+    """BASELINE config #3: 2^20 coefficients, enter then exit, exact round trip; monomial spot checks."""
+    n = 1 << 20
+    t = dvp.ec_fft.FFTree(n)
+    c = rand_fr_np(n, 3)
+    e = t.enter(c)
+    back = t.exit(e)
+    assert (back == c).all()
+    # enter of a X^j + b X^k is a L^j + b L^k on every leaf: check 64 random leaves
+    rnd = random.Random(4)
+    j, k, a, b = rnd.randrange(n), rnd.randrange(n), rnd.randrange(o.P), rnd.randrange(o.P)
+    sp = np.zeros((n, 4), dtype=np.uint64)
+    sp[j] = to_limbs([a])[0]
+    sp[k] = to_limbs([b])[0]
+    ev = t.enter(sp)
+    leaves = t.leaves()
+    for idx in [0, 1, n - 1] + [rnd.randrange(n) for _ in range(61)]:
+        L = from_limbs(leaves[idx][None])[0]
+        assert from_limbs(ev[idx][None])[0] == (a * pow(L, j, o.P) + b * pow(L, k, o.P)) % o.P
+
+
+def test_extend_consistent_with_enter(dvp):
+    """evaluations of one polynomial (degree < m) on D and D' via enter on the 2m tree must be linked by extend."""
+    t = dvp.ec_fft.FFTree(1 << 12)
+    m = 1 << 11
+    c = np.zeros((2 * m, 4), dtype=np.uint64)
+    c[:m] = rand_fr_np(m, 5)
+    e = t.enter(c)
+    assert (t.extend(np.ascontiguousarray(e[0::2])) == e[1::2]).all()

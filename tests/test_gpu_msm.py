@@ -1,0 +1,125 @@
+"""GPU parity tests (-m gpu): sect233k1 MSM / fixed-base mulgen / codec through the C ABI.
+Bit-exact (affine group elements) against the OpenSSL-pinned C oracle; BASELINE config #2
+(2^16 points) is checked through the discrete-log identity sum s_i (k_i G) = (sum s_i k_i) G,
+exactly the shape of the reference's own test_msm (src/curve.rs:218-232)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyref as o
+import c_oracle as co
+from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod
+
+pytestmark = pytest.mark.gpu
+OSSL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k233_openssl.json")))["vectors"]
+
+
+def H(s):
+    return int(s, 16)
+
+
+def gpu_msm(dvp, scalars, bases, inf=None):
+    xy, is_inf = dvp.curve.multi_scalar_mul(scalars, bases, inf)
+    return np_to_pt(xy, is_inf)
+
+
+def test_mulgen_against_openssl(dvp):
+    ks = [H(e["k"]) for e in OSSL]
+    xy, inf = dvp.curve.point_scalar_mul_gen_batch(to_limbs(ks + [0]))
+    for i, e in enumerate(OSSL):
+        assert np_to_pt(xy[i], inf[i]) == (H(e["x"]), H(e["y"]))
+    assert inf[-1] == 1  # 0 * G = neutral
+
+
+def test_msm_edge_cases(dvp):
+    g = [co.k233_mulgen(k) for k in (1, 2, 3, 4, 5)]
+    G = pts_to_np(g)
+    assert gpu_msm(dvp, to_limbs([1]), G[:1]) == g[0]
+    assert gpu_msm(dvp, to_limbs([o.P - 1]), G[2:3]) == o.k233_neg(g[2])
+    assert gpu_msm(dvp, to_limbs([0, 0, 0]), G[:3]) is None            # all-zero scalars
+    assert gpu_msm(dvp, to_limbs([1, o.P - 1]), G[[3, 3]]) is None     # P + (-P)
+    assert gpu_msm(dvp, to_limbs([1, 1]), G[[3, 3]]) == co.k233_mulgen(8)  # P + P inside one bucket
+    assert gpu_msm(dvp, np.zeros((0, 4), np.uint64), np.zeros((0, 8), np.uint64)) is None  # empty
+    inf = np.array([0, 1, 0], dtype=np.uint8)                              # neutral among the bases
+    assert gpu_msm(dvp, to_limbs([7, 9, 11]), G[:3], inf) == co.k233_mulgen(7 * 1 + 11 * 3)
+    with pytest.raises(dvp.DvpError) as ei:                                 # scalar >= p is rejected
+        gpu_msm(dvp, to_limbs([5, o.P]), G[:2])
+    assert ei.value.status == -1 and ei.value.index == 1
+
+
+def test_msm_all_equal_bases_like_reference(dvp):
+    """test_msm, src/curve.rs:218-232 (10 000 random scalars on G)."""
+    n = 10000
+    s = rand_fr_np(n, 11)
+    G = np.tile(pts_to_np([o.G_STD]), (n, 1))
+    assert gpu_msm(dvp, s, G) == co.k233_mulgen(sum(from_limbs(s)) % o.P)
+
+
+def test_msm_vs_reference_shaped_cpu(dvp):
+    n = 777
+    k, s = rand_fr_np(n, 21), rand_fr_np(n, 22)
+    bases, inf = dvp.curve.point_scalar_mul_gen_batch(k)
+    assert not inf.any()
+    assert gpu_msm(dvp, s, bases) == co.msm(s, bases, threads=4)
+
+
+def test_msm_skewed_scalars(dvp):
+    """many equal / tiny scalars: one bucket receives most points (load-balance path of the reduction)."""
+    n = 5000
+    k = rand_fr_np(n, 31)
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
+    s = np.zeros((n, 4), dtype=np.uint64)
+    s[:, 0] = 1
+    s[::7, 0] = 2
+    s[::11, 0] = 0
+    assert gpu_msm(dvp, s, bases) == co.k233_mulgen(np_dot_mod(s, k))
+
+
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_msm_config2(dvp, log_n):
+    """BASELINE config #2: 2^16 random scalars/bases, bit-exact vs the CPU restatement."""
+    n = 1 << log_n
+    k, s = rand_fr_np(n, 41 + log_n), rand_fr_np(n, 42 + log_n)
+    bases, inf = dvp.curve.point_scalar_mul_gen_batch(k)
+    assert not inf.any()
+    got = gpu_msm(dvp, s, bases)
+    assert got == co.k233_mulgen(np_dot_mod(s, k))
+    if log_n == 12:  # and directly against the per-point scalar-mult + add-tree CPU shape
+        assert got == co.msm(s, bases, threads=8)
+
+
+def test_codec_roundtrip_and_invalid(dvp):
+    ks = [1, 2, 3, 0xDEADBEEF, o.P - 1] + [random.Random(5).randrange(o.P) for _ in range(20)]
+    enc = dvp.curve.point_scalar_mul_gen_batch_bytes(to_limbs(ks + [0]))
+    for i, k in enumerate(ks):
+        assert enc[i].tobytes() == co.xsk233_encode(co.k233_mulgen(k))
+    assert enc[-1].tobytes() == bytes(30)
+    xy, inf = dvp.curve.from_bytes(enc)
+    for i, k in enumerate(ks):
+        assert np_to_pt(xy[i], inf[i]) == co.k233_mulgen(k)
+    assert inf[-1] == 1
+    assert (dvp.curve.to_bytes(xy, inf) == enc).all()
+    rnd = random.Random(6)
+    seen_bad = 0
+    for _ in range(24):
+        w = rnd.getrandbits(233).to_bytes(30, "little")
+        exp, ok = co.xsk233_decode(w)
+        try:
+            x, i_ = dvp.curve.from_bytes(np.frombuffer(w, dtype=np.uint8))
+            assert ok and np_to_pt(x[0], i_[0]) == exp
+        except dvp.DvpError as e:
+            assert not ok and e.status == -2 and e.index == 0
+            seen_bad += 1
+    assert seen_bad > 0
+
+
+def test_msm_wire_format(dvp):
+    """scalars 32-B LE + bases 30-B encodings in, 30-B encoding out (the reference's file payloads)."""
+    n = 300
+    k, s = rand_fr_np(n, 51), rand_fr_np(n, 52)
+    enc = dvp.curve.point_scalar_mul_gen_batch_bytes(k)
+    out = dvp.curve.multi_scalar_mul_bytes(s.view(np.uint8).reshape(n, 32), enc)
+    assert out == co.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)))

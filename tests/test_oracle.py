@@ -1,0 +1,188 @@
+"""CPU tests (-m "not gpu"): pin the oracle before anything is compared against it.
+
+Pins, strongest first:
+  * K-233 group law + scalar multiplication: OpenSSL sect233k1 vectors (third party).
+  * ECFFT extend/enter/exit: the reference's own identities (src/ec_fft.rs:883-907 -- extend ==
+    interpolate-then-evaluate; enter == Horner; exit(enter(c)) == c).
+  * BLAKE3: official test vectors (lengths 0, 1, 1025).
+  * toy R1CS end to end (src/dvsnark_test.rs:131-180): verify == true.
+  * xsk233 30-byte codec: PARITY UNPINNED (no known-answer bytes exist offline); only round-trip and
+    C-vs-Python agreement are checked.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyref as o
+import c_oracle as co
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+OSSL = json.load(open(os.path.join(GOLD, "k233_openssl.json")))["vectors"]
+VEC = json.load(open(os.path.join(GOLD, "oracle_vectors.json")))
+
+
+def H(s):
+    return int(s, 16)
+
+
+def test_gf233_python_and_c_match_golden():
+    for e in VEC["gf233"]:
+        a, b = H(e["a"]), H(e["b"])
+        assert o.gf_mul(a, b) == H(e["mul"]) == co.gf_mul(a, b)
+        assert o.gf_sqr(a) == H(e["sqr"]) == co.gf_sqr(a)
+        assert o.gf_inv(a) == H(e["inv"]) == co.gf_inv(a)
+        assert o.gf_sqrt(a) == H(e["sqrt"])
+        assert o.gf_trace(a) == e["trace"] == o.gf_trace_def(a)
+        assert o.gf_mul(a, o.gf_inv(a)) == 1
+
+
+def test_k233_against_openssl():
+    assert o.k233_on_curve(o.G_STD) and o.k233_mul(o.K233_ORDER, o.G_STD) is None
+    for e in OSSL[:24]:  # python big-int scalar mult is slow; the C oracle covers all 64
+        assert o.k233_mul(H(e["k"]), o.G_STD) == (H(e["x"]), H(e["y"]))
+    for e in OSSL:
+        exp = (H(e["x"]), H(e["y"]))
+        assert co.k233_mulgen(H(e["k"])) == exp
+        assert co.k233_mul(H(e["k"]), o.G_STD, frob=False) == exp  # integer double-and-add
+        assert co.k233_mul(H(e["k"]), o.G_STD, frob=True) == exp   # tau-adic (reference-shaped)
+
+
+def test_msm_linearity_like_reference():
+    """src/curve.rs:198-232: k1 G + k2 G == (k1+k2) G; MSM over equal bases == (sum s) G."""
+    rnd = random.Random(1)
+    n = 64
+    ss = [rnd.randrange(o.P) for _ in range(n)]
+    g = np.array([[(c >> (64 * i)) & (2**64 - 1) for c in o.G_STD for i in range(4)]] * n, dtype=np.uint64)
+    sc = np.array([[(s >> (64 * i)) & (2**64 - 1) for i in range(4)] for s in ss], dtype=np.uint64)
+    assert co.msm(sc, g, threads=2) == co.k233_mulgen(sum(ss) % o.P)
+    m = VEC["msm6"]
+    pts = [co.k233_mulgen(H(k)) for k in m["k"]]
+    b = np.array([[(c >> (64 * i)) & (2**64 - 1) for c in p for i in range(4)] for p in pts], dtype=np.uint64)
+    s6 = np.array([[(H(s) >> (64 * i)) & (2**64 - 1) for i in range(4)] for s in m["s"]], dtype=np.uint64)
+    assert co.msm(s6, b) == (H(m["x"]), H(m["y"]))
+
+
+def test_tau_adic_digits():
+    lam = 0x606590EF0A0A0ABF8D755A2BE31F5449DFFF5B430733472D4910444625
+    assert (lam * lam + lam + 2) % o.P == 0
+    frob_g = (o.gf_sqr(o.G_STD[0]), o.gf_sqr(o.G_STD[1]))
+    assert co.k233_mulgen(lam) == frob_g  # tau(G) = lambda G
+    rnd = random.Random(2)
+    for s in [0, 1, 2, o.P - 1] + [rnd.randrange(o.P) for _ in range(300)]:
+        d = co.tau_digits(s)
+        assert len(d) <= 240
+        assert sum(b * pow(lam, i, o.P) for i, b in enumerate(d)) % o.P == s
+
+
+def test_xsk233_codec_candidate_roundtrip():
+    for e in VEC["xsk233_candidate"]:
+        pt = co.k233_mulgen(H(e["k"]))
+        assert o.xsk233_encode(pt).hex() == e["enc"] == co.xsk233_encode(pt).hex()
+        assert o.xsk233_decode(bytes.fromhex(e["enc"])) == (pt, True)
+        assert co.xsk233_decode(bytes.fromhex(e["enc"])) == (pt, True)
+    assert o.xsk233_decode(bytes(30)) == (None, True)  # neutral (src/io_utils.rs:255-260)
+    rnd = random.Random(3)
+    for _ in range(12):
+        w = rnd.getrandbits(233).to_bytes(30, "little")
+        assert o.xsk233_decode(w) == co.xsk233_decode(w)
+    assert o.xsk233_decode(b"\xff" * 30)[1] is False
+
+
+def test_ecfft_extend_matches_interpolation():
+    """test_interpolate_and_extend_match, src/ec_fft.rs:883-907 (n = 16) + golden freeze."""
+    rnd = random.Random(4)
+    for log_n in (2, 4, 5):
+        t = o.FFTree(log_n)
+        d, d2 = t.both_domains()
+        ev = [rnd.randrange(o.P) for _ in range(len(d))]
+        out = t.extend(ev)
+        for k in range(len(d)):
+            assert out[k] == o.lagrange_eval(d, ev, d2[k])
+        assert t.extend(out, to_even=True) == ev
+    for key in ("4", "6"):
+        g = VEC["ecfft"][key]
+        t = o.FFTree(int(key))
+        assert [hex(x) for x in t.leaves()] == g["leaves"]
+        assert [hex(x) for x in t.extend([H(x) for x in g["extend_in"]])] == g["extend_out"]
+
+
+def test_ecfft_enter_exit():
+    rnd = random.Random(5)
+    for log_n in (1, 3, 5):
+        t = o.FFTree(log_n)
+        n = 1 << log_n
+        c = [rnd.randrange(o.P) for _ in range(n)]
+        e = t.enter(c)
+        assert all(e[k] == o.poly_eval(c, t.leaves()[k]) for k in range(n))
+        assert t.exit(e) == c
+    g = VEC["ecfft"]["4"]
+    t = o.FFTree(4)
+    assert [hex(x) for x in t.enter([H(x) for x in g["coeffs"]])] == g["enter_out"]
+
+
+def test_domain_interleave_and_shift():
+    """test_subtree / test_union_of_sub_tree_leaves, src/ec_fft.rs:633-645,1043-1054."""
+    t = o.FFTree(5)
+    L = t.leaves()
+    assert o.FFTree(5, shifted=True, base_log_n=5).leaves() == L[1:] + L[:1]
+    assert o.FFTree(4, base_log_n=5).leaves() == L[0::2]
+    assert o.FFTree(4, shifted=True, base_log_n=5).leaves() == L[1::2]
+    assert len(set(L)) == len(L)
+
+
+def test_vanishing_poly_chain():
+    """test_vanishing_poly, src/ec_fft.rs:820-880: Z(d_i) = 0 and Z == prod (X - d_i)."""
+    t = o.FFTree(4)
+    d, _ = t.both_domains()
+    z = o.poly_from_roots(d)
+    for x in d:
+        assert t.vanish_even_at(x) == 0
+    assert t.vanish_even_at(12345) == o.poly_eval(z, 12345)
+
+
+def test_blake3_official_vectors():
+    b = VEC["blake3"]
+    assert b["0"] == "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    assert b["1"] == "2d3adedff11b61f14c886e35afa036736dcd87a74d27b5c1510225d0f592e213"
+    assert b["1025"].startswith("d00278ae47eb27b34faecf67b4fe263f82d5412916c1ffd97c8cb7fb814b8444")
+    for n, h in b.items():
+        assert o.blake3(bytes(i % 251 for i in range(int(n)))).hex() == h
+
+
+def test_frbits_and_proof_bits():
+    """src/curve.rs:30-59, src/proving.rs:691-770."""
+    x = 0x1234567890ABCDEF << 100
+    assert o.frbits_to_fr(o.frbits_from_fr(x)) == (x, True)
+    assert o.frbits_to_fr([1] * 232)[1] is False
+    bits = o.proof_to_bits(bytes(range(30)), bytes(range(30, 60)), 5, 7)
+    assert len(bits) == 240 + 240 + 232 + 232
+    assert o.fr_to_le_bytes_stripped(0) == b"" and o.fr_to_le_bytes_stripped(256) == b"\x00\x01"
+
+
+def test_toy_r1cs_end_to_end():
+    """test_dvsnark_prover_over_toy_r1cs, src/dvsnark_test.rs:131-180."""
+    toy = VEC["toy"]
+    trap = tuple(H(x) for x in toy["trapdoor"])
+    tree = o.FFTree(4)
+    st = o.setup_srs_scalars(tree, o.TOY_ROWS, o.TOY_COEFFS, 2, trap)
+
+    def alpha_fn(dl):
+        return o.transcript_challenge(co.xsk233_encode(co.k233_mulgen(dl)), o.TOY_PUBLIC)
+
+    pr = o.prove_scalars(tree, st, o.TOY_PUBLIC, o.TOY_PRIVATE, alpha_fn)
+    assert hex(pr["alpha"]) == toy["alpha"] and hex(pr["a0"]) == toy["a0"] and hex(pr["b0"]) == toy["b0"]
+    assert o.verify_dl(trap, o.TOY_PUBLIC, pr["dl_commit_p"], pr["dl_kzg"], pr["a0"], pr["b0"], pr["alpha"])
+    assert not o.verify_dl(trap, [25, 13], pr["dl_commit_p"], pr["dl_kzg"], pr["a0"], pr["b0"], pr["alpha"])
+    # commitments as real group elements through the reference-shaped C MSM
+    def to_np(vals):
+        return np.array([[(v >> (64 * i)) & (2**64 - 1) for i in range(4)] for v in vals], dtype=np.uint64)
+
+    def bases(scal):
+        return np.array([[(c >> (64 * i)) & (2**64 - 1) for c in co.k233_mulgen(k) for i in range(4)] for k in scal], dtype=np.uint64)
+
+    gk = st["g_k"][0] + st["g_k"][1] + st["g_k"][2]
+    kzg = co.msm(to_np(pr["s_k"]), bases(gk))
+    assert co.xsk233_encode(kzg).hex() == toy["kzg_k"]
