@@ -22,6 +22,9 @@ _SIGS = {
     "dvp_device_count": (C.c_int, []),
     "dvp_set_device": (C.c_int, [C.c_int]),
     "dvp_last_error_index": (C.c_int64, []),
+    "dvp_profile_enable": (None, [C.c_int]),
+    "dvp_profile_reset": (None, []),
+    "dvp_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "dvp_ecfft_create": (C.c_int, [u32, C.c_int, u32, C.POINTER(vp)]),
     "dvp_ecfft_destroy": (None, [vp]),
     "dvp_ecfft_log2_leaves": (u32, [vp]),
@@ -35,6 +38,11 @@ _SIGS = {
     "dvp_ecfft_vanish_at": (C.c_int, [vp, C.c_int, u64p, u64p]),
     "dvp_fr_batch_inverse": (C.c_int, [u64p, sz]),
     "dvp_fr_batch_inverse_dev": (C.c_int, [vp, sz, vp]),
+    "dvp_fr_vec_mul": (C.c_int, [u64p, u64p, sz, u64p]),
+    "dvp_fr_vec_scale": (C.c_int, [u64p, u64p, sz, u64p]),
+    "dvp_fr_vec_scalar_sub": (C.c_int, [u64p, u64p, sz, u64p]),
+    "dvp_fr_vec_dot": (C.c_int, [u64p, u64p, sz, u64p]),
+    "dvp_fr_spmv": (C.c_int, [vp, vp, vp, u32, u64p, u32, u64p, u32, u64p]),
     "dvp_barycentric_eval": (C.c_int, [u64p, u64p, u64p, u64p, sz, u64p, u64p]),
     "dvp_msm_affine": (C.c_int, [u64p, u64p, u8p, sz, u64p, C.POINTER(C.c_int)]),
     "dvp_msm_affine_dev": (C.c_int, [vp, vp, vp, sz, vp, vp, vp]),
@@ -43,6 +51,19 @@ _SIGS = {
     "dvp_mulgen_batch_affine": (C.c_int, [u64p, sz, u64p, u8p]),
     "dvp_points_encode": (C.c_int, [u64p, u8p, sz, u8p]),
     "dvp_points_decode": (C.c_int, [u8p, sz, u64p, u8p]),
+    "dvp_prover_create": (C.c_int, [u32, u32, u32, C.POINTER(vp)]),
+    "dvp_prover_destroy": (None, [vp]),
+    "dvp_prover_set_coeffs": (C.c_int, [vp, u64p, u32]),
+    "dvp_prover_set_matrix": (C.c_int, [vp, C.c_int, u32, vp, vp, vp]),
+    "dvp_prover_set_srs_encoded": (C.c_int, [vp, C.c_int, u8p, sz]),
+    "dvp_prover_set_srs_affine": (C.c_int, [vp, C.c_int, u64p, u8p, sz]),
+    "dvp_prover_set_srs_affine_dev": (C.c_int, [vp, C.c_int, vp, vp, sz]),
+    "dvp_prove": (C.c_int, [vp, u64p, u32, u64p, u32, u8p]),
+    "dvp_prover_debug_read": (C.c_int, [vp, C.c_char_p, u64p, sz]),
+    "dvp_prover_domains": (C.c_int, [vp, u64p, u64p]),
+    "dvp_prover_domain_tables": (C.c_int, [vp, C.c_int, u64p, u64p]),
+    "dvp_transcript_challenge": (C.c_int, [u8p, u64p, u32, u64p]),
+    "dvp_blake3": (C.c_int, [u8p, sz, u8p]),
 }
 EXPORTED = []
 for _name, (_res, _args) in _SIGS.items():

@@ -1,10 +1,63 @@
 // Library-wide C ABI pieces: status strings, device selection, last-error bookkeeping.
 #include "common.h"
 
+#include <mutex>
+#include <vector>
+#include <cstring>
+
 namespace dvp {
 thread_local int64_t g_last_error_index = -1;
 thread_local hipError_t g_last_hip_error = hipSuccess;
+
+bool g_prof_enabled = false;
+static std::mutex g_prof_mu;
+static double g_prof_ms[PROF_NSLOTS] = {0};
+static uint64_t g_prof_n[PROF_NSLOTS] = {0};
+struct Pending { int slot; hipEvent_t e0, e1; };
+static std::vector<Pending> g_prof_pending;
+static const char* kProfNames[PROF_NSLOTS] = {"msm_accum_affine", "msm_total", "extend_total", "prove_total"};
+
+ProfScope::ProfScope(int slot_, hipStream_t st_) : slot(slot_), st(st_) {
+  if (!g_prof_enabled) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  (void)hipEventRecord(e0, st);
+}
+void ProfScope::stop() {
+  if (!e0) return;
+  (void)hipEventRecord(e1, st);
+  std::lock_guard<std::mutex> g(g_prof_mu);
+  g_prof_pending.push_back({slot, e0, e1});
+  e0 = e1 = nullptr;
+}
+void prof_collect() {
+  std::lock_guard<std::mutex> g(g_prof_mu);
+  for (auto& p : g_prof_pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      g_prof_ms[p.slot] += ms;
+      g_prof_n[p.slot] += 1;
+    }
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  g_prof_pending.clear();
+}
 }  // namespace dvp
+
+extern "C" void dvp_profile_enable(int on) { dvp::g_prof_enabled = on != 0; }
+extern "C" void dvp_profile_reset(void) {
+  dvp::prof_collect();
+  std::lock_guard<std::mutex> g(dvp::g_prof_mu);
+  for (int i = 0; i < dvp::PROF_NSLOTS; ++i) { dvp::g_prof_ms[i] = 0; dvp::g_prof_n[i] = 0; }
+}
+extern "C" int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches) {
+  if (!name || !total_ms || !launches) return DVP_EINVAL;
+  dvp::prof_collect();
+  std::lock_guard<std::mutex> g(dvp::g_prof_mu);
+  for (int i = 0; i < dvp::PROF_NSLOTS; ++i)
+    if (!strcmp(name, dvp::kProfNames[i])) { *total_ms = dvp::g_prof_ms[i]; *launches = dvp::g_prof_n[i]; return DVP_OK; }
+  return DVP_EINVAL;
+}
 
 extern "C" const char* dvp_strerror(int s) {
   switch (s) {

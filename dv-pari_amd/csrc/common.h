@@ -61,4 +61,18 @@ struct DevBuf {
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// ---- per-kernel HIP-event timers (bench.py's roofline leg; off by default) ------------------------
+// A timed launch records two events on the launch stream; prof_collect() (called where the host
+// already synchronises) folds the elapsed times into named slots readable through dvp_profile_read.
+enum ProfSlot { PROF_MSM_ACCUM_AFFINE = 0, PROF_MSM_TOTAL, PROF_EXTEND_TOTAL, PROF_PROVE_TOTAL, PROF_NSLOTS };
+extern bool g_prof_enabled;
+struct ProfScope {
+  int slot;
+  hipStream_t st;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(int slot_, hipStream_t st_);
+  void stop();
+};
+void prof_collect();
+
 }  // namespace dvp

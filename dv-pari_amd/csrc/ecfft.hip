@@ -206,28 +206,7 @@ __global__ void __launch_bounds__(256) k_check_canonical(const Fr* __restrict__ 
 
 using namespace dvp;
 
-// ---- context -----------------------------------------------------------------------------------
-struct MatSet {
-  Fr* dec = nullptr;  // (n-1) x 4 Fr, layer d at offset 4*(n - (n>>d))
-  Fr* rec = nullptr;
-};
-
-struct dvp_ecfft {
-  int log_n = 0;
-  uint32_t n_leaves = 0;
-  int device = 0;
-  Fr* layers = nullptr;  // layer d at offset layer_off[d], N>>d entries, Montgomery
-  std::vector<size_t> layer_off;
-  std::vector<Fr> x0, t;        // per layer, Montgomery (host copies)
-  std::map<int, MatSet> mats;   // key = sl*2 + to_even
-  std::map<int, Fr*> xnn;       // key = sl ; (N>>sl) entries: leaf^((N>>sl)/2)
-  Fr* scratch = nullptr;        // 6 x N Fr work space for enter/exit
-  Fr* d_x0 = nullptr;           // device copies of x0/t (Montgomery)
-  Fr* d_t = nullptr;
-  std::mutex mu;
-
-  Fr* layer(int d) const { return layers + layer_off[d]; }
-};
+#include "ecfft_internal.h"
 
 static const int TPB = 256;
 
@@ -266,7 +245,7 @@ static void launch_bfly(Fr* data, const Fr* mats, int lh, uint32_t n, hipStream_
 }
 
 // in-place extend of `batch` vectors of n = (N>>sl)/2 values
-static int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) {
+int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) {
   uint32_t n = (c->n_leaves >> sl) >> 1;
   if (n <= 1) return DVP_OK;
   MatSet* ms;
@@ -474,20 +453,6 @@ static int enter_core(dvp_ecfft* c, int sl0, const Fr* d_coeffs, Fr* d_out, hipS
 }
 
 namespace dvp {
-// Z_0(x) = U - c0 V through the first kk isogenies (x Montgomery in, Montgomery out)
-__device__ __forceinline__ Fr vanish_chain(Fr x, const Fr* __restrict__ x0s, const Fr* __restrict__ ts, int kk, Fr c0) {
-  Fr u = x, v = fr_one_mont();
-  for (int d = 0; d < kk; ++d) {
-    Fr x0 = x0s[d], t = ts[d];
-    Fr uv = fr_mul(u, v), vv = fr_sqr(v);
-    Fr nu = fr_add(fr_sub(fr_sqr(u), fr_mul(x0, uv)), fr_mul(t, vv));
-    Fr nv = fr_sub(uv, fr_mul(x0, vv));
-    u = nu;
-    v = nv;
-  }
-  return fr_sub(u, fr_mul(c0, v));
-}
-
 // exit tables of the stride-2^sl subtree: xinv[i] = 1/xnn[2i], z0inv[i] = 1/Z_0(leaf 2i+1)
 __global__ void __launch_bounds__(256)
 k_exit_tables(const Fr* __restrict__ L0, int sl, uint32_t h, const Fr* __restrict__ xnn, const Fr* __restrict__ x0s,
@@ -572,6 +537,18 @@ __global__ void k_c_base(const Fr* __restrict__ L0, Fr* __restrict__ ctab) {
 }
 }  // namespace dvp
 
+// device copies of the per-layer isogeny constants
+int ecfft_device_consts(dvp_ecfft* c) {
+  std::lock_guard<std::mutex> g(c->mu);
+  if (!c->d_x0) {
+    DVP_HIP(hipMalloc((void**)&c->d_x0, c->log_n * sizeof(Fr)));
+    DVP_HIP(hipMalloc((void**)&c->d_t, c->log_n * sizeof(Fr)));
+    DVP_HIP(hipMemcpy(c->d_x0, c->x0.data(), c->log_n * sizeof(Fr), hipMemcpyHostToDevice));
+    DVP_HIP(hipMemcpy(c->d_t, c->t.data(), c->log_n * sizeof(Fr), hipMemcpyHostToDevice));
+  }
+  return DVP_OK;
+}
+
 struct ExitTab {
   Fr* xinv = nullptr;   // h
   Fr* z0inv = nullptr;  // h
@@ -585,12 +562,7 @@ static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStr
 // Build (once) the exit tables of every stride level >= sl, deepest first.
 static int ensure_exit_tables(dvp_ecfft* c, int sl_min, hipStream_t st) {
   const uint32_t N = c->n_leaves;
-  if (!c->d_x0) {
-    DVP_HIP(hipMalloc((void**)&c->d_x0, c->log_n * sizeof(Fr)));
-    DVP_HIP(hipMalloc((void**)&c->d_t, c->log_n * sizeof(Fr)));
-    DVP_HIP(hipMemcpy(c->d_x0, c->x0.data(), c->log_n * sizeof(Fr), hipMemcpyHostToDevice));
-    DVP_HIP(hipMemcpy(c->d_t, c->t.data(), c->log_n * sizeof(Fr), hipMemcpyHostToDevice));
-  }
+  DVP_TRY(ecfft_device_consts(c));
   for (int sl = c->log_n - 1; sl >= sl_min; --sl) {
     {
       std::lock_guard<std::mutex> g(g_exit_mu);

@@ -155,3 +155,134 @@ extern "C" int dvp_barycentric_eval(const uint64_t* domain, const uint64_t* bar_
   DVP_HIP(hipMemcpy(out, o.p, sizeof(Fr), hipMemcpyDeviceToHost));
   return DVP_OK;
 }
+
+// ---- generic pointwise / reduction helpers (the rayon maps of src/proving.rs:492-654 and the setup
+// loops of src/srs.rs:53-84,138-160 expressed as reusable vector ops; host-pointer flavours) ---------
+namespace dvp {
+__global__ void __launch_bounds__(256) k_vec_mul(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_mul(fr_to_mont(a[i]), b[i]);
+}
+__global__ void __launch_bounds__(256) k_vec_scale(const Fr* __restrict__ a, Fr s_m, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_mul(s_m, a[i]);
+}
+__global__ void __launch_bounds__(256) k_vec_scalar_sub(Fr s, const Fr* __restrict__ a, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_sub(s, a[i]);
+}
+__global__ void __launch_bounds__(256) k_vec_dot_partial(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ partial) {
+  __shared__ Fr sh[256];
+  Fr s = fr_zero();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s = fr_add(s, fr_mul(fr_to_mont(a[i]), b[i]));
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(256) k_sum_final(const Fr* __restrict__ partial, uint32_t nb, Fr* __restrict__ out) {
+  __shared__ Fr sh[256];
+  Fr s = fr_zero();
+  for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+// out[r] = sum_k coeffs[cid[k]] * x[col[k]] over row r (eval_row, src/gnark_r1cs.rs:273-280)
+__global__ void __launch_bounds__(256)
+k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col, const uint32_t* __restrict__ cid,
+       const Fr* __restrict__ coeffs, const Fr* __restrict__ x, uint32_t n_rows, Fr* __restrict__ out) {
+  uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rows) return;
+  Fr acc = fr_zero();
+  for (uint32_t k = row_ptr[r]; k < row_ptr[r + 1]; ++k) acc = fr_add(acc, fr_mul(fr_to_mont(coeffs[cid[k]]), x[col[k]]));
+  out[r] = acc;
+}
+}  // namespace dvp
+
+static int up(DevBuf& b, const void* h, size_t bytes) {
+  DVP_TRY(b.alloc(bytes));
+  DVP_HIP(hipMemcpy(b.p, h, bytes, hipMemcpyHostToDevice));
+  return DVP_OK;
+}
+
+extern "C" int dvp_fr_vec_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out) {
+  if (!n) return DVP_OK;
+  if (!a || !b || !out) return DVP_EINVAL;
+  DevBuf da, db;
+  DVP_TRY(up(da, a, n * 32));
+  DVP_TRY(up(db, b, n * 32));
+  hipLaunchKernelGGL(k_vec_mul, dim3(cdiv(n, 256)), dim3(256), 0, 0, da.as<Fr>(), db.as<Fr>(), da.as<Fr>(), n);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, da.p, n * 32, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+extern "C" int dvp_fr_vec_scale(const uint64_t* a, const uint64_t s[4], size_t n, uint64_t* out) {
+  if (!n) return DVP_OK;
+  if (!a || !s || !out) return DVP_EINVAL;
+  Fr sc;
+  memcpy(sc.v, s, 32);
+  if (!fr_is_canonical(sc)) return DVP_EINVAL;
+  DevBuf da;
+  DVP_TRY(up(da, a, n * 32));
+  hipLaunchKernelGGL(k_vec_scale, dim3(cdiv(n, 256)), dim3(256), 0, 0, da.as<Fr>(), fr_to_mont(sc), da.as<Fr>(), n);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, da.p, n * 32, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+extern "C" int dvp_fr_vec_scalar_sub(const uint64_t s[4], const uint64_t* a, size_t n, uint64_t* out) {
+  if (!n) return DVP_OK;
+  if (!a || !s || !out) return DVP_EINVAL;
+  Fr sc;
+  memcpy(sc.v, s, 32);
+  if (!fr_is_canonical(sc)) return DVP_EINVAL;
+  DevBuf da;
+  DVP_TRY(up(da, a, n * 32));
+  hipLaunchKernelGGL(k_vec_scalar_sub, dim3(cdiv(n, 256)), dim3(256), 0, 0, sc, da.as<Fr>(), da.as<Fr>(), n);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, da.p, n * 32, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+extern "C" int dvp_fr_vec_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]) {
+  if (!a || !b || !out) return DVP_EINVAL;
+  DevBuf da, db, part, o;
+  DVP_TRY(up(da, a, (n ? n : 1) * 32));
+  DVP_TRY(up(db, b, (n ? n : 1) * 32));
+  uint32_t nb = cdiv(n ? n : 1, 256);
+  if (nb > 1024) nb = 1024;
+  DVP_TRY(part.alloc(nb * sizeof(Fr)));
+  DVP_TRY(o.alloc(sizeof(Fr)));
+  hipLaunchKernelGGL(k_vec_dot_partial, dim3(nb), dim3(256), 0, 0, da.as<Fr>(), db.as<Fr>(), n, part.as<Fr>());
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, 0, part.as<Fr>(), nb, o.as<Fr>());
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, o.p, 32, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+extern "C" int dvp_fr_spmv(const uint32_t* row_ptr, const uint32_t* col, const uint32_t* coeff_ids, uint32_t n_rows,
+                           const uint64_t* coeffs, uint32_t n_coeffs, const uint64_t* x, uint32_t n_cols, uint64_t* out) {
+  if (!n_rows) return DVP_OK;
+  if (!row_ptr || !coeffs || !x || !out) return DVP_EINVAL;
+  size_t nnz = row_ptr[n_rows];
+  for (size_t k = 0; k < nnz; ++k)
+    if (col[k] >= n_cols || coeff_ids[k] >= n_coeffs) { g_last_error_index = (int64_t)k; return DVP_EINVAL; }
+  DevBuf rp, c, id, cf, dx, o;
+  DVP_TRY(up(rp, row_ptr, ((size_t)n_rows + 1) * 4));
+  DVP_TRY(up(c, col, (nnz ? nnz : 1) * 4));
+  DVP_TRY(up(id, coeff_ids, (nnz ? nnz : 1) * 4));
+  DVP_TRY(up(cf, coeffs, (size_t)n_coeffs * 32));
+  DVP_TRY(up(dx, x, (size_t)n_cols * 32));
+  DVP_TRY(o.alloc((size_t)n_rows * 32));
+  hipLaunchKernelGGL(k_spmv, dim3(cdiv(n_rows, 256)), dim3(256), 0, 0, rp.as<uint32_t>(), c.as<uint32_t>(), id.as<uint32_t>(),
+                     cf.as<Fr>(), dx.as<Fr>(), n_rows, o.as<Fr>());
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, o.p, (size_t)n_rows * 32, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}

@@ -363,6 +363,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   Ld* tail = (Ld*)(base + o_tail);
   const uint32_t nk = p.nkeys;
 
+  ProfScope ps_total(PROF_MSM_TOTAL, st);
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
   DVP_HIP(hipMemsetAsync(cnt, 0, ((size_t)nk + 1) * 4, st));
   DVP_HIP(hipMemsetAsync(cursor, 0, ((size_t)nk + 1) * 4, st));
@@ -373,8 +374,12 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   // level 1: affine gather
   hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, cnt, ntask, nk, p.K);
   DVP_TRY(scan_exclusive(ntask, toff, nk, bsum, st));
-  hipLaunchKernelGGL(k_accum_affine, dim3(cdiv(p.t1_max, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, toff,
-                     nk, p.K, bufA);
+  {
+    ProfScope ps(PROF_MSM_ACCUM_AFFINE, st);
+    hipLaunchKernelGGL(k_accum_affine, dim3(cdiv(p.t1_max, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, toff,
+                       nk, p.K, bufA);
+    ps.stop();
+  }
   // further levels: (cnt, off) <- (ntask, toff)
   uint32_t *c_cnt = ntask, *c_off = toff, *n_cnt = cnt2, *n_off = off2;
   Ld *in = bufA, *outb = bufB;
@@ -407,6 +412,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     cntT = half;
   }
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  ps_total.stop();
   DVP_HIP(hipGetLastError());
   // the scalar-range flag is the only thing that needs the host
   unsigned long long e;

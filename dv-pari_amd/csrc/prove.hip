@@ -1,0 +1,602 @@
+// Proof::prove on gfx950 -- the orchestration of src/proving.rs:426-688 with every vector stage on
+// the device and only the BLAKE3 transcript (src/proving.rs:79-198) and the 118-byte proof assembly on
+// the host.  Stage map (reference line -> kernel):
+//   get_matrix_evaluations_from_witness   :348-403  -> k_r1cs_eval  (CSR rows, one thread per row; the
+//                                                      Vandermonde fold C' = C - D is applied on the fly)
+//   multi_scalar_mul(assignment, g_m)     :462-463  \  one MSM over [w | q2] x [g_m | g_q]
+//   multi_scalar_mul(q_vals2, g_q)        :511-512  /  (commit_p = msm_q + msm_gm, :515)
+//   extend_evals                          :410-422  -> dvp_ecfft batched extend (4 vectors)
+//   r_vals2 / q_vals2                     :492-508  -> k_quotient
+//   transcript -> alpha                   :517-558  -> host BLAKE3 + k_alpha_denoms (domain check)
+//   barycentric evaluations a0,b0,i0      :561-594  -> k_bary3_partial / k_bary3_final
+//     (Z(alpha) comes from the isogeny chain instead of a Horner pass over z_poly)
+//   denom_invs, denom_invs2               :599-616  -> k_alpha_denoms + batch inverse
+//   k_scalar_a / _b / r_vals / k_scalar_r :619-654  -> k_kscalars (interleaved [D_i, D'_i])
+//   multi_scalar_mul(srs_s_k, srs_g_k)    :666-680  -> MSM over 4m points
+// The prover-side precomputes of prover_prepares_precomputes (:225-325) -- barycentric weights and
+// 1/Z_D on D' -- are regenerated on the device from the isogeny chain (k_domain_tables), so neither
+// z_poly nor the FFTR tree cache is needed.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "blake3.h"
+#include "common.h"
+#include "ecfft_internal.h"
+#include "k233.cuh"
+
+extern "C" int dvp_ecfft_create(uint32_t log_n, int shifted, uint32_t base_log, dvp_ecfft** out);
+extern "C" void dvp_ecfft_destroy(dvp_ecfft* c);
+int ecfft_device_consts(dvp_ecfft* c);
+
+namespace dvp {
+
+int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy,
+                   void* d_out_inf, hipStream_t st);
+int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipStream_t st);
+int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st);
+int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
+
+// ---- domain tables from the isogeny chain ---------------------------------------------------------
+// For S = even leaves (D) of the 2m-leaf tree, Z_S = U - c0 V with (U,V) the projective image under
+// the first kk = log2(m) isogenies.  Forward-mode derivative gives Z_S'(s_i) for the barycentric
+// weights; Z_S on the other half gives z_vals2inv.
+//   bar_w[i]   = 1 / Z_S'(S[i])          (Montgomery)
+//   zinv_o[i]  = 1 / Z_S(other[i])       (Montgomery)
+// which = 0: S = even leaves, other = odd leaves; which = 1: mirrored.
+__global__ void __launch_bounds__(256)
+k_domain_tables(const Fr* __restrict__ L0, uint32_t m, const Fr* __restrict__ x0s, const Fr* __restrict__ ts, int kk,
+                const Fr* __restrict__ ctop /* layer kk: 2 leaves */, int which, Fr* __restrict__ bar_w, Fr* __restrict__ zinv_o) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr c0 = ctop[which];
+  Fr s = L0[2 * (size_t)i + which];
+  Fr o = L0[2 * (size_t)i + 1 - which];
+  zinv_o[i] = fr_inv(vanish_chain(o, x0s, ts, kk, c0));
+  // derivative at s
+  Fr u = s, v = fr_one_mont(), du = fr_one_mont(), dv = fr_zero();
+  for (int d = 0; d < kk; ++d) {
+    Fr x0 = x0s[d], t = ts[d];
+    Fr uv = fr_mul(u, v), vv = fr_sqr(v);
+    Fr duv = fr_add(fr_mul(du, v), fr_mul(u, dv));  // (uv)'
+    Fr dvv = fr_dbl(fr_mul(v, dv));                 // (v^2)'
+    Fr nu = fr_add(fr_sub(fr_sqr(u), fr_mul(x0, uv)), fr_mul(t, vv));
+    Fr nv = fr_sub(uv, fr_mul(x0, vv));
+    Fr ndu = fr_add(fr_sub(fr_dbl(fr_mul(u, du)), fr_mul(x0, duv)), fr_mul(t, dvv));
+    Fr ndv = fr_sub(duv, fr_mul(x0, dvv));
+    u = nu; v = nv; du = ndu; dv = ndv;
+  }
+  bar_w[i] = fr_inv(fr_sub(du, fr_mul(c0, dv)));
+}
+
+// contiguous Montgomery copies of D and D'
+__global__ void __launch_bounds__(256) k_split_domains(const Fr* __restrict__ L0, uint32_t m, Fr* __restrict__ d, Fr* __restrict__ d2) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  d[i] = L0[2 * (size_t)i];
+  d2[i] = L0[2 * (size_t)i + 1];
+}
+
+// ---- stage kernels ---------------------------------------------------------------------------------
+struct Csr {
+  const uint32_t* row_ptr;  // n_rows + 1
+  const uint32_t* wire;
+  const uint32_t* coeff;
+  uint32_t n_rows;
+};
+
+__device__ __forceinline__ Fr csr_row(const Csr& m, uint32_t row, const Fr* __restrict__ coeffs_m, const Fr* __restrict__ w) {
+  Fr acc = fr_zero();
+  if (row >= m.n_rows) return acc;
+  for (uint32_t k = m.row_ptr[row]; k < m.row_ptr[row + 1]; ++k)
+    acc = fr_add(acc, fr_mul(coeffs_m[m.coeff[k]], w[m.wire[k]]));  // eval_row, src/gnark_r1cs.rs:273-280
+  return acc;
+}
+
+// E = [a | b | c' | i] (4 x m, canonical).  c' = C w - i(d), i(d) = sum_j pub_j d^j (src/gnark_r1cs.rs:333-399)
+__global__ void __launch_bounds__(256)
+k_r1cs_eval(Csr A, Csr B, Csr C, const Fr* __restrict__ coeffs_m, const Fr* __restrict__ w, const Fr* __restrict__ dom_m,
+            uint32_t npub, uint32_t m, Fr* __restrict__ E, unsigned long long* __restrict__ unsat) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr a = csr_row(A, i, coeffs_m, w), b = csr_row(B, i, coeffs_m, w), cw = csr_row(C, i, coeffs_m, w);
+  Fr d = dom_m[i];
+  Fr iv = fr_zero();
+  for (int j = (int)npub - 1; j >= 0; --j) iv = fr_add(fr_mul(d, iv), w[1 + j]);  // Horner, canonical
+  // a*b == c' + i  <=>  a*b == C w      (assert_eq!, src/proving.rs:389-395)
+  if (!fr_eq(fr_mul(fr_to_mont(a), b), cw)) atomicMin(unsat, (unsigned long long)i);
+  E[i] = a;
+  E[(size_t)m + i] = b;
+  E[2 * (size_t)m + i] = fr_sub(cw, iv);
+  E[3 * (size_t)m + i] = iv;
+}
+
+// r2 = a2 b2 - i2 ; q2 = (r2 - c2) * z2inv        (src/proving.rs:492-508)
+__global__ void __launch_bounds__(256)
+k_quotient(const Fr* __restrict__ E2, const Fr* __restrict__ z2inv_m, uint32_t m, Fr* __restrict__ r2, Fr* __restrict__ q2) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr a = E2[i], b = E2[(size_t)m + i], c = E2[2 * (size_t)m + i], iv = E2[3 * (size_t)m + i];
+  Fr r = fr_sub(fr_mul(fr_to_mont(a), b), iv);
+  r2[i] = r;
+  q2[i] = fr_mul(z2inv_m[i], fr_sub(r, c));
+}
+
+// den[i] = d_i - alpha, den2[i] = d'_i - alpha (canonical); flags alpha in D u D' (src/proving.rs:548-556)
+__global__ void __launch_bounds__(256)
+k_alpha_denoms(const Fr* __restrict__ d_m, const Fr* __restrict__ d2_m, Fr alpha_m, uint32_t m, Fr* __restrict__ den,
+               Fr* __restrict__ den2, unsigned long long* __restrict__ hit) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr x = fr_sub(d_m[i], alpha_m), y = fr_sub(d2_m[i], alpha_m);
+  if (fr_is_zero(x) || fr_is_zero(y)) atomicMin(hit, (unsigned long long)i);
+  den[i] = fr_from_mont(x);
+  den2[i] = fr_from_mont(y);
+}
+
+// partial sums of  y_i * w_i * dinv_i  for y in {a, b, i}   (dinv = 1/(d_i - alpha), canonical)
+__global__ void __launch_bounds__(256)
+k_bary3_partial(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, const Fr* __restrict__ dinv, uint32_t m,
+                Fr* __restrict__ partial /* [3][nb] Montgomery */) {
+  __shared__ Fr sh[256];
+  Fr s[3] = {fr_zero(), fr_zero(), fr_zero()};
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    Fr k = fr_mul(barw_m[i], fr_to_mont(dinv[i]));  // Montgomery
+    s[0] = fr_add(s[0], fr_mul(k, fr_to_mont(E[i])));
+    s[1] = fr_add(s[1], fr_mul(k, fr_to_mont(E[(size_t)m + i])));
+    s[2] = fr_add(s[2], fr_mul(k, fr_to_mont(E[3 * (size_t)m + i])));
+  }
+  for (int v = 0; v < 3; ++v) {
+    sh[threadIdx.x] = s[v];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = sh[0];
+    __syncthreads();
+  }
+}
+// out[0..2] = a0, b0, i0 (canonical); out[3] = r0 = a0 b0 - i0.   P(alpha) = -Z(alpha) * sum y w / (d - alpha)
+__global__ void __launch_bounds__(256) k_bary3_final(const Fr* __restrict__ partial, uint32_t nb, Fr neg_z_alpha_m, Fr* __restrict__ out) {
+  __shared__ Fr sh[256];
+  Fr res[3];
+  for (int v = 0; v < 3; ++v) {
+    Fr s = fr_zero();
+    for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[(size_t)v * nb + i]);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
+    }
+    res[v] = fr_mul(sh[0], neg_z_alpha_m);  // Montgomery
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = fr_from_mont(res[0]);
+    out[1] = fr_from_mont(res[1]);
+    out[2] = fr_from_mont(res[2]);
+    out[3] = fr_from_mont(fr_sub(fr_mul(res[0], res[1]), res[2]));
+  }
+}
+
+// S = [k_a | k_b | k_r] with k_r interleaved [D_i, D'_i]   (src/proving.rs:619-654)
+__global__ void __launch_bounds__(256)
+k_kscalars(const Fr* __restrict__ E, const Fr* __restrict__ r2, const Fr* __restrict__ dinv, const Fr* __restrict__ dinv2,
+           const Fr* __restrict__ abir0 /* a0,b0,i0,r0 canonical */, uint32_t m, Fr* __restrict__ S) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  Fr a0 = abir0[0], b0 = abir0[1], r0 = abir0[3];
+  Fr a = E[i], b = E[(size_t)m + i], iv = E[3 * (size_t)m + i];
+  Fr di = fr_to_mont(dinv[i]), di2 = fr_to_mont(dinv2[i]);
+  S[i] = fr_mul(di, fr_sub(a, a0));
+  S[(size_t)m + i] = fr_mul(di, fr_sub(b, b0));
+  Fr r = fr_sub(fr_mul(fr_to_mont(a), b), iv);
+  S[2 * (size_t)m + 2 * (size_t)i] = fr_mul(di, fr_sub(r, r0));
+  S[2 * (size_t)m + 2 * (size_t)i + 1] = fr_mul(di2, fr_sub(r2[i], r0));
+}
+
+__global__ void __launch_bounds__(256) k_to_mont_vec(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fr_to_mont(in[i]);
+}
+__global__ void __launch_bounds__(256) k_from_mont_vec(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fr_from_mont(in[i]);
+}
+__global__ void k_inf32_to_8(const uint32_t* in, uint8_t* out) { out[0] = in[0] ? 1 : 0; out[1] = in[1] ? 1 : 0; }
+
+}  // namespace dvp
+
+using namespace dvp;
+
+struct DevCsr {
+  uint32_t* row_ptr = nullptr;
+  uint32_t* wire = nullptr;
+  uint32_t* coeff = nullptr;
+  uint32_t n_rows = 0;
+  size_t nnz = 0;
+};
+
+struct dvp_prover {
+  uint32_t log_m = 0, m = 0, n_pub = 0, n_wires = 0;
+  dvp_ecfft* tree = nullptr;  // 2m leaves (tree2n)
+  Fr *dD = nullptr, *dD2 = nullptr, *barw = nullptr, *z2inv = nullptr;  // Montgomery, m each
+  DevCsr mat[3];
+  Fr* coeffs_m = nullptr;
+  uint32_t n_coeffs = 0;
+  Aff* bases_a = nullptr;      // [g_m | g_q]        n_wires + m
+  uint8_t* inf_a = nullptr;
+  Aff* bases_k = nullptr;      // [g_k0 | g_k1 | g_k2] 4m
+  uint8_t* inf_k = nullptr;
+  bool have_srs[5] = {false, false, false, false, false};
+  // work buffers
+  Fr *w = nullptr, *E = nullptr, *E2 = nullptr, *r2 = nullptr, *SA = nullptr /* [w | q2] */, *den = nullptr, *den2 = nullptr,
+     *SK = nullptr, *partial = nullptr, *abir0 = nullptr;
+  unsigned long long* flags = nullptr;  // [0] unsat row, [1] alpha hit
+  Aff* pts = nullptr;                   // 2 result points
+  uint32_t* pts_inf32 = nullptr;
+  uint8_t* pts_inf8 = nullptr;
+  uint8_t* enc = nullptr;               // 60 bytes
+  Fr ctop_host[2];                      // layer log_m leaves (collapse points of D, D'), Montgomery
+  // last-proof intermediates kept for parity tests
+  Fr alpha_canon, abir0_host[4];
+};
+
+static const int PT = 256;
+
+static Fr host_vanish(const dvp_prover* p, int which, const Fr& x_m) {
+  const dvp_ecfft* c = p->tree;
+  int kk = (int)p->log_m;
+  Fr u = x_m, v = fr_one_mont();
+  for (int d = 0; d < kk; ++d) {
+    Fr uv = fr_mul(u, v), vv = fr_sqr(v);
+    Fr nu = fr_add(fr_sub(fr_sqr(u), fr_mul(c->x0[d], uv)), fr_mul(c->t[d], vv));
+    Fr nv = fr_sub(uv, fr_mul(c->x0[d], vv));
+    u = nu;
+    v = nv;
+  }
+  return fr_sub(u, fr_mul(p->ctop_host[which], v));
+}
+
+extern "C" int dvp_prover_create(uint32_t log2_m, uint32_t n_public, uint32_t n_wires, dvp_prover** out) {
+  if (!out || log2_m < 1 || log2_m > 26 || n_wires < 1 + n_public) return DVP_EINVAL;
+  dvp_prover* p = new dvp_prover();
+  p->log_m = log2_m;
+  p->m = 1u << log2_m;
+  p->n_pub = n_public;
+  p->n_wires = n_wires;
+  const size_t m = p->m;
+  DVP_TRY(dvp_ecfft_create(log2_m + 1, 0, log2_m + 1, &p->tree));  // TREE_2N, src/proving.rs:274
+  DVP_TRY(ecfft_device_consts(p->tree));
+  auto A = [&](void** q, size_t bytes) -> int { DVP_HIP(hipMalloc(q, bytes ? bytes : 16)); return DVP_OK; };
+  DVP_TRY(A((void**)&p->dD, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->dD2, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->barw, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->z2inv, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->bases_a, (n_wires + m) * sizeof(Aff)));
+  DVP_TRY(A((void**)&p->inf_a, n_wires + m));
+  DVP_TRY(A((void**)&p->bases_k, 4 * m * sizeof(Aff)));
+  DVP_TRY(A((void**)&p->inf_k, 4 * m));
+  DVP_TRY(A((void**)&p->w, n_wires * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->E, 4 * m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->E2, 4 * m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->r2, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->SA, (n_wires + m) * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->den, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->den2, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->SK, 4 * m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->partial, 3 * 1024 * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->abir0, 4 * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->flags, 16));
+  DVP_TRY(A((void**)&p->pts, 2 * sizeof(Aff)));
+  DVP_TRY(A((void**)&p->pts_inf32, 8));
+  DVP_TRY(A((void**)&p->pts_inf8, 8));
+  DVP_TRY(A((void**)&p->enc, 64));
+  DVP_HIP(hipMemset(p->inf_a, 0, n_wires + m));
+  DVP_HIP(hipMemset(p->inf_k, 0, 4 * m));
+  dvp_ecfft* t = p->tree;
+  int kk = (int)log2_m;
+  hipLaunchKernelGGL(k_split_domains, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, p->dD, p->dD2);
+  Fr* dummy;
+  DVP_TRY(A((void**)&dummy, m * sizeof(Fr)));
+  // bar weights of D and 1/Z_D on D'
+  hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, kk,
+                     t->layer(kk), 0, p->barw, p->z2inv);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(p->ctop_host, t->layer(kk), 2 * sizeof(Fr), hipMemcpyDeviceToHost));
+  DVP_HIP(hipDeviceSynchronize());
+  (void)hipFree(dummy);
+  *out = p;
+  return DVP_OK;
+}
+
+extern "C" void dvp_prover_destroy(dvp_prover* p) {
+  if (!p) return;
+  void* ptrs[] = {p->dD, p->dD2, p->barw, p->z2inv, p->coeffs_m, p->bases_a, p->inf_a, p->bases_k, p->inf_k, p->w, p->E,
+                  p->E2, p->r2, p->SA, p->den, p->den2, p->SK, p->partial, p->abir0, p->flags, p->pts, p->pts_inf32,
+                  p->pts_inf8, p->enc};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
+  for (auto& mt : p->mat) {
+    if (mt.row_ptr) (void)hipFree(mt.row_ptr);
+    if (mt.wire) (void)hipFree(mt.wire);
+    if (mt.coeff) (void)hipFree(mt.coeff);
+  }
+  dvp_ecfft_destroy(p->tree);
+  delete p;
+}
+
+extern "C" int dvp_prover_set_coeffs(dvp_prover* p, const uint64_t* coeffs, uint32_t n) {
+  if (!p || !coeffs || !n) return DVP_EINVAL;
+  if (p->coeffs_m) (void)hipFree(p->coeffs_m);
+  DVP_HIP(hipMalloc((void**)&p->coeffs_m, (size_t)n * sizeof(Fr)));
+  DevBuf tmp;
+  DVP_TRY(tmp.alloc((size_t)n * sizeof(Fr)));
+  DVP_HIP(hipMemcpy(tmp.p, coeffs, (size_t)n * sizeof(Fr), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_to_mont_vec, dim3(cdiv(n, PT)), dim3(PT), 0, 0, tmp.as<Fr>(), p->coeffs_m, (size_t)n);
+  DVP_HIP(hipDeviceSynchronize());
+  p->n_coeffs = n;
+  return DVP_OK;
+}
+
+// which: 0 = L (A), 1 = R (B), 2 = O (C) of src/gnark_r1cs.rs:112-119; CSR over n_rows <= m rows
+extern "C" int dvp_prover_set_matrix(dvp_prover* p, int which, uint32_t n_rows, const uint32_t* row_ptr,
+                                     const uint32_t* wire_ids, const uint32_t* coeff_ids) {
+  if (!p || which < 0 || which > 2 || !row_ptr || n_rows > p->m) return DVP_EINVAL;
+  size_t nnz = row_ptr[n_rows];
+  if (nnz && (!wire_ids || !coeff_ids)) return DVP_EINVAL;
+  for (size_t k = 0; k < nnz; ++k)
+    if (wire_ids[k] >= p->n_wires || (p->n_coeffs && coeff_ids[k] >= p->n_coeffs)) {
+      g_last_error_index = (int64_t)k;
+      return DVP_EINVAL;
+    }
+  DevCsr& mt = p->mat[which];
+  if (mt.row_ptr) { (void)hipFree(mt.row_ptr); (void)hipFree(mt.wire); (void)hipFree(mt.coeff); }
+  DVP_HIP(hipMalloc((void**)&mt.row_ptr, ((size_t)n_rows + 1) * 4));
+  DVP_HIP(hipMalloc((void**)&mt.wire, (nnz ? nnz : 1) * 4));
+  DVP_HIP(hipMalloc((void**)&mt.coeff, (nnz ? nnz : 1) * 4));
+  DVP_HIP(hipMemcpy(mt.row_ptr, row_ptr, ((size_t)n_rows + 1) * 4, hipMemcpyHostToDevice));
+  if (nnz) {
+    DVP_HIP(hipMemcpy(mt.wire, wire_ids, nnz * 4, hipMemcpyHostToDevice));
+    DVP_HIP(hipMemcpy(mt.coeff, coeff_ids, nnz * 4, hipMemcpyHostToDevice));
+  }
+  mt.n_rows = n_rows;
+  mt.nnz = nnz;
+  return DVP_OK;
+}
+
+// which: 0 g_m (n_wires), 1 g_q (m), 2 g_k_0 (m), 3 g_k_1 (m), 4 g_k_2 (2m) -- src/artifacts.rs names;
+// enc = payload of the reference's point-vector file (n x 30 B, src/io_utils.rs:83-111), decoded ONCE
+// into HBM-resident affine bases (the reference re-reads and re-decodes them on every prove()).
+static int srs_slot(dvp_prover* p, int which, Aff** base, uint8_t** inf, size_t* n) {
+  size_t m = p->m;
+  switch (which) {
+    case 0: *base = p->bases_a; *inf = p->inf_a; *n = p->n_wires; return DVP_OK;
+    case 1: *base = p->bases_a + p->n_wires; *inf = p->inf_a + p->n_wires; *n = m; return DVP_OK;
+    case 2: *base = p->bases_k; *inf = p->inf_k; *n = m; return DVP_OK;
+    case 3: *base = p->bases_k + m; *inf = p->inf_k + m; *n = m; return DVP_OK;
+    case 4: *base = p->bases_k + 2 * m; *inf = p->inf_k + 2 * m; *n = 2 * m; return DVP_OK;
+  }
+  return DVP_EINVAL;
+}
+extern "C" int dvp_prover_set_srs_encoded(dvp_prover* p, int which, const uint8_t* enc, size_t n) {
+  if (!p || !enc) return DVP_EINVAL;
+  Aff* base; uint8_t* inf; size_t want;
+  DVP_TRY(srs_slot(p, which, &base, &inf, &want));
+  if (n != want) return DVP_EINVAL;
+  DevBuf de;
+  DVP_TRY(de.alloc(n * 30));
+  DVP_HIP(hipMemcpy(de.p, enc, n * 30, hipMemcpyHostToDevice));
+  DVP_TRY(decode_dev(de.as<uint8_t>(), n, base, inf, 0));
+  p->have_srs[which] = true;
+  return DVP_OK;
+}
+extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_t* xy, const uint8_t* inf_in, size_t n) {
+  if (!p || !xy) return DVP_EINVAL;
+  Aff* base; uint8_t* inf; size_t want;
+  DVP_TRY(srs_slot(p, which, &base, &inf, &want));
+  if (n != want) return DVP_EINVAL;
+  DVP_HIP(hipMemcpy(base, xy, n * sizeof(Aff), hipMemcpyHostToDevice));
+  if (inf_in) DVP_HIP(hipMemcpy(inf, inf_in, n, hipMemcpyHostToDevice));
+  else DVP_HIP(hipMemset(inf, 0, n));
+  p->have_srs[which] = true;
+  return DVP_OK;
+}
+// device-to-device flavour (bases produced on the GPU, e.g. by dvp_mulgen on the same device)
+extern "C" int dvp_prover_set_srs_affine_dev(dvp_prover* p, int which, const void* d_xy, const void* d_inf, size_t n) {
+  if (!p || !d_xy) return DVP_EINVAL;
+  Aff* base; uint8_t* inf; size_t want;
+  DVP_TRY(srs_slot(p, which, &base, &inf, &want));
+  if (n != want) return DVP_EINVAL;
+  DVP_HIP(hipMemcpy(base, d_xy, n * sizeof(Aff), hipMemcpyDeviceToDevice));
+  if (d_inf) DVP_HIP(hipMemcpy(inf, d_inf, n, hipMemcpyDeviceToDevice));
+  else DVP_HIP(hipMemset(inf, 0, n));
+  p->have_srs[which] = true;
+  return DVP_OK;
+}
+
+// Transcript::output, src/proving.rs:164-197 (srs/circuit hashes are hashes of EMPTY buffers, :86-105,113-132)
+static void transcript_challenge(const uint8_t commit_p[30], const uint64_t* pub, uint32_t npub, uint8_t out32[32]) {
+  uint8_t h_empty[32], h_wc[32], h_pi[32], h_ct[32], h_rt[32], buf[64];
+  b3::hash(nullptr, 0, h_empty);
+  b3::hash(commit_p, 30, h_wc);
+  std::vector<uint8_t> pi((size_t)npub * 29);
+  for (uint32_t j = 0; j < npub; ++j) memcpy(pi.data() + 29 * (size_t)j, (const uint8_t*)(pub + 4 * (size_t)j), 29);
+  b3::hash(pi.data(), pi.size(), h_pi);
+  memcpy(buf, h_empty, 32); memcpy(buf + 32, h_empty, 32);
+  b3::hash(buf, 64, h_ct);
+  memcpy(buf, h_wc, 32); memcpy(buf + 32, h_pi, 32);
+  b3::hash(buf, 64, h_rt);
+  memcpy(buf, h_ct, 32); memcpy(buf + 32, h_rt, 32);
+  b3::hash(buf, 64, out32);
+  out32[28] = out32[29] = out32[30] = out32[31] = 0;  // 224-bit challenge
+}
+
+extern "C" int dvp_transcript_challenge(const uint8_t commit_p[30], const uint64_t* public_inputs, uint32_t n_public, uint64_t out[4]) {
+  if (!commit_p || (n_public && !public_inputs) || !out) return DVP_EINVAL;
+  uint8_t h[32];
+  transcript_challenge(commit_p, public_inputs, n_public, h);
+  memcpy(out, h, 32);
+  return DVP_OK;
+}
+
+extern "C" int dvp_blake3(const uint8_t* data, size_t len, uint8_t out[32]) {
+  if ((len && !data) || !out) return DVP_EINVAL;
+  b3::hash(data, len, out);
+  return DVP_OK;
+}
+
+// Proof::prove(cache_dir, public_inputs, private_inputs) -> Proof, src/proving.rs:426-688.
+// proof = commit_p[30] | kzg_k[30] | a0[29 LE] | b0[29 LE]  (the byte image of Proof::to_bits, :691-718)
+extern "C" int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
+                         uint32_t n_private, uint8_t proof[118]) {
+  if (!p || !proof || n_public != p->n_pub || 1 + n_public + n_private != p->n_wires) return DVP_EINVAL;
+  if ((n_public && !public_inputs) || (n_private && !private_inputs)) return DVP_EINVAL;
+  for (int k = 0; k < 5; ++k)
+    if (!p->have_srs[k]) return DVP_EINVAL;
+  if (!p->coeffs_m || !p->mat[0].row_ptr || !p->mat[1].row_ptr || !p->mat[2].row_ptr) return DVP_EINVAL;
+  hipStream_t st = 0;
+  const uint32_t m = p->m;
+  const size_t nw = p->n_wires;
+  ProfScope ps(PROF_PROVE_TOTAL, st);
+  // assignment = [1, public, private]  (src/proving.rs:449-452)
+  {
+    Fr one = fr_one_canon();
+    DVP_HIP(hipMemcpyAsync(p->w, &one, sizeof(Fr), hipMemcpyHostToDevice, st));
+    if (n_public) DVP_HIP(hipMemcpyAsync(p->w + 1, public_inputs, (size_t)n_public * 32, hipMemcpyHostToDevice, st));
+    if (n_private) DVP_HIP(hipMemcpyAsync(p->w + 1 + n_public, private_inputs, (size_t)n_private * 32, hipMemcpyHostToDevice, st));
+  }
+  DVP_HIP(hipMemsetAsync(p->flags, 0xff, 16, st));
+  Csr A{p->mat[0].row_ptr, p->mat[0].wire, p->mat[0].coeff, p->mat[0].n_rows};
+  Csr B{p->mat[1].row_ptr, p->mat[1].wire, p->mat[1].coeff, p->mat[1].n_rows};
+  Csr C{p->mat[2].row_ptr, p->mat[2].wire, p->mat[2].coeff, p->mat[2].n_rows};
+  dim3 gm(cdiv(m, PT)), bt(PT);
+  hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, n_public, m, p->E, p->flags);
+  // extend a, b, c', i from D to D'
+  DVP_HIP(hipMemcpyAsync(p->E2, p->E, 4 * (size_t)m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  {
+    ProfScope pe(PROF_EXTEND_TOTAL, st);
+    DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2, 4, st));
+    pe.stop();
+  }
+  // scalars of MSM A = [w | q2]
+  DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_quotient, gm, bt, 0, st, p->E2, p->z2inv, m, p->r2, p->SA + nw);
+  DVP_HIP(hipGetLastError());
+  {
+    unsigned long long f[2];
+    DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+    if (f[0] != ~0ull) {
+      g_last_error_index = (int64_t)f[0];
+      return DVP_EUNSAT;
+    }
+  }
+  int rc = msm_affine_dev(p->SA, p->bases_a, p->inf_a, nw + m, p->pts, p->pts_inf32, st);
+  if (rc != DVP_OK) return rc;
+  hipLaunchKernelGGL(k_inf32_to_8, dim3(1), dim3(1), 0, st, p->pts_inf32, p->pts_inf8);
+  DVP_TRY(encode_dev(p->pts, p->pts_inf8, 1, p->enc, st));
+  uint8_t commit_p[30];
+  DVP_HIP(hipMemcpyAsync(commit_p, p->enc, 30, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  uint8_t ch[32];
+  transcript_challenge(commit_p, public_inputs, n_public, ch);
+  Fr alpha;
+  memcpy(alpha.v, ch, 32);
+  p->alpha_canon = alpha;
+  Fr alpha_m = fr_to_mont(alpha);
+  Fr z_alpha_m = host_vanish(p, 0, alpha_m);
+  // denominators, batch inverse, barycentric a0,b0,i0
+  hipLaunchKernelGGL(k_alpha_denoms, gm, bt, 0, st, p->dD, p->dD2, alpha_m, m, p->den, p->den2, p->flags + 1);
+  DVP_TRY(batch_inverse_dev(p->den, m, st));
+  DVP_TRY(batch_inverse_dev(p->den2, m, st));
+  uint32_t nb = cdiv(m, PT);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_bary3_partial, dim3(nb), bt, 0, st, p->E, p->barw, p->den, m, p->partial);
+  hipLaunchKernelGGL(k_bary3_final, dim3(1), bt, 0, st, p->partial, nb, fr_neg(z_alpha_m), p->abir0);
+  hipLaunchKernelGGL(k_kscalars, gm, bt, 0, st, p->E, p->r2, p->den, p->den2, p->abir0, m, p->SK);
+  DVP_HIP(hipGetLastError());
+  rc = msm_affine_dev(p->SK, p->bases_k, p->inf_k, 4 * (size_t)m, p->pts + 1, p->pts_inf32 + 1, st);
+  if (rc != DVP_OK) return rc;
+  hipLaunchKernelGGL(k_inf32_to_8, dim3(1), dim3(1), 0, st, p->pts_inf32, p->pts_inf8);
+  DVP_TRY(encode_dev(p->pts, p->pts_inf8, 2, p->enc, st));
+  uint8_t enc[60];
+  unsigned long long f[2];
+  DVP_HIP(hipMemcpyAsync(enc, p->enc, 60, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipMemcpyAsync(p->abir0_host, p->abir0, 4 * sizeof(Fr), hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
+  ps.stop();
+  DVP_HIP(hipStreamSynchronize(st));
+  if (f[1] != ~0ull) {
+    g_last_error_index = (int64_t)f[1];
+    return DVP_ECHALLENGE;
+  }
+  memcpy(proof, enc, 60);
+  memcpy(proof + 60, p->abir0_host[0].v, 29);  // FrBits::from_fr(a0): 232 LE bits, src/curve.rs:30-40
+  memcpy(proof + 89, p->abir0_host[1].v, 29);
+  return DVP_OK;
+}
+
+// Parity-test access to the intermediates of the last dvp_prove call.  name in:
+//  "a","b","c","i" (m each), "a2","b2","c2","i2", "r2", "q2", "ka","kb" (m), "kr" (2m),
+//  "alpha","a0","b0","i0","r0" (1), "bar_wts","z_vals2inv","D","D2" (m, canonical)
+extern "C" int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems) {
+  if (!p || !name || !out) return DVP_EINVAL;
+  const size_t m = p->m;
+  std::string s(name);
+  const Fr* src = nullptr;
+  size_t n = m;
+  bool mont = false;
+  if (s == "a") src = p->E; else if (s == "b") src = p->E + m; else if (s == "c") src = p->E + 2 * m; else if (s == "i") src = p->E + 3 * m;
+  else if (s == "a2") src = p->E2; else if (s == "b2") src = p->E2 + m; else if (s == "c2") src = p->E2 + 2 * m; else if (s == "i2") src = p->E2 + 3 * m;
+  else if (s == "r2") src = p->r2; else if (s == "q2") src = p->SA + p->n_wires;
+  else if (s == "ka") src = p->SK; else if (s == "kb") src = p->SK + m; else if (s == "kr") { src = p->SK + 2 * m; n = 2 * m; }
+  else if (s == "bar_wts") { src = p->barw; mont = true; } else if (s == "z_vals2inv") { src = p->z2inv; mont = true; }
+  else if (s == "D") { src = p->dD; mont = true; } else if (s == "D2") { src = p->dD2; mont = true; }
+  else if (s == "alpha") { if (n_elems != 1) return DVP_EINVAL; memcpy(out, p->alpha_canon.v, 32); return DVP_OK; }
+  else if (s == "a0" || s == "b0" || s == "i0" || s == "r0") {
+    if (n_elems != 1) return DVP_EINVAL;
+    int k = s == "a0" ? 0 : s == "b0" ? 1 : s == "i0" ? 2 : 3;
+    memcpy(out, p->abir0_host[k].v, 32);
+    return DVP_OK;
+  } else return DVP_EINVAL;
+  if (n_elems != n) return DVP_EINVAL;
+  if (mont) {
+    DevBuf tmp;
+    DVP_TRY(tmp.alloc(n * sizeof(Fr)));
+    hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(n, PT)), dim3(PT), 0, 0, src, tmp.as<Fr>(), n);
+    DVP_HIP(hipMemcpy(out, tmp.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  } else {
+    DVP_HIP(hipMemcpy(out, src, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  }
+  return DVP_OK;
+}
+
+// Domain tables for setup-side callers (compute_barycentric_weights / evaluate_vanishing_poly_at_domain +
+// batch_inversion, src/ec_fft.rs:284-335,407-419): which = 0 -> (1/Z_D'(D), 1/Z_D(D')), which = 1 -> mirrored.
+extern "C" int dvp_prover_domain_tables(dvp_prover* p, int which, uint64_t* bar_weights, uint64_t* zinv_other) {
+  if (!p || !bar_weights || !zinv_other || (which != 0 && which != 1)) return DVP_EINVAL;
+  const size_t m = p->m;
+  dvp_ecfft* t = p->tree;
+  DevBuf bw, zi, o1, o2;
+  DVP_TRY(bw.alloc(m * sizeof(Fr)));
+  DVP_TRY(zi.alloc(m * sizeof(Fr)));
+  DVP_TRY(o1.alloc(m * sizeof(Fr)));
+  DVP_TRY(o2.alloc(m * sizeof(Fr)));
+  hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, (int)p->log_m,
+                     t->layer((int)p->log_m), which, bw.as<Fr>(), zi.as<Fr>());
+  hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, 0, bw.as<Fr>(), o1.as<Fr>(), m);
+  hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, 0, zi.as<Fr>(), o2.as<Fr>(), m);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(bar_weights, o1.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
+  DVP_HIP(hipMemcpy(zinv_other, o2.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+
+extern "C" int dvp_prover_domains(dvp_prover* p, uint64_t* d, uint64_t* d2) {
+  if (!p || !d || !d2) return DVP_EINVAL;
+  DVP_TRY(dvp_prover_debug_read(p, "D", d, p->m));
+  return dvp_prover_debug_read(p, "D2", d2, p->m);
+}

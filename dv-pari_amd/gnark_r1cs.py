@@ -1,0 +1,176 @@
+"""Host mirror of src/gnark_r1cs.rs: the sparse R1CS (rows of (wire_id, coeff_id) terms over a
+coefficient table), kept as three CSR matrices so it can be handed to the GPU prover unchanged."""
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import fr
+
+P = fr.P
+
+
+@dataclass
+class Csr:
+    row_ptr: np.ndarray  # uint32 [n_rows+1]
+    wire: np.ndarray     # uint32 [nnz]
+    coeff: np.ndarray    # uint32 [nnz]
+
+    @staticmethod
+    def from_rows(rows):
+        """rows: list of lists of (wire_id, coeff_id)"""
+        rp = np.zeros(len(rows) + 1, dtype=np.uint32)
+        rp[1:] = np.cumsum([len(r) for r in rows])
+        flat = [t for r in rows for t in r]
+        w = np.array([t[0] for t in flat], dtype=np.uint32)
+        c = np.array([t[1] for t in flat], dtype=np.uint32)
+        return Csr(rp, w, c)
+
+    def transpose(self, n_cols):
+        """CSR of the transpose: rows = wires, 'wire' column then holds the original row index."""
+        n_rows = self.row_ptr.shape[0] - 1
+        rows = np.repeat(np.arange(n_rows, dtype=np.uint32), np.diff(self.row_ptr).astype(np.int64))
+        order = np.argsort(self.wire, kind="stable")
+        rp = np.zeros(n_cols + 1, dtype=np.uint32)
+        np.add.at(rp, self.wire.astype(np.int64) + 1, 1)
+        rp = np.cumsum(rp).astype(np.uint32)
+        return Csr(rp, rows[order], self.coeff[order])
+
+
+@dataclass
+class R1CSInstance:
+    """R1CSInstance, src/gnark_r1cs.rs:263-296 (rows as CSR, coefficient table canonical)."""
+    num_constraints: int      # padded to a power of two
+    num_public_inputs: int
+    n_rows: int               # real rows
+    n_wires: int
+    l: Csr
+    r: Csr
+    o: Csr
+    coeffs: np.ndarray        # uint64 [n_coeffs, 4]
+
+    @staticmethod
+    def from_rows(rows, coeffs, num_public_inputs, n_wires=None):
+        """rows: list of (l_terms, r_terms, o_terms); coeffs: python ints."""
+        m = 1
+        while m < len(rows):
+            m *= 2
+        if n_wires is None:
+            n_wires = 1 + max(t[0] for row in rows for part in row for t in part)
+        return R1CSInstance(m, num_public_inputs, len(rows), n_wires, Csr.from_rows([r[0] for r in rows]),
+                            Csr.from_rows([r[1] for r in rows]), Csr.from_rows([r[2] for r in rows]), fr.vec(coeffs))
+
+    # ---- the SP1/gnark dump format, src/gnark_r1cs.rs:84-91,121-185 (writer mirrors :405-438) -------------
+    def to_dump_bytes(self) -> bytes:
+        out = [struct.pack("<I", self.coeffs.shape[0])]
+        for c in fr.to_ints(self.coeffs):
+            out.append(c.to_bytes(32, "big"))
+        out.append(struct.pack("<I", self.n_rows))
+        for i in range(self.n_rows):
+            parts = []
+            for m in (self.l, self.r, self.o):
+                a, b = int(m.row_ptr[i]), int(m.row_ptr[i + 1])
+                parts.append((m.wire[a:b], m.coeff[a:b]))
+            out.append(struct.pack("<III", *(len(p[0]) for p in parts)))
+            for w, c in parts:
+                inter = np.empty(2 * len(w), dtype="<u4")
+                inter[0::2], inter[1::2] = w, c
+                out.append(inter.tobytes())
+        return b"".join(out)
+
+    @staticmethod
+    def from_dump_bytes(buf: bytes, num_public_inputs: int):
+        """load_sparse_r1cs_from_file + from_dump, src/gnark_r1cs.rs:121-185,282-296."""
+        (nc,) = struct.unpack_from("<I", buf, 0)
+        off = 4
+        coeffs = [int.from_bytes(buf[off + 32 * i: off + 32 * (i + 1)], "big") % P for i in range(nc)]
+        off += 32 * nc
+        (nr,) = struct.unpack_from("<I", buf, off)
+        off += 4
+        rows = []
+        for _ in range(nr):
+            nl, nrr, no = struct.unpack_from("<III", buf, off)
+            off += 12
+            row = []
+            for cnt in (nl, nrr, no):
+                arr = np.frombuffer(buf, dtype="<u4", count=2 * cnt, offset=off)
+                off += 8 * cnt
+                row.append([(int(arr[2 * k]), int(arr[2 * k + 1])) for k in range(cnt)])
+            rows.append(tuple(row))
+        return R1CSInstance.from_rows(rows, coeffs, num_public_inputs)
+
+
+def load_witness_bytes(buf: bytes):
+    """witness file: u32-BE count || count x 32-byte BE elements (src/gnark_r1cs.rs:58-77,188-198)."""
+    (n,) = struct.unpack_from(">I", buf, 0)
+    return [int.from_bytes(buf[4 + 32 * i: 4 + 32 * (i + 1)], "big") % P for i in range(n)]
+
+
+def evaluate_monomial_basis_poly(public_inputs, alpha):
+    """src/gnark_r1cs.rs:391-399"""
+    acc, pw = 0, 1
+    for x in public_inputs:
+        acc = (acc + x * pw) % P
+        pw = pw * alpha % P
+    return acc
+
+
+TOY_COEFFS = [1, 2]
+TOY_ROWS = [  # src/dvsnark_test.rs:84-115 -- wires 1=0, o=1, w=2, y=3, z=4, x=5, t=6, s=7
+    ([(5, 0)], [(5, 0)], [(3, 0)]),
+    ([(3, 0), (4, 0)], [(0, 0)], [(2, 0)]),
+    ([(4, 1)], [(0, 0)], [(6, 0)]),
+    ([(5, 0), (6, 0)], [(0, 0)], [(7, 0)]),
+    ([(2, 0), (7, 0)], [(0, 0)], [(1, 0)]),
+]
+TOY_PUBLIC = [24, 13]
+TOY_PRIVATE = [9, 4, 3, 8, 11]
+
+
+def synthetic_dense(log_m: int, seed: int = 0x5EED0004, n_coeffs: int = 256):
+    """BASELINE config #4: m = 2^log_m real rows, n_wires = m, wires [1, pub0, pub1, private...]; row i is
+    (w[a] + c*w[b]) * w[d] = w[o] with a fresh o while wires remain, then identity rows w[a]*1 = w[a].
+    Returns (R1CSInstance, public_inputs, private_inputs), the witness built by forward evaluation."""
+    m = 1 << log_m
+    rng = np.random.default_rng(seed)
+    coeffs = [1] + [int.from_bytes(rng.bytes(28), "little") for _ in range(n_coeffs - 1)]
+    n_free = 4  # wires 0..3 are inputs: 1, pub0, pub1, priv0
+    w = [1] + [int.from_bytes(rng.bytes(28), "little") for _ in range(3)] + [0] * (m - n_free)
+    a_idx = rng.integers(0, 1 << 62, size=m)
+    b_idx = rng.integers(0, 1 << 62, size=m)
+    d_idx = rng.integers(0, 1 << 62, size=m)
+    c_idx = rng.integers(0, n_coeffs, size=m)
+    lw = np.zeros((m, 2), dtype=np.uint32)
+    lc = np.zeros((m, 2), dtype=np.uint32)
+    rw = np.zeros(m, dtype=np.uint32)
+    ow = np.zeros(m, dtype=np.uint32)
+    for i in range(m):
+        o = n_free + i
+        if o < m:
+            a, b, d = int(a_idx[i]) % o, int(b_idx[i]) % o, int(d_idx[i]) % o
+            ci = int(c_idx[i])
+            w[o] = (w[a] + coeffs[ci] * w[b]) % P * w[d] % P
+            lw[i] = (a, b)
+            lc[i] = (0, ci)
+            rw[i], ow[i] = d, o
+        else:  # wires exhausted: w[a] * 1 = w[a]
+            a = int(a_idx[i]) % m
+            lw[i] = (a, a)
+            lc[i] = (0, 0)
+            # (w[a] + 1*w[a]) * 1 = 2 w[a] would need a new wire; use l = {a}, so make the second term vanish:
+            rw[i], ow[i] = 0, a
+    # rows with two L terms, except the tail rows which have one
+    tail = max(0, m - (m - n_free))
+    n_l = np.full(m, 2, dtype=np.int64)
+    n_l[m - n_free:] = 1
+    rp_l = np.zeros(m + 1, dtype=np.uint32)
+    rp_l[1:] = np.cumsum(n_l)
+    mask = np.ones((m, 2), dtype=bool)
+    mask[m - n_free:, 1] = False
+    l = Csr(rp_l, lw[mask], lc[mask])
+    rp1 = np.arange(m + 1, dtype=np.uint32)
+    zeros = np.zeros(m, dtype=np.uint32)
+    r = Csr(rp1, rw, zeros)
+    o = Csr(rp1, ow, zeros.copy())
+    inst = R1CSInstance(m, 2, m, m, l, r, o, fr.vec(coeffs))
+    return inst, w[1:3], w[3:]

@@ -1,0 +1,140 @@
+"""Host mirror of src/proving.rs: Proof (to_bits/from_bits), Transcript challenge, and Proof::prove
+driven through the GPU prover context (dvp_prover_* / dvp_prove in include/dvpari.h)."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import fr
+from ._native import lib, check, ptr
+from .gnark_r1cs import R1CSInstance
+
+P = fr.P
+
+
+@dataclass
+class Proof:
+    """src/proving.rs:40-50"""
+    commit_p: bytes  # 30
+    kzg_k: bytes     # 30
+    a0: bytes        # 29 = 232 LE bits (FrBits)
+    b0: bytes
+
+    def to_bytes(self) -> bytes:
+        return self.commit_p + self.kzg_k + self.a0 + self.b0
+
+    @staticmethod
+    def from_bytes(b: bytes):
+        assert len(b) == 118
+        return Proof(b[:30], b[30:60], b[60:89], b[89:118])
+
+    def to_bits(self):
+        """Proof::to_bits, src/proving.rs:691-718 (LE bit order inside each byte)."""
+        return [(byte >> i) & 1 for byte in self.to_bytes() for i in range(8)]
+
+    @staticmethod
+    def from_bits(bits):
+        """Proof::from_bits, src/proving.rs:721-770."""
+        assert len(bits) == 944
+        by = bytes(sum(bits[8 * i + j] << j for j in range(8)) for i in range(118))
+        return Proof.from_bytes(by)
+
+    def a0_fr(self):
+        v = int.from_bytes(self.a0, "little")
+        return (v, True) if v < P else (0, False)  # FrBits::to_fr, src/curve.rs:43-59
+
+    def b0_fr(self):
+        v = int.from_bytes(self.b0, "little")
+        return (v, True) if v < P else (0, False)
+
+
+def transcript_challenge(commit_p: bytes, public_inputs) -> int:
+    """Transcript::output, src/proving.rs:164-197."""
+    cp = np.frombuffer(commit_p, dtype=np.uint8).copy()
+    pub = fr.vec(public_inputs) if len(public_inputs) else np.zeros((1, 4), dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    check(lib.dvp_transcript_challenge(ptr(cp), ptr(pub), len(public_inputs), ptr(out)), "dvp_transcript_challenge")
+    return fr.to_int(out)
+
+
+def blake3(data: bytes) -> bytes:
+    d = np.frombuffer(data, dtype=np.uint8).copy() if data else np.zeros(1, dtype=np.uint8)
+    out = np.zeros(32, dtype=np.uint8)
+    check(lib.dvp_blake3(ptr(d), len(data), ptr(out)), "dvp_blake3")
+    return out.tobytes()
+
+
+class Prover:
+    """The artefacts Proof::prove reads from cache_dir (R1CS dump, SRS point vectors, TREE_2N and the
+    prover precomputes, src/proving.rs:435-511,562-565,666-672), loaded once and kept in HBM."""
+
+    def __init__(self, inst: R1CSInstance):
+        self.inst = inst
+        self.m = inst.num_constraints
+        self.log_m = self.m.bit_length() - 1
+        h = C.c_void_p()
+        check(lib.dvp_prover_create(self.log_m, inst.num_public_inputs, inst.n_wires, C.byref(h)), "dvp_prover_create")
+        self._h = h
+        check(lib.dvp_prover_set_coeffs(h, ptr(inst.coeffs), inst.coeffs.shape[0]), "dvp_prover_set_coeffs")
+        for which, mat in enumerate((inst.l, inst.r, inst.o)):
+            check(lib.dvp_prover_set_matrix(h, which, inst.n_rows, ptr(mat.row_ptr), ptr(mat.wire), ptr(mat.coeff)),
+                  "dvp_prover_set_matrix")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dvp_prover_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- SRS -------------------------------------------------------------------------------------
+    def set_srs(self, srs):
+        for which, (xy, inf) in enumerate(srs.as_list()):
+            xy = np.ascontiguousarray(xy, dtype=np.uint64)
+            inf = np.ascontiguousarray(inf, dtype=np.uint8)
+            check(lib.dvp_prover_set_srs_affine(self._h, which, ptr(xy), ptr(inf), xy.shape[0]), "dvp_prover_set_srs_affine")
+
+    def set_srs_encoded(self, which: int, enc: np.ndarray):
+        """payload of a reference point-vector file (n x 30 bytes, src/io_utils.rs:83-111)"""
+        e = np.ascontiguousarray(enc, dtype=np.uint8).reshape(-1, 30)
+        check(lib.dvp_prover_set_srs_encoded(self._h, which, ptr(e), e.shape[0]), "dvp_prover_set_srs_encoded")
+
+    # ---- domain data -------------------------------------------------------------------------------
+    def domains(self):
+        d = np.zeros((self.m, 4), dtype=np.uint64)
+        d2 = np.zeros((self.m, 4), dtype=np.uint64)
+        check(lib.dvp_prover_domains(self._h, ptr(d), ptr(d2)), "dvp_prover_domains")
+        return d, d2
+
+    def domain_tables(self, which: int):
+        a = np.zeros((self.m, 4), dtype=np.uint64)
+        b = np.zeros((self.m, 4), dtype=np.uint64)
+        check(lib.dvp_prover_domain_tables(self._h, which, ptr(a), ptr(b)), "dvp_prover_domain_tables")
+        return a, b
+
+    def vanish_at(self, which: int, x: int) -> int:
+        """Z_D(x) / Z_D'(x) through the isogeny chain"""
+        from .ec_fft import FFTree  # noqa: F401  (same chain as dvp_ecfft_vanish_at, on the prover's own tree)
+        if not hasattr(self, "_tree"):
+            self._tree = FFTree(2 * self.m)
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib.dvp_ecfft_vanish_at(self._tree._h, which, ptr(fr.limbs(x)), ptr(out)), "dvp_ecfft_vanish_at")
+        return fr.to_int(out)
+
+    # ---- prove -------------------------------------------------------------------------------------
+    def prove(self, public_inputs, private_inputs) -> Proof:
+        """Proof::prove(cache_dir, public_inputs, private_inputs), src/proving.rs:426-688."""
+        pub = public_inputs if isinstance(public_inputs, np.ndarray) else fr.vec(public_inputs)
+        prv = private_inputs if isinstance(private_inputs, np.ndarray) else fr.vec(private_inputs)
+        pub = np.ascontiguousarray(pub, dtype=np.uint64).reshape(-1, 4)
+        prv = np.ascontiguousarray(prv, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(118, dtype=np.uint8)
+        check(lib.dvp_prove(self._h, ptr(pub), pub.shape[0], ptr(prv), prv.shape[0], ptr(out)), "dvp_prove")
+        return Proof.from_bytes(out.tobytes())
+
+    def debug(self, name: str, n: int = None):
+        if n is None:
+            n = 1 if name in ("alpha", "a0", "b0", "i0", "r0") else (2 * self.m if name == "kr" else self.m)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        check(lib.dvp_prover_debug_read(self._h, name.encode(), ptr(out), n), "dvp_prover_debug_read")
+        return out

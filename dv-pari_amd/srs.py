@@ -1,0 +1,106 @@
+"""Host mirror of src/srs.rs: Trapdoor, SRS, verifier_runs_setup (its arithmetic; the cache-dir file
+plumbing of the reference is out of scope) and verify.  Every vector stage runs on the GPU through
+the C ABI; python ints only appear for the handful of trapdoor scalars."""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import curve, fr
+from .gnark_r1cs import R1CSInstance, evaluate_monomial_basis_poly
+
+P = fr.P
+
+
+@dataclass
+class Trapdoor:
+    """src/srs.rs:41-50"""
+    tau: int
+    delta: int
+    epsilon: int
+
+
+@dataclass
+class SRS:
+    """src/srs.rs:30-39; bases as affine [n,8] uint64 + infinity masks."""
+    g_m: tuple
+    g_q: tuple
+    g_k: tuple  # three (xy, inf) pairs
+
+    def as_list(self):
+        return [self.g_m, self.g_q, self.g_k[0], self.g_k[1], self.g_k[2]]
+
+
+def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
+    """The scalars k with base = k*G for every SRS vector: verifier_runs_setup + compute_srs_matrices,
+    src/srs.rs:112-167,177-361 (Lagrange bases at tau through the barycentric formula,
+    src/ec_fft.rs:340-390,424-450; accumulate_m_values, src/srs.rs:53-84)."""
+    assert td.tau % P and td.delta % P and td.epsilon % P  # src/srs.rs:199-201
+    m = inst.num_constraints
+    d, d2 = prover.domains()
+    bar, z2inv = prover.domain_tables(0)      # 1/Z_D'(D_i), 1/Z_D(D'_i)
+    bard, z2dinv = prover.domain_tables(1)    # 1/Z_D''(D'_i), 1/Z_D'(D_i)
+    z_tau = prover.vanish_at(0, td.tau)
+    zd_tau = prover.vanish_at(1, td.tau)
+    assert z_tau and zd_tau
+    delta2 = td.delta * td.delta % P
+    # L_i(tau) = Z(tau) / ((tau - s_i) Z'(s_i))
+    l_tau = fr.scale(fr.mul(fr.batch_inverse(fr.scalar_sub(td.tau, d)), bar), z_tau)
+    l_taud = fr.scale(fr.mul(fr.batch_inverse(fr.scalar_sub(td.tau, d2)), bard), zd_tau)
+    l_taul = np.empty((2 * m, 4), dtype=np.uint64)  # unified domain, interleaved (src/ec_fft.rs:445-448)
+    l_taul[0::2] = fr.scale(fr.mul(l_tau, z2dinv), zd_tau)
+    l_taul[1::2] = fr.scale(fr.mul(l_taud, z2inv), z_tau)
+    # m_j(tau, delta) = sum_i (A_ij + delta B_ij + delta^2 C'_ij) L_i(tau), C' = C - D (Vandermonde on the public wires)
+    lt_rows = l_tau[: inst.n_rows]
+    mv = fr.to_ints(fr.spmv(*_t(inst.l, inst.n_wires), inst.coeffs, lt_rows))
+    mb = fr.to_ints(fr.spmv(*_t(inst.r, inst.n_wires), inst.coeffs, lt_rows))
+    mc = fr.to_ints(fr.spmv(*_t(inst.o, inst.n_wires), inst.coeffs, lt_rows))
+    m_vals = [(a + td.delta * b + delta2 * c) % P for a, b, c in zip(mv, mb, mc)]
+    pw = fr.vec([1] * m)
+    for j in range(inst.num_public_inputs):  # -d_i^j on wire 1+j of every row (src/gnark_r1cs.rs:333-386)
+        m_vals[1 + j] = (m_vals[1 + j] - delta2 * fr.dot(pw, l_tau)) % P
+        pw = fr.mul(pw, d)
+    g_m = fr.scale(fr.vec(m_vals), td.epsilon)
+    g_q = fr.scale(l_taud, z_tau * delta2 % P * td.epsilon % P)
+    g_k = [l_tau, fr.scale(l_tau, td.delta), fr.scale(l_taul, delta2)]
+    return g_m, g_q, g_k
+
+
+def _t(csr, n_wires):
+    t = csr.transpose(n_wires)
+    return t.row_ptr, t.wire, t.coeff
+
+
+def verifier_runs_setup(prover, inst: R1CSInstance, td: Trapdoor) -> SRS:
+    """SRS::verifier_runs_setup, src/srs.rs:177-361: the 6m fixed-base multiplications of
+    compute_srs_matrices (:126-160) run as one batched GPU kernel per vector."""
+    g_m, g_q, g_k = srs_scalars(prover, inst, td)
+    mg = curve.point_scalar_mul_gen_batch
+    return SRS(mg(g_m), mg(g_q), tuple(mg(v) for v in g_k))
+
+
+def verify(td: Trapdoor, public_inputs, proof) -> bool:
+    """SRS::verify, src/srs.rs:374-428."""
+    from .proving import Proof, transcript_challenge
+
+    pr = proof if isinstance(proof, Proof) else Proof.from_bytes(proof)
+    try:
+        pts, inf = curve.from_bytes(np.frombuffer(pr.commit_p + pr.kzg_k, dtype=np.uint8).reshape(2, 30))
+    except Exception:
+        return False
+    a0, ok_a = pr.a0_fr()
+    b0, ok_b = pr.b0_fr()
+    if not (ok_a and ok_b):
+        return False
+    alpha = transcript_challenge(pr.commit_p, public_inputs)
+    i0 = evaluate_monomial_basis_poly(public_inputs, alpha)
+    r0 = (a0 * b0 - i0) % P
+    delta2 = td.delta * td.delta % P
+    u0 = (a0 + td.delta * b0 + delta2 * r0) % P * td.epsilon % P
+    v0 = (td.tau - alpha) * td.epsilon % P
+    gxy, ginf = curve.point_scalar_mul_gen_batch(fr.vec([1]))
+    bases = np.stack([pts[1], gxy[0]])
+    binf = np.array([inf[1], 0], dtype=np.uint8)
+    lhs, lhs_inf = curve.multi_scalar_mul(fr.vec([v0, u0]), bases, binf)
+    if lhs_inf or inf[0]:
+        return bool(lhs_inf) and bool(inf[0])
+    return bool((lhs == pts[0]).all())

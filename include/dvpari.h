@@ -52,6 +52,12 @@ int dvp_set_device(int device_id);
 /* last failing index for DVP_EDECODE / DVP_EUNSAT / DVP_EINVAL (thread-local), or -1 */
 int64_t dvp_last_error_index(void);
 
+/* Per-kernel HIP-event timers for the measurement harness (bench.py): off by default.  Names:
+ * "msm_accum_affine" (the dominant MSM kernel), "msm_total", "extend_total", "prove_total". */
+void dvp_profile_enable(int on);
+void dvp_profile_reset(void);
+int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
+
 /* ------------------------------------------------------------------------------------------ */
 /* ECFFT over Fr -- replaces ecfft::FFTree as built by build_sect_ecfft_tree                    */
 /* (src/ec_fft.rs:197-239) and used through extend/enter/exit.                                  */
@@ -87,6 +93,15 @@ int dvp_ecfft_vanish_at(const dvp_ecfft* ctx, int which, const uint64_t x[4], ui
 /* ------------------------------------------------------------------------------------------ */
 int dvp_fr_batch_inverse(uint64_t* vals, size_t n); /* in place; zeros stay zero */
 int dvp_fr_batch_inverse_dev(void* d_vals, size_t n, void* stream);
+/* the rayon pointwise maps of src/proving.rs:492-654 and the setup loops of src/srs.rs:53-84,138-160
+ * as reusable vector ops (canonical in, canonical out): out = a o b ; out = s*a ; out = s - a ;
+ * <a,b> ; sparse rows out[r] = sum coeffs[cid]*x[col] (eval_row, src/gnark_r1cs.rs:273-280) */
+int dvp_fr_vec_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
+int dvp_fr_vec_scale(const uint64_t* a, const uint64_t s[4], size_t n, uint64_t* out);
+int dvp_fr_vec_scalar_sub(const uint64_t s[4], const uint64_t* a, size_t n, uint64_t* out);
+int dvp_fr_vec_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
+int dvp_fr_spmv(const uint32_t* row_ptr, const uint32_t* col, const uint32_t* coeff_ids, uint32_t n_rows,
+                const uint64_t* coeffs, uint32_t n_coeffs, const uint64_t* x, uint32_t n_cols, uint64_t* out);
 int dvp_barycentric_eval(const uint64_t* domain, const uint64_t* bar_weights, const uint64_t z_at_alpha[4],
                          const uint64_t* evals, size_t n, const uint64_t alpha[4], uint64_t out[4]);
 
@@ -112,6 +127,44 @@ int dvp_mulgen_batch_affine(const uint64_t* scalars, size_t n, uint64_t* out_xy 
 /* CurvePoint::to_bytes / from_bytes over vectors (src/curve.rs:93-109, src/io_utils.rs:217-226) */
 int dvp_points_encode(const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* out_enc);
 int dvp_points_decode(const uint8_t* enc, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Prover -- Proof::prove(cache_dir, public_inputs, private_inputs), src/proving.rs:426-688,      */
+/* with the cache_dir artefacts handed over once and kept resident in HBM.                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct dvp_prover dvp_prover;
+
+/* m = 2^log2_m constraints (R1CSInstance::num_constraints, src/gnark_r1cs.rs:291); witness vector
+ * = [1, public.., private..] of n_wires entries (src/proving.rs:355-359).  Builds TREE_2N and the
+ * prover precomputes of prover_prepares_precomputes (src/proving.rs:225-325) on the device. */
+int dvp_prover_create(uint32_t log2_m, uint32_t n_public, uint32_t n_wires, dvp_prover** out);
+void dvp_prover_destroy(dvp_prover* p);
+/* coefficient table of the R1CS dump (canonical; src/gnark_r1cs.rs:282-296) */
+int dvp_prover_set_coeffs(dvp_prover* p, const uint64_t* coeffs, uint32_t n);
+/* one of L/R/O (which = 0/1/2) as CSR over n_rows <= m rows of (wire_id, coeff_id) terms
+ * (src/gnark_r1cs.rs:97-119).  The Vandermonde fold of update_to_include_vandermode_matrix_d
+ * (:333-386) is applied inside the kernel, do not pre-apply it. */
+int dvp_prover_set_matrix(dvp_prover* p, int which, uint32_t n_rows, const uint32_t* row_ptr, const uint32_t* wire_ids,
+                          const uint32_t* coeff_ids);
+/* SRS vectors, which = 0 g_m (n_wires), 1 g_q (m), 2 g_k_0 (m), 3 g_k_1 (m), 4 g_k_2 (2m)
+ * (src/artifacts.rs:18-83, src/srs.rs:126-160): file payload (n x 30 B) or affine. */
+int dvp_prover_set_srs_encoded(dvp_prover* p, int which, const uint8_t* enc, size_t n);
+int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_t* xy, const uint8_t* inf, size_t n);
+int dvp_prover_set_srs_affine_dev(dvp_prover* p, int which, const void* d_xy, const void* d_inf, size_t n);
+/* proof = commit_p[30] | kzg_k[30] | a0[29] | b0[29]: the byte image of Proof::to_bits (:691-718) */
+int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
+              uint32_t n_private, uint8_t proof[118]);
+/* intermediates of the last proof, for parity tests (names: see prove.hip) */
+int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);
+/* (D, D') = get_both_domains(tree2n), src/ec_fft.rs:179-189 */
+int dvp_prover_domains(dvp_prover* p, uint64_t* d, uint64_t* d2);
+/* which = 0: (1/Z_D'(D_i), 1/Z_D(D'_i)) = (bar_wts, z_vals2inv); which = 1: the D' mirrors
+ * (bar_wtsd, z_vals2d_inv) -- compute_barycentric_weights / prepare_z_inv, src/srs.rs:267-311 */
+int dvp_prover_domain_tables(dvp_prover* p, int which, uint64_t* bar_weights, uint64_t* zinv_other);
+
+/* Transcript::output, src/proving.rs:164-197, and the BLAKE3 hash it is built on */
+int dvp_transcript_challenge(const uint8_t commit_p[30], const uint64_t* public_inputs, uint32_t n_public, uint64_t out[4]);
+int dvp_blake3(const uint8_t* data, size_t len, uint8_t out[32]);
 
 #ifdef __cplusplus
 }

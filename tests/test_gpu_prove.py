@@ -1,0 +1,127 @@
+"""GPU parity tests (-m gpu): Proof::prove end to end through the C ABI.
+
+  * BASELINE config #1 (toy R1CS of src/dvsnark_test.rs:131-180): every stage vector, the challenge,
+    a0/b0 and both commitments are compared bit-exactly with the golden values frozen from the
+    oracle, and the designated-verifier check (src/srs.rs:374-428) accepts.
+  * a 2^8-row synthetic R1CS: same comparison against the oracle run live.
+  * 2^14 rows: verify == true, tamper -> false, unsatisfied witness -> DVP_EUNSAT with the row index.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyref as o
+import c_oracle as co
+from util import to_limbs, from_limbs
+
+pytestmark = pytest.mark.gpu
+VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+
+
+def H(s):
+    return int(s, 16)
+
+
+def rows_of(inst):
+    rows = []
+    for i in range(inst.n_rows):
+        row = []
+        for mt in (inst.l, inst.r, inst.o):
+            a, b = int(mt.row_ptr[i]), int(mt.row_ptr[i + 1])
+            row.append([(int(mt.wire[k]), int(mt.coeff[k])) for k in range(a, b)])
+        rows.append(tuple(row))
+    return rows
+
+
+def test_transcript_and_blake3(dvp):
+    for n, h in VEC["blake3"].items():
+        assert dvp.proving.blake3(bytes(i % 251 for i in range(int(n)))).hex() == h
+    assert hex(dvp.proving.transcript_challenge(bytes(range(30)), o.TOY_PUBLIC)) == VEC["challenge_toy"]
+
+
+def check_against_oracle(dvp, inst, pub, prv, trap, golden=None):
+    pv = dvp.proving.Prover(inst)
+    td = dvp.srs.Trapdoor(*trap)
+    # setup scalars vs the oracle's brute-force setup
+    tree = o.FFTree(pv.log_m + 1)
+    st = o.setup_srs_scalars(tree, rows_of(inst), from_limbs(inst.coeffs), inst.num_public_inputs, trap)
+    g_m, g_q, g_k = dvp.srs.srs_scalars(pv, inst, td)
+    assert from_limbs(g_m) == st["g_m"] + [0] * (inst.n_wires - len(st["g_m"]))
+    assert from_limbs(g_q) == st["g_q"]
+    for j in range(3):
+        assert from_limbs(g_k[j]) == st["g_k"][j]
+    assert from_limbs(pv.debug("bar_wts")) == st["tables"]["bar_wts"]
+    assert from_limbs(pv.debug("z_vals2inv")) == st["tables"]["z_vals2inv"]
+    d, d2 = pv.domains()
+    assert (from_limbs(d), from_limbs(d2)) == tuple(tree.both_domains())
+    srs = dvp.srs.verifier_runs_setup(pv, inst, td)
+    pv.set_srs(srs)
+    proof = pv.prove(pub, prv)
+
+    def alpha_fn(dl):
+        return o.transcript_challenge(co.xsk233_encode(co.k233_mulgen(dl)), pub)
+
+    pr = o.prove_scalars(tree, st, pub, prv, alpha_fn)
+    for key in ("a", "b", "c", "i", "a2", "b2", "c2", "i2", "r2", "q2", "ka", "kb", "kr"):
+        assert from_limbs(pv.debug(key)) == pr[key], key
+    for key in ("alpha", "a0", "b0", "i0", "r0"):
+        assert from_limbs(pv.debug(key))[0] == pr[key], key
+    assert proof.commit_p == co.xsk233_encode(co.k233_mulgen(pr["dl_commit_p"]))
+    assert proof.kzg_k == co.xsk233_encode(co.k233_mulgen(pr["dl_kzg"]))
+    assert proof.a0_fr() == (pr["a0"], True) and proof.b0_fr() == (pr["b0"], True)
+    assert o.verify_dl(trap, pub, pr["dl_commit_p"], pr["dl_kzg"], pr["a0"], pr["b0"], pr["alpha"])
+    assert dvp.srs.verify(td, pub, proof)
+    assert dvp.proving.Proof.from_bits(proof.to_bits()) == proof
+    assert proof.to_bits() == o.proof_to_bits(proof.commit_p, proof.kzg_k, pr["a0"], pr["b0"])
+    if golden:
+        assert proof.commit_p.hex() == golden["commit_p"] and proof.kzg_k.hex() == golden["kzg_k"]
+        assert hex(pr["alpha"]) == golden["alpha"]
+    return pv, td, proof
+
+
+def test_toy_r1cs_config1(dvp):
+    """test_dvsnark_prover_over_toy_r1cs, src/dvsnark_test.rs:131-180, on the GPU path."""
+    toy = VEC["toy"]
+    inst = dvp.gnark_r1cs.R1CSInstance.from_rows(dvp.gnark_r1cs.TOY_ROWS, dvp.gnark_r1cs.TOY_COEFFS, 2)
+    assert inst.num_constraints == 8 and inst.n_wires == 8
+    trap = tuple(H(x) for x in toy["trapdoor"])
+    pv, td, proof = check_against_oracle(dvp, inst, o.TOY_PUBLIC, o.TOY_PRIVATE, trap, golden=toy)
+    # wrong public input must be rejected by the verifier
+    assert not dvp.srs.verify(td, [25, 13], proof)
+    # a witness that violates row 2 (2z*1 = t) is reported, not proved
+    bad = list(o.TOY_PRIVATE)
+    bad[3] += 1
+    with pytest.raises(dvp.DvpError) as ei:
+        pv.prove(o.TOY_PUBLIC, bad)
+    assert ei.value.status == -3 and ei.value.index == 2
+
+
+def test_synthetic_2_8_vs_oracle(dvp):
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(8)
+    rnd = random.Random(8)
+    trap = (rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    check_against_oracle(dvp, inst, pub, prv, trap)
+
+
+def test_synthetic_2_14_verifies(dvp):
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(14)
+    rnd = random.Random(14)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    proof = pv.prove(pub, prv)
+    assert dvp.srs.verify(td, pub, proof)
+    # proofs are deterministic (bit-identical bytes on a re-run)
+    assert pv.prove(pub, prv) == proof
+    tampered = dvp.proving.Proof(proof.commit_p, proof.kzg_k, (int.from_bytes(proof.a0, "little") ^ 1).to_bytes(29, "little"), proof.b0)
+    assert not dvp.srs.verify(td, pub, tampered)
+    assert not dvp.srs.verify(td, [pub[0], (pub[1] + 1) % o.P], proof)
+    # SRS handed over in the reference's file format (30-byte encodings) gives the same proof
+    pv2 = dvp.proving.Prover(inst)
+    srs = dvp.srs.verifier_runs_setup(pv2, inst, td)
+    for which, (xy, inf) in enumerate(srs.as_list()):
+        pv2.set_srs_encoded(which, dvp.curve.to_bytes(xy, inf))
+    assert pv2.prove(pub, prv) == proof
