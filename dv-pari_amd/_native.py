@@ -59,6 +59,12 @@ _SIGS = {
     "dvp_prover_set_srs_affine": (C.c_int, [vp, C.c_int, u64p, u8p, sz]),
     "dvp_prover_set_srs_affine_dev": (C.c_int, [vp, C.c_int, vp, vp, sz]),
     "dvp_prove": (C.c_int, [vp, u64p, u32, u64p, u32, u8p]),
+    "dvp_prove_dev": (C.c_int, [vp, vp, u8p, vp]),
+    "dvp_prove_begin": (C.c_int, [vp, vp, vp]),
+    "dvp_prover_msm_size": (C.c_size_t, [vp, C.c_int]),
+    "dvp_prover_msm_partial": (C.c_int, [vp, C.c_int, sz, sz, vp, vp, vp]),
+    "dvp_prove_challenge": (C.c_int, [vp, vp, vp, vp]),
+    "dvp_prove_finish": (C.c_int, [vp, vp, vp, u8p, vp]),
     "dvp_prover_debug_read": (C.c_int, [vp, C.c_char_p, u64p, sz]),
     "dvp_prover_domains": (C.c_int, [vp, u64p, u64p]),
     "dvp_prover_domain_tables": (C.c_int, [vp, C.c_int, u64p, u64p]),

@@ -242,6 +242,8 @@ struct dvp_prover {
   Fr ctop_host[2];                      // layer log_m leaves (collapse points of D, D'), Montgomery
   // last-proof intermediates kept for parity tests
   Fr alpha_canon, abir0_host[4];
+  std::vector<uint64_t> pub_host;
+  uint8_t commit_p_host[30];
 };
 
 static const int PT = 256;
@@ -448,67 +450,87 @@ extern "C" int dvp_blake3(const uint8_t* data, size_t len, uint8_t out[32]) {
   return DVP_OK;
 }
 
-// Proof::prove(cache_dir, public_inputs, private_inputs) -> Proof, src/proving.rs:426-688.
-// proof = commit_p[30] | kzg_k[30] | a0[29 LE] | b0[29 LE]  (the byte image of Proof::to_bits, :691-718)
-extern "C" int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
-                         uint32_t n_private, uint8_t proof[118]) {
-  if (!p || !proof || n_public != p->n_pub || 1 + n_public + n_private != p->n_wires) return DVP_EINVAL;
-  if ((n_public && !public_inputs) || (n_private && !private_inputs)) return DVP_EINVAL;
+// ---- Proof::prove in phases ------------------------------------------------------------------------
+// The two MSMs are the only stages that shard across GPUs, so prove is exposed as
+//   begin -> [commitment MSM, possibly partial per rank] -> challenge -> [K MSM] -> finish
+// and dvp_prove / dvp_prove_dev run the phases back to back on one device.
+static bool prover_ready(dvp_prover* p) {
   for (int k = 0; k < 5; ++k)
-    if (!p->have_srs[k]) return DVP_EINVAL;
-  if (!p->coeffs_m || !p->mat[0].row_ptr || !p->mat[1].row_ptr || !p->mat[2].row_ptr) return DVP_EINVAL;
-  hipStream_t st = 0;
+    if (!p->have_srs[k]) return false;
+  return p->coeffs_m && p->mat[0].row_ptr && p->mat[1].row_ptr && p->mat[2].row_ptr;
+}
+
+// phase 1 (src/proving.rs:434-508): assignment -> a,b,c',i -> extend -> q2; leaves SA = [w | q2].
+// d_assignment: n_wires canonical Fr = [1, public.., private..] already in HBM.
+extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream) {
+  if (!p || !d_assignment || !prover_ready(p)) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
   const size_t nw = p->n_wires;
-  ProfScope ps(PROF_PROVE_TOTAL, st);
-  // assignment = [1, public, private]  (src/proving.rs:449-452)
-  {
-    Fr one = fr_one_canon();
-    DVP_HIP(hipMemcpyAsync(p->w, &one, sizeof(Fr), hipMemcpyHostToDevice, st));
-    if (n_public) DVP_HIP(hipMemcpyAsync(p->w + 1, public_inputs, (size_t)n_public * 32, hipMemcpyHostToDevice, st));
-    if (n_private) DVP_HIP(hipMemcpyAsync(p->w + 1 + n_public, private_inputs, (size_t)n_private * 32, hipMemcpyHostToDevice, st));
-  }
+  if (d_assignment != p->w) DVP_HIP(hipMemcpyAsync(p->w, d_assignment, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  p->pub_host.resize((size_t)p->n_pub * 4);
+  if (p->n_pub) DVP_HIP(hipMemcpyAsync(p->pub_host.data(), p->w + 1, (size_t)p->n_pub * 32, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemsetAsync(p->flags, 0xff, 16, st));
   Csr A{p->mat[0].row_ptr, p->mat[0].wire, p->mat[0].coeff, p->mat[0].n_rows};
   Csr B{p->mat[1].row_ptr, p->mat[1].wire, p->mat[1].coeff, p->mat[1].n_rows};
   Csr C{p->mat[2].row_ptr, p->mat[2].wire, p->mat[2].coeff, p->mat[2].n_rows};
   dim3 gm(cdiv(m, PT)), bt(PT);
-  hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, n_public, m, p->E, p->flags);
-  // extend a, b, c', i from D to D'
+  hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, p->n_pub, m, p->E, p->flags);
   DVP_HIP(hipMemcpyAsync(p->E2, p->E, 4 * (size_t)m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   {
     ProfScope pe(PROF_EXTEND_TOTAL, st);
     DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2, 4, st));
     pe.stop();
   }
-  // scalars of MSM A = [w | q2]
   DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_quotient, gm, bt, 0, st, p->E2, p->z2inv, m, p->r2, p->SA + nw);
   DVP_HIP(hipGetLastError());
-  {
-    unsigned long long f[2];
-    DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
-    DVP_HIP(hipStreamSynchronize(st));
-    if (f[0] != ~0ull) {
-      g_last_error_index = (int64_t)f[0];
-      return DVP_EUNSAT;
-    }
+  unsigned long long f[2];
+  DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  if (f[0] != ~0ull) {
+    g_last_error_index = (int64_t)f[0];
+    return DVP_EUNSAT;  // assert_eq!(a*b, c+i), src/proving.rs:389-395
   }
-  int rc = msm_affine_dev(p->SA, p->bases_a, p->inf_a, nw + m, p->pts, p->pts_inf32, st);
-  if (rc != DVP_OK) return rc;
+  return DVP_OK;
+}
+
+// which = 0: <[w | q2], [g_m | g_q]> (n_wires + m terms; commit_p = msm_q + msm_gm, src/proving.rs:463,512,515)
+// which = 1: <[k_a | k_b | k_r], [g_k_0 | g_k_1 | g_k_2]> (4m terms, src/proving.rs:666-680)
+// restricted to the index range [lo, hi): the per-GPU shard of the sum.
+extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
+  if (!p || (which != 0 && which != 1) || !d_out_xy || !d_out_inf) return DVP_EINVAL;
+  size_t total = which ? 4 * (size_t)p->m : (size_t)p->n_wires + p->m;
+  if (lo > hi || hi > total) return DVP_EINVAL;
+  const Fr* sc = which ? p->SK : p->SA;
+  const Aff* bs = which ? p->bases_k : p->bases_a;
+  const uint8_t* inf = which ? p->inf_k : p->inf_a;
+  return msm_affine_dev(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, (hipStream_t)stream);
+}
+extern "C" size_t dvp_prover_msm_size(const dvp_prover* p, int which) {
+  if (!p) return 0;
+  return which ? 4 * (size_t)p->m : (size_t)p->n_wires + p->m;
+}
+
+// phase 2 (src/proving.rs:515-654): commit_p -> alpha -> a0,b0,i0,r0 -> K scalars SK.
+extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream) {
+  if (!p || !d_commit_xy || !d_commit_inf) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t m = p->m;
+  dim3 gm(cdiv(m, PT)), bt(PT);
+  if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
+  if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_inf32_to_8, dim3(1), dim3(1), 0, st, p->pts_inf32, p->pts_inf8);
   DVP_TRY(encode_dev(p->pts, p->pts_inf8, 1, p->enc, st));
-  uint8_t commit_p[30];
-  DVP_HIP(hipMemcpyAsync(commit_p, p->enc, 30, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
   uint8_t ch[32];
-  transcript_challenge(commit_p, public_inputs, n_public, ch);
+  transcript_challenge(p->commit_p_host, p->pub_host.data(), p->n_pub, ch);
   Fr alpha;
   memcpy(alpha.v, ch, 32);
   p->alpha_canon = alpha;
   Fr alpha_m = fr_to_mont(alpha);
   Fr z_alpha_m = host_vanish(p, 0, alpha_m);
-  // denominators, batch inverse, barycentric a0,b0,i0
   hipLaunchKernelGGL(k_alpha_denoms, gm, bt, 0, st, p->dD, p->dD2, alpha_m, m, p->den, p->den2, p->flags + 1);
   DVP_TRY(batch_inverse_dev(p->den, m, st));
   DVP_TRY(batch_inverse_dev(p->den2, m, st));
@@ -518,25 +540,60 @@ extern "C" int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t 
   hipLaunchKernelGGL(k_bary3_final, dim3(1), bt, 0, st, p->partial, nb, fr_neg(z_alpha_m), p->abir0);
   hipLaunchKernelGGL(k_kscalars, gm, bt, 0, st, p->E, p->r2, p->den, p->den2, p->abir0, m, p->SK);
   DVP_HIP(hipGetLastError());
-  rc = msm_affine_dev(p->SK, p->bases_k, p->inf_k, 4 * (size_t)m, p->pts + 1, p->pts_inf32 + 1, st);
-  if (rc != DVP_OK) return rc;
+  return DVP_OK;
+}
+
+// phase 3 (src/proving.rs:682-687): kzg_k -> bytes; proof = commit_p | kzg_k | a0 | b0.
+extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream) {
+  if (!p || !d_kzg_xy || !d_kzg_inf || !proof) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (d_kzg_xy != p->pts + 1) DVP_HIP(hipMemcpyAsync(p->pts + 1, d_kzg_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
+  if (d_kzg_inf != p->pts_inf32 + 1) DVP_HIP(hipMemcpyAsync(p->pts_inf32 + 1, d_kzg_inf, 4, hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(k_inf32_to_8, dim3(1), dim3(1), 0, st, p->pts_inf32, p->pts_inf8);
-  DVP_TRY(encode_dev(p->pts, p->pts_inf8, 2, p->enc, st));
-  uint8_t enc[60];
+  DVP_TRY(encode_dev(p->pts + 1, p->pts_inf8 + 1, 1, p->enc + 30, st));
+  uint8_t kz[30];
   unsigned long long f[2];
-  DVP_HIP(hipMemcpyAsync(enc, p->enc, 60, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipMemcpyAsync(kz, p->enc + 30, 30, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemcpyAsync(p->abir0_host, p->abir0, 4 * sizeof(Fr), hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
-  ps.stop();
   DVP_HIP(hipStreamSynchronize(st));
   if (f[1] != ~0ull) {
     g_last_error_index = (int64_t)f[1];
-    return DVP_ECHALLENGE;
+    return DVP_ECHALLENGE;  // alpha in D u D', src/proving.rs:548-556
   }
-  memcpy(proof, enc, 60);
+  memcpy(proof, p->commit_p_host, 30);
+  memcpy(proof + 30, kz, 30);
   memcpy(proof + 60, p->abir0_host[0].v, 29);  // FrBits::from_fr(a0): 232 LE bits, src/curve.rs:30-40
   memcpy(proof + 89, p->abir0_host[1].v, 29);
   return DVP_OK;
+}
+
+// Proof::prove with the assignment already resident in HBM (the timed configuration of bench.py)
+extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t proof[118], void* stream) {
+  if (!p || !d_assignment || !proof) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  ProfScope ps(PROF_PROVE_TOTAL, st);
+  DVP_TRY(dvp_prove_begin(p, d_assignment, stream));
+  DVP_TRY(dvp_prover_msm_partial(p, 0, 0, dvp_prover_msm_size(p, 0), p->pts, p->pts_inf32, stream));
+  DVP_TRY(dvp_prove_challenge(p, p->pts, p->pts_inf32, stream));
+  DVP_TRY(dvp_prover_msm_partial(p, 1, 0, dvp_prover_msm_size(p, 1), p->pts + 1, p->pts_inf32 + 1, stream));
+  ps.stop();
+  return dvp_prove_finish(p, p->pts + 1, p->pts_inf32 + 1, proof, stream);
+}
+
+// Proof::prove(cache_dir, public_inputs, private_inputs) -> Proof, src/proving.rs:426-688 (host witness).
+// proof = commit_p[30] | kzg_k[30] | a0[29 LE] | b0[29 LE]  (the byte image of Proof::to_bits, :691-718)
+extern "C" int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
+                         uint32_t n_private, uint8_t proof[118]) {
+  if (!p || !proof || n_public != p->n_pub || 1 + n_public + n_private != p->n_wires) return DVP_EINVAL;
+  if ((n_public && !public_inputs) || (n_private && !private_inputs)) return DVP_EINVAL;
+  if (!prover_ready(p)) return DVP_EINVAL;
+  // assignment = [1, public, private]  (src/proving.rs:449-452)
+  Fr one = fr_one_canon();
+  DVP_HIP(hipMemcpy(p->w, &one, sizeof(Fr), hipMemcpyHostToDevice));
+  if (n_public) DVP_HIP(hipMemcpy(p->w + 1, public_inputs, (size_t)n_public * 32, hipMemcpyHostToDevice));
+  if (n_private) DVP_HIP(hipMemcpy(p->w + 1 + n_public, private_inputs, (size_t)n_private * 32, hipMemcpyHostToDevice));
+  return dvp_prove_dev(p, p->w, proof, nullptr);
 }
 
 // Parity-test access to the intermediates of the last dvp_prove call.  name in:

@@ -138,3 +138,27 @@ class Prover:
         out = np.zeros((n, 4), dtype=np.uint64)
         check(lib.dvp_prover_debug_read(self._h, name.encode(), ptr(out), n), "dvp_prover_debug_read")
         return out
+
+    # ---- device-resident / phased flavours --------------------------------------------------------------
+    def prove_dev(self, d_assignment: int, stream: int = 0) -> Proof:
+        """assignment = [1, public.., private..] as n_wires x 4 uint64 already in HBM (device pointer)."""
+        out = np.zeros(118, dtype=np.uint8)
+        check(lib.dvp_prove_dev(self._h, d_assignment, ptr(out), stream), "dvp_prove_dev")
+        return Proof.from_bytes(out.tobytes())
+
+    def begin(self, d_assignment: int, stream: int = 0):
+        check(lib.dvp_prove_begin(self._h, d_assignment, stream), "dvp_prove_begin")
+
+    def msm_size(self, which: int) -> int:
+        return int(lib.dvp_prover_msm_size(self._h, which))
+
+    def msm_partial(self, which: int, lo: int, hi: int, d_out_xy: int, d_out_inf: int, stream: int = 0):
+        check(lib.dvp_prover_msm_partial(self._h, which, lo, hi, d_out_xy, d_out_inf, stream), "dvp_prover_msm_partial")
+
+    def challenge(self, d_commit_xy: int, d_commit_inf: int, stream: int = 0):
+        check(lib.dvp_prove_challenge(self._h, d_commit_xy, d_commit_inf, stream), "dvp_prove_challenge")
+
+    def finish(self, d_kzg_xy: int, d_kzg_inf: int, stream: int = 0) -> Proof:
+        out = np.zeros(118, dtype=np.uint8)
+        check(lib.dvp_prove_finish(self._h, d_kzg_xy, d_kzg_inf, ptr(out), stream), "dvp_prove_finish")
+        return Proof.from_bytes(out.tobytes())

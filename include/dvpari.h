@@ -154,6 +154,16 @@ int dvp_prover_set_srs_affine_dev(dvp_prover* p, int which, const void* d_xy, co
 /* proof = commit_p[30] | kzg_k[30] | a0[29] | b0[29]: the byte image of Proof::to_bits (:691-718) */
 int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
               uint32_t n_private, uint8_t proof[118]);
+/* the same with the assignment [1, public.., private..] (n_wires canonical Fr) already in HBM */
+int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t proof[118], void* stream);
+/* prove in phases, so that the two MSMs -- the only stages that shard across GPUs -- can be split by
+ * index range and their partial sums combined by the caller (all-gather + local add):
+ *   begin -> msm_partial(0, lo, hi) -> challenge(commit point) -> msm_partial(1, lo, hi) -> finish */
+int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream);
+size_t dvp_prover_msm_size(const dvp_prover* p, int which);
+int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
+int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream);
+int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream);
 /* intermediates of the last proof, for parity tests (names: see prove.hip) */
 int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);
 /* (D, D') = get_both_domains(tree2n), src/ec_fft.rs:179-189 */
