@@ -1,0 +1,124 @@
+"""CPU test of the N>1 path (gloo, world_size 2): the sharding / all-gather / combine orchestration of
+dv-pari_amd.distributed.prove_sharded, with the GPU work replaced by an oracle-backed backend
+(the orchestration is what is under test here; the GPU kernels are covered by the -m gpu tests)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_covers_everything():
+    sys.path.insert(0, ROOT)
+    dist_mod = importlib.import_module("dv-pari_amd.distributed")
+    for total in (0, 1, 7, 8, 1000, 6291456):
+        for world in (1, 2, 3, 8):
+            rs = [dist_mod.shard_range(total, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == total
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import pyref as o
+    import c_oracle as co
+    from util import to_limbs, pts_to_np
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist_mod = importlib.import_module("dv-pari_amd.distributed")
+
+    trap = (0x1111 + (1 << 100), 0x2222 + (1 << 90), 0x3333 + (1 << 80))
+    tree = o.FFTree(4)
+    st = o.setup_srs_scalars(tree, o.TOY_ROWS, o.TOY_COEFFS, 2, trap)
+
+    def pack(pt):
+        t = torch.zeros(10, dtype=torch.int64)
+        if pt is None:
+            t[8] = 1
+        else:
+            t[:8] = torch.from_numpy(pts_to_np([pt])[0].view(np.int64))
+        return t
+
+    def unpack(t):
+        if int(t[8]) & 0xFFFFFFFF:
+            return None
+        a = t[:8].numpy().view(np.uint64)
+        return (int.from_bytes(a[:4].tobytes(), "little"), int.from_bytes(a[4:].tobytes(), "little"))
+
+    class OracleBackend:
+        """same protocol as distributed.GpuBackend, arithmetic by the C oracle"""
+
+        def begin(self, assignment):
+            self.state = {}
+            self.w = assignment
+            self.pr = o.prove_scalars(tree, st, assignment[1:3], assignment[3:], self._alpha)
+            gk = st["g_k"][0] + st["g_k"][1] + st["g_k"][2]
+            self.sc = [self.pr["w"] + self.pr["q2"], self.pr["s_k"]]
+            self.bases = [[co.k233_mulgen(k) for k in st["g_m"] + st["g_q"]], [co.k233_mulgen(k) for k in gk]]
+
+        def _alpha(self, dl):
+            return o.transcript_challenge(co.xsk233_encode(co.k233_mulgen(dl)), o.TOY_PUBLIC)
+
+        def msm_size(self, which):
+            return len(self.sc[which])
+
+        def msm_partial(self, which, lo, hi):
+            if hi == lo:
+                return pack(None)
+            b = [p for p in self.bases[which][lo:hi]]
+            inf = np.array([1 if p is None else 0 for p in b], dtype=np.uint8)
+            arr = pts_to_np([p if p is not None else (0, 0) for p in b])
+            return pack(co.msm(to_limbs(self.sc[which][lo:hi]), arr, inf))
+
+        def combine(self, gathered):
+            acc = None
+            for row in gathered:
+                acc = o.k233_add(acc, unpack(row))
+            return pack(acc)
+
+        def challenge(self, point):
+            self.commit = unpack(point)
+
+        def finish(self, point):
+            return (co.xsk233_encode(self.commit), co.xsk233_encode(unpack(point)), self.pr["a0"], self.pr["b0"])
+
+    be = OracleBackend()
+    assignment = [1] + o.TOY_PUBLIC + o.TOY_PRIVATE
+    proof = dist_mod.prove_sharded(be, assignment)
+    exp_commit = co.xsk233_encode(co.k233_mulgen(be.pr["dl_commit_p"]))
+    exp_kzg = co.xsk233_encode(co.k233_mulgen(be.pr["dl_kzg"]))
+    ok = proof[0] == exp_commit and proof[1] == exp_kzg
+    q.put((rank, ok, proof[0].hex()))
+    dist.destroy_process_group()
+
+
+def test_prove_sharded_world2_gloo():
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]  # every rank holds the same commitment
