@@ -103,6 +103,77 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q) {
   return r;
 }
 
+
+// ---- LDS-comb flavours (hot kernels): same formulas, products through the LDS table multiplier
+// (gf233.cuh), with the table of a repeated operand built once: 6 builds for the 8 products of the mixed
+// addition (Z1 and C are used twice), 9 builds for the 13 products of the full addition. ----------------
+GF_DEV Ld ld_dbl(const Ld& p, const GfLds& L) {
+  Gf z1s = gf_sqr(p.Z), x1s = gf_sqr(p.X);
+  Ld r;
+  r.Z = gf_mul(x1s, z1s, L);
+  Gf z1q = gf_sqr(z1s);
+  r.X = gf_add(gf_sqr(x1s), z1q);
+  Gf t = gf_mul(z1q, r.Z, L);
+  r.Y = gf_add(t, gf_mul(gf_add(gf_sqr(p.Y), z1q), r.X, L));
+  return r;
+}
+
+GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const GfLds& L) {
+  if (ld_is_inf(p)) return ld_from_aff(q);
+  Gf A = gf_add(p.Y, gf_mul(q.y, gf_sqr(p.Z), L));
+  gf_tab_build(L, p.Z);
+  Gf B = gf_add(p.X, gf_mul_tab(q.x, L));
+  if (gf_is_zero(B)) {
+    if (gf_is_zero(A)) return ld_dbl(ld_from_aff(q), L);  // p == q
+    return ld_infinity();                                 // p == -q
+  }
+  Gf C = gf_mul_tab(B, L);  // Z1 * B
+  gf_tab_build(L, C);
+  Gf D = gf_mul_tab(gf_sqr(B), L);
+  Gf E = gf_mul_tab(A, L);
+  Ld r;
+  r.Z = gf_sqr(C);
+  r.X = gf_add(gf_add(gf_sqr(A), D), E);
+  Gf F = gf_add(r.X, gf_mul(q.x, r.Z, L));
+  Gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(r.Z), L);
+  r.Y = gf_add(gf_mul(gf_add(E, r.Z), F, L), G);
+  return r;
+}
+
+GF_DEV Ld ld_add(const Ld& p, const Ld& q, const GfLds& L) {
+  if (ld_is_inf(p)) return q;
+  if (ld_is_inf(q)) return p;
+  Gf A1 = gf_mul(q.Y, gf_sqr(p.Z), L);
+  Gf A2 = gf_mul(p.Y, gf_sqr(q.Z), L);
+  gf_tab_build(L, p.Z);
+  Gf B1 = gf_mul_tab(q.X, L);
+  Gf E = gf_mul_tab(q.Z, L);
+  Gf B2 = gf_mul(p.X, q.Z, L);
+  Gf C = gf_add(A1, A2);
+  Gf D = gf_add(B1, B2);
+  if (gf_is_zero(D)) {
+    if (gf_is_zero(C)) return ld_dbl(p, L);
+    return ld_infinity();
+  }
+  Gf Ds = gf_sqr(D);
+  gf_tab_build(L, Ds);
+  Gf DB = gf_mul_tab(B1, L);
+  Gf DA = gf_mul_tab(A1, L);
+  gf_tab_build(L, E);
+  Gf F = gf_mul_tab(D, L);
+  Gf I = gf_mul_tab(DB, L);
+  gf_tab_build(L, F);
+  Gf G = gf_mul_tab(Ds, L);
+  Gf H = gf_mul_tab(C, L);
+  Ld r;
+  r.Z = gf_sqr(F);
+  r.X = gf_add(gf_add(gf_sqr(C), H), G);
+  I = gf_add(I, r.X);
+  Gf J = gf_add(DA, r.X);
+  r.Y = gf_add(gf_mul(I, H, L), gf_mul(J, r.Z, L));
+  return r;
+}
+
 // Frobenius tau(x,y) = (x^2,y^2), applied k times
 GF_DEV Ld ld_frob_n(Ld p, int k) {
 #pragma unroll 1

@@ -175,6 +175,8 @@ __global__ void __launch_bounds__(256)
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
                Ld* __restrict__ out) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
@@ -183,13 +185,15 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   uint32_t len = min(K, cnt[key] - j * K);
   Ld acc = ld_from_aff(bases[items[start]]);
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) acc = ld_madd(acc, bases[items[start + t]]);
+  for (uint32_t t = 1; t < len; ++t) acc = ld_madd(acc, bases[items[start + t]], L);
   out[tid] = acc;
 }
 
 __global__ void __launch_bounds__(256)
 k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
              const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K, Ld* __restrict__ out) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
@@ -198,7 +202,7 @@ k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const 
   uint32_t len = min(K, cnt[key] - j * K);
   Ld acc = in[start];
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) acc = ld_add(acc, in[start + t]);
+  for (uint32_t t = 1; t < len; ++t) acc = ld_add(acc, in[start + t], L);
   out[tid] = acc;
 }
 
@@ -214,13 +218,15 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 // ---- pruned sum-over-subsets merge (see file header, step 4) ---------------------------------------
 // level j: blocks of 2^(j+1) buckets; slot s <= j: A[base+s] += A[base+2^j+s]; slot j+1 <- T_right
 __global__ void __launch_bounds__(256) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= total) return;
   uint32_t blk = tid / (uint32_t)(j + 1), s = tid - blk * (uint32_t)(j + 1);
   size_t base = (size_t)blk << (j + 1);
   Ld l = A[base + s], r = A[base + ((size_t)1 << j) + s];
   if (s == 0 && j >= 2) A[base + 1 + j] = r;
-  A[base + s] = ld_add(l, r);
+  A[base + s] = ld_add(l, r, L);
 }
 
 // E[w*c+t] = tau^(w*c+t)( A[w*2^c + 1 + t] )
@@ -376,7 +382,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   DVP_TRY(scan_exclusive(ntask, toff, nk, bsum, st));
   {
     ProfScope ps(PROF_MSM_ACCUM_AFFINE, st);
-    hipLaunchKernelGGL(k_accum_affine, dim3(cdiv(p.t1_max, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, toff,
+    hipLaunchKernelGGL(k_accum_affine, dim3(cdiv(p.t1_max, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, (const Aff*)d_bases, items, cnt, off, toff,
                        nk, p.K, bufA);
     ps.stop();
   }
@@ -388,7 +394,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, c_cnt, n_cnt, nk, p.K);
     DVP_TRY(scan_exclusive(n_cnt, n_off, nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
-    hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, 256)), dim3(256), 0, st, in, c_cnt, c_off, n_off, nk, p.K, outb);
+    hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, in, c_cnt, c_off, n_off, nk, p.K, outb);
     cap = tmax;
     // rotate: the (cnt,off) arrays of two levels ago are free again
     uint32_t* f_cnt = c_cnt; uint32_t* f_off = c_off;
@@ -399,7 +405,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   hipLaunchKernelGGL(k_bucket_gather, dim3(cdiv(nk, 256)), dim3(256), 0, st, in, c_cnt, c_off, nk, bkt);
   for (int j = 0; j < p.c; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
-    hipLaunchKernelGGL(k_merge, dim3(cdiv(total, 256)), dim3(256), 0, st, bkt, j, total);
+    hipLaunchKernelGGL(k_merge, dim3(cdiv(total, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, bkt, j, total);
   }
   uint32_t cntT = (uint32_t)(p.W * p.c);
   Ld* ta = tail;
