@@ -33,7 +33,7 @@ namespace dvp {
 // Scalars >= r are rejected (flag); points flagged infinite contribute nothing.
 __global__ void __launch_bounds__(256)
 k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W,
-         uint16_t* __restrict__ digits, uint32_t* __restrict__ hist, unsigned long long* __restrict__ err) {
+         uint16_t* __restrict__ digits, unsigned long long* __restrict__ err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -57,7 +57,6 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
     dig |= tau_step(r0, r1) << bitpos;
     if (++bitpos == c) {
       digits[(size_t)w * n + i] = (uint16_t)dig;
-      if (dig) atomicAdd(&hist[((uint32_t)w << c) + dig], 1u);
       dig = 0;
       bitpos = 0;
       ++w;
@@ -141,18 +140,67 @@ static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_
   return DVP_OK;
 }
 
-// ---- scatter -------------------------------------------------------------------------------------
+// ---- counting sort by (window, pattern) without global atomics ---------------------------------------
+// Scattered global atomics run at ~16 G/s on MI355X (they execute at the memory side), which made
+// histogram + scatter cost as much as a third of the MSM.  Instead each block owns a chunk of
+// SORT_CHUNK scalars of ONE window and keeps the 2^c counters in LDS (c <= 15: 2^15 x 4 B = 128 KB of
+// the CU's 160 KB):
+//   k_hist_local  : LDS histogram (two u16 counters per word) -> hist[w][chunk][2^c] (u16)
+//   k_hist_scan   : per (w, pattern): exclusive prefix over chunks -> chunk_off (u32) and cnt[w][pattern]
+//   (scan of cnt -> off, as before)
+//   k_scatter_local: LDS cursors = off + chunk_off, ds_add_rtn per digit -> items[]
+constexpr uint32_t SORT_CHUNK = 32768;  // counts fit in u16
+constexpr int SORT_TPB = 1024;
+
+__global__ void __launch_bounds__(SORT_TPB)
+k_hist_local(const uint16_t* __restrict__ digits, uint32_t n, int c, uint16_t* __restrict__ hist) {
+  extern __shared__ uint32_t lds_cnt[];  // 2^(c-1) words
+  const uint32_t chunk = blockIdx.x, w = blockIdx.y, nb = 1u << c, nchunks = gridDim.x;
+  for (uint32_t k = threadIdx.x; k < (nb >> 1); k += SORT_TPB) lds_cnt[k] = 0;
+  __syncthreads();
+  uint32_t lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
+  const uint16_t* dg = digits + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_TPB) {
+    uint32_t d = dg[i];
+    if (d) atomicAdd(&lds_cnt[d >> 1], 1u << (16 * (d & 1)));
+  }
+  __syncthreads();
+  uint32_t* out = (uint32_t*)(hist + ((size_t)w * nchunks + chunk) * nb);
+  for (uint32_t k = threadIdx.x; k < (nb >> 1); k += SORT_TPB) out[k] = lds_cnt[k];
+}
+
 __global__ void __launch_bounds__(256)
-k_scatter(const uint16_t* __restrict__ digits, uint32_t n, int c, int W, const uint32_t* __restrict__ off,
-          uint32_t* __restrict__ cursor, uint32_t* __restrict__ items) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  int w = blockIdx.y;
-  if (i >= n) return;
-  uint32_t d = digits[(size_t)w * n + i];
-  if (!d) return;
-  uint32_t key = ((uint32_t)w << c) + d;
-  uint32_t pos = off[key] + atomicAdd(&cursor[key], 1u);
-  items[pos] = i;
+k_hist_scan(const uint16_t* __restrict__ hist, uint32_t nchunks, int c, int W, uint32_t* __restrict__ chunk_off,
+            uint32_t* __restrict__ cnt) {
+  uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t nb = 1u << c;
+  if (key >= ((uint32_t)W << c)) return;
+  uint32_t w = key >> c, b = key & (nb - 1);
+  uint32_t run = 0;
+  for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    size_t idx = ((size_t)w * nchunks + ch) * nb + b;
+    uint32_t v = hist[idx];
+    chunk_off[idx] = run;
+    run += v;
+  }
+  cnt[key] = run;
+}
+
+__global__ void __launch_bounds__(SORT_TPB)
+k_scatter_local(const uint16_t* __restrict__ digits, uint32_t n, int c, const uint32_t* __restrict__ off,
+                const uint32_t* __restrict__ chunk_off, uint32_t* __restrict__ items) {
+  extern __shared__ uint32_t lds_cur[];  // 2^c words
+  const uint32_t chunk = blockIdx.x, w = blockIdx.y, nb = 1u << c, nchunks = gridDim.x;
+  const uint32_t* co = chunk_off + ((size_t)w * nchunks + chunk) * nb;
+  const uint32_t* of = off + ((size_t)w << c);
+  for (uint32_t k = threadIdx.x; k < nb; k += SORT_TPB) lds_cur[k] = of[k] + co[k];
+  __syncthreads();
+  uint32_t lo = chunk * SORT_CHUNK, hi = min(n, lo + SORT_CHUNK);
+  const uint16_t* dg = digits + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_TPB) {
+    uint32_t d = dg[i];
+    if (d) items[atomicAdd(&lds_cur[d], 1u)] = i;
+  }
 }
 
 // ---- segmented reduction by fan-in K ----------------------------------------------------------------
@@ -295,12 +343,12 @@ static MsmPlan msm_plan(size_t n) {
   // cost model: ceil(240/c) * (8.4 n + 28 * 2^c) field multiplications
   double best = 1e300;
   p.c = 4;
-  for (int c = 4; c <= 16; ++c) {
+  for (int c = 4; c <= 15; ++c) {  // <= 15: the sort keeps 2^c u32 cursors in LDS
     int W = (TAU_DIGITS + c - 1) / c;
     double cost = W * (8.4 * (double)n + 28.0 * (double)(1u << c));
     if (cost < best) { best = cost; p.c = c; }
   }
-  if (const char* e = getenv("DVP_MSM_C")) { int c = atoi(e); if (c >= 2 && c <= 16) p.c = c; }
+  if (const char* e = getenv("DVP_MSM_C")) { int c = atoi(e); if (c >= 2 && c <= 15) p.c = c; }
   p.W = (TAU_DIGITS + p.c - 1) / p.c;
   p.nkeys = (uint32_t)p.W << p.c;
   p.e_max = n * (size_t)p.W;
@@ -330,6 +378,16 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     return DVP_OK;
   }
   if (n > (1u << 27)) return DVP_EINVAL;
+  {
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+      attr_err = hipFuncSetAttribute((const void*)k_scatter_local, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute((const void*)k_hist_local, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    });
+    DVP_HIP(attr_err);
+  }
   MsmPlan p = msm_plan(n);
   std::lock_guard<std::mutex> g(g_ws.mu);
   // carve the workspace
@@ -346,6 +404,9 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   size_t o_off2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_bsum = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);
   size_t o_items = carve(p.e_max * 4);
+  const size_t sort_cells = (size_t)p.W * cdiv(n, SORT_CHUNK) << p.c;
+  size_t o_hist16 = carve(sort_cells * 2);
+  size_t o_choff = carve(sort_cells * 4);
   size_t o_bufA = carve(p.t1_max * sizeof(Ld));
   size_t o_bufB = carve(p.t2_max * sizeof(Ld));
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
@@ -363,6 +424,8 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   auto* off2 = (uint32_t*)(base + o_off2);
   auto* bsum = (uint32_t*)(base + o_bsum);
   auto* items = (uint32_t*)(base + o_items);
+  auto* hist16 = (uint16_t*)(base + o_hist16);
+  auto* chunk_off = (uint32_t*)(base + o_choff);
   Ld* bufA = (Ld*)(base + o_bufA);
   Ld* bufB = (Ld*)(base + o_bufB);
   Ld* bkt = (Ld*)(base + o_bkt);
@@ -371,12 +434,16 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
-  DVP_HIP(hipMemsetAsync(cnt, 0, ((size_t)nk + 1) * 4, st));
-  DVP_HIP(hipMemsetAsync(cursor, 0, ((size_t)nk + 1) * 4, st));
+  (void)cursor;
   hipLaunchKernelGGL(k_recode, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
-                     (uint32_t)n, p.c, p.W, digits, cnt, err);
-  DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
-  hipLaunchKernelGGL(k_scatter, dim3(cdiv(n, 256), p.W), dim3(256), 0, st, digits, (uint32_t)n, p.c, p.W, off, cursor, items);
+                     (uint32_t)n, p.c, p.W, digits, err);
+  {
+    const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
+    hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
+    hipLaunchKernelGGL(k_hist_scan, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, nchunks, p.c, p.W, chunk_off, cnt);
+    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
+    hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
+  }
   // level 1: affine gather
   hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, cnt, ntask, nk, p.K);
   DVP_TRY(scan_exclusive(ntask, toff, nk, bsum, st));
