@@ -118,31 +118,53 @@ GF_DEV Ld ld_dbl(const Ld& p, const GfLds& L) {
   return r;
 }
 
-GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const GfLds& L) {
-  if (ld_is_inf(p)) return ld_from_aff(q);
+// in-place forms (no aggregate returns through divergent paths: those made hipcc keep the accumulator
+// in scratch, 68 B/lane of write+read traffic per addition)
+GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const GfLds& L) {
+  if (ld_is_inf(p)) {
+    p.X = q.x;
+    p.Y = q.y;
+    p.Z = gf_one();
+    return;
+  }
   Gf A = gf_add(p.Y, gf_mul(q.y, gf_sqr(p.Z), L));
   gf_tab_build(L, p.Z);
   Gf B = gf_add(p.X, gf_mul_tab(q.x, L));
   if (gf_is_zero(B)) {
-    if (gf_is_zero(A)) return ld_dbl(ld_from_aff(q), L);  // p == q
-    return ld_infinity();                                 // p == -q
+    if (gf_is_zero(A)) {  // p == q: double the affine point
+      Ld t;
+      t.X = q.x; t.Y = q.y; t.Z = gf_one();
+      t = ld_dbl(t, L);
+      p.X = t.X; p.Y = t.Y; p.Z = t.Z;
+    } else {              // p == -q
+      p.X = gf_one(); p.Y = gf_zero(); p.Z = gf_zero();
+    }
+    return;
   }
   Gf C = gf_mul_tab(B, L);  // Z1 * B
   gf_tab_build(L, C);
   Gf D = gf_mul_tab(gf_sqr(B), L);
   Gf E = gf_mul_tab(A, L);
-  Ld r;
-  r.Z = gf_sqr(C);
-  r.X = gf_add(gf_add(gf_sqr(A), D), E);
-  Gf F = gf_add(r.X, gf_mul(q.x, r.Z, L));
-  Gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(r.Z), L);
-  r.Y = gf_add(gf_mul(gf_add(E, r.Z), F, L), G);
+  Gf Z3 = gf_sqr(C);
+  Gf X3 = gf_add(gf_add(gf_sqr(A), D), E);
+  Gf F = gf_add(X3, gf_mul(q.x, Z3, L));
+  Gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(Z3), L);
+  p.Y = gf_add(gf_mul(gf_add(E, Z3), F, L), G);
+  p.X = X3;
+  p.Z = Z3;
+}
+GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const GfLds& L) {
+  Ld r = p;
+  ld_madd_ip(r, q, L);
   return r;
 }
 
-GF_DEV Ld ld_add(const Ld& p, const Ld& q, const GfLds& L) {
-  if (ld_is_inf(p)) return q;
-  if (ld_is_inf(q)) return p;
+GF_DEV void ld_add_ip(Ld& p, const Ld& q, const GfLds& L) {
+  if (ld_is_inf(q)) return;
+  if (ld_is_inf(p)) {
+    p.X = q.X; p.Y = q.Y; p.Z = q.Z;
+    return;
+  }
   Gf A1 = gf_mul(q.Y, gf_sqr(p.Z), L);
   Gf A2 = gf_mul(p.Y, gf_sqr(q.Z), L);
   gf_tab_build(L, p.Z);
@@ -152,8 +174,13 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q, const GfLds& L) {
   Gf C = gf_add(A1, A2);
   Gf D = gf_add(B1, B2);
   if (gf_is_zero(D)) {
-    if (gf_is_zero(C)) return ld_dbl(p, L);
-    return ld_infinity();
+    if (gf_is_zero(C)) {
+      Ld t = ld_dbl(p, L);
+      p.X = t.X; p.Y = t.Y; p.Z = t.Z;
+    } else {
+      p.X = gf_one(); p.Y = gf_zero(); p.Z = gf_zero();
+    }
+    return;
   }
   Gf Ds = gf_sqr(D);
   gf_tab_build(L, Ds);
@@ -165,12 +192,17 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q, const GfLds& L) {
   gf_tab_build(L, F);
   Gf G = gf_mul_tab(Ds, L);
   Gf H = gf_mul_tab(C, L);
-  Ld r;
-  r.Z = gf_sqr(F);
-  r.X = gf_add(gf_add(gf_sqr(C), H), G);
-  I = gf_add(I, r.X);
-  Gf J = gf_add(DA, r.X);
-  r.Y = gf_add(gf_mul(I, H, L), gf_mul(J, r.Z, L));
+  Gf Z3 = gf_sqr(F);
+  Gf X3 = gf_add(gf_add(gf_sqr(C), H), G);
+  I = gf_add(I, X3);
+  Gf J = gf_add(DA, X3);
+  p.Y = gf_add(gf_mul(I, H, L), gf_mul(J, Z3, L));
+  p.X = X3;
+  p.Z = Z3;
+}
+GF_DEV Ld ld_add(const Ld& p, const Ld& q, const GfLds& L) {
+  Ld r = p;
+  ld_add_ip(r, q, L);
   return r;
 }
 

@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, 
   return lo;
 }
 
-__global__ void __launch_bounds__(EC_TPB)
+__global__ void __launch_bounds__(EC_TPB, 2)
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
                Ld* __restrict__ out) {
@@ -237,11 +237,11 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   uint32_t len = min(K, cnt[key] - j * K);
   Ld acc = ld_from_aff(bases[items[start]]);
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) acc = ld_madd(acc, bases[items[start + t]], L);
+  for (uint32_t t = 1; t < len; ++t) ld_madd_ip(acc, bases[items[start + t]], L);
   out[tid] = acc;
 }
 
-__global__ void __launch_bounds__(EC_TPB)
+__global__ void __launch_bounds__(EC_TPB, 2)
 k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
              const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K, Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
@@ -254,7 +254,7 @@ k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const 
   uint32_t len = min(K, cnt[key] - j * K);
   Ld acc = in[start];
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) acc = ld_add(acc, in[start + t], L);
+  for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
   out[tid] = acc;
 }
 
@@ -269,7 +269,7 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 
 // ---- pruned sum-over-subsets merge (see file header, step 4) ---------------------------------------
 // level j: blocks of 2^(j+1) buckets; slot s <= j: A[base+s] += A[base+2^j+s]; slot j+1 <- T_right
-__global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+__global__ void __launch_bounds__(EC_TPB, 2) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
   extern __shared__ char lds_raw[];
   GfLds L = gf_lds_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
