@@ -137,10 +137,18 @@ def main():
     pairs_per_launch = pairs_total / max(acc_n, 1)
     acc_avg_ms = acc_ms / max(acc_n, 1)
     achieved = 96.0 * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 if acc_n else 0.0
-    # VALU model: W windows x (8M+5S ~ 8.4 field multiplications) per pair, 2.8k lane-ops per multiplication
-    peak_lane_ops = 256 * 128 * 2.4e9
-    W = 15 if log_m >= 18 else 16
-    valu_ops = pairs_per_launch * W * 8.4 * 2870
+    # work model: W windows x (8M+5S ~ 8.65 field-multiplication equivalents) per pair; ceiling = the
+    # LDS-comb multiplier's own microbenchmark rate (scratch/ubench/gfmul_lds.hip: 25.6 G products/s chip-wide)
+    W = -(-240 // 15)
+    mul_eq = pairs_per_launch * W * 8.65
+    mul_ceiling = 25.6e9
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_accum_affine.json")))
+        if log_m == 20 and world == 1:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": "R1CS constraints/sec (prove)",
         "value": value,
@@ -169,16 +177,17 @@ def main():
             "peak": 8000.0,
             "unit": "GB/s",
             "frac": achieved / 8000.0,
-            "traffic": None,
+            "traffic": traffic,
             "launches": int(acc_n),
             "avg_launch_ms": acc_avg_ms,
             "algorithmic_bytes_per_launch": 96.0 * pairs_per_launch,
-            "valu_model": {
-                "note": "kernel is integer-VALU bound: tau-adic windows x (8M+5S) per pair, ~2.87k lane-ops per GF(2^233) multiplication",
-                "lane_ops_per_launch": valu_ops,
-                "achieved_lane_ops_per_s": valu_ops / (acc_avg_ms * 1e-3) if acc_n else 0.0,
-                "peak_lane_ops_per_s": peak_lane_ops,
-                "frac": (valu_ops / (acc_avg_ms * 1e-3)) / peak_lane_ops if acc_n else 0.0,
+            "work_model": {
+                "note": "kernel is bound by GF(2^233) products (integer VALU + LDS table reads; gfx950 has no carry-less "
+                        "multiply): tau-adic windows x (8M+5S) per pair; ceiling = measured rate of the multiplier alone",
+                "mul_equivalents_per_launch": mul_eq,
+                "achieved_mul_per_s": mul_eq / (acc_avg_ms * 1e-3) if acc_n else 0.0,
+                "multiplier_microbench_mul_per_s": mul_ceiling,
+                "frac": (mul_eq / (acc_avg_ms * 1e-3)) / mul_ceiling if acc_n else 0.0,
             },
         },
         "stages_ms_per_step": {
