@@ -20,6 +20,7 @@
 // All of it runs on the VALU (no MFMA: there is no dense contraction in this algorithm, and
 // gfx950 has no carry-less multiplier -- see gf233.cuh).
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -223,6 +224,7 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, 
   return lo;
 }
 
+template <bool INDIRECT>
 __global__ void __launch_bounds__(EC_TPB, 2)
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
@@ -235,9 +237,16 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   uint32_t j = tid - toff[key];
   uint32_t start = off[key] + j * K;
   uint32_t len = min(K, cnt[key] - j * K);
-  Ld acc = ld_from_aff(bases[items[start]]);
+  // INDIRECT: bases gathered through the sorted index list; otherwise `bases` is the compacted output of
+  // the affine rounds, where x == 0 marks infinity
+  Aff first = INDIRECT ? bases[items[start]] : bases[start];
+  Ld acc = (!INDIRECT && gf_is_zero(first.x)) ? ld_infinity() : ld_from_aff(first);
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) ld_madd_ip(acc, bases[items[start + t]], L);
+  for (uint32_t t = 1; t < len; ++t) {
+    Aff q = INDIRECT ? bases[items[start + t]] : bases[start + t];
+    if (!INDIRECT && gf_is_zero(q.x)) continue;
+    ld_madd_ip(acc, q, L);
+  }
   out[tid] = acc;
 }
 
@@ -256,6 +265,183 @@ k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const 
 #pragma unroll 1
   for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
   out[tid] = acc;
+}
+
+// ---- multi-squaring tables for the fast inversion (gf233.cuh) ----------------------------------------
+__global__ void __launch_bounds__(256) k_build_sqr_tables(Gf* __restrict__ t29, Gf* __restrict__ t58, Gf* __restrict__ t116) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;  // 3 * 30 * 256 entries
+  if (tid >= 3 * 30 * 256) return;
+  uint32_t which = tid / (30 * 256), e = tid - which * 30 * 256, pos = e >> 8, byte = e & 255;
+  Gf v = gf_zero();
+  v.w[pos >> 2] = byte << (8 * (pos & 3));
+  if (pos == 29) v.w[7] &= 0x1FFu;  // bits >= 233 never occur in a reduced element
+  int k = which == 0 ? 29 : which == 1 ? 58 : 116;
+  v = gf_sqr_n(v, k);
+  (which == 0 ? t29 : which == 1 ? t58 : t116)[e] = v;
+}
+static std::mutex g_sqr_mu;
+static Gf* g_sqr_tab[16] = {nullptr};
+int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
+  int dev;
+  DVP_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return DVP_EINVAL;
+  std::lock_guard<std::mutex> g(g_sqr_mu);
+  if (!g_sqr_tab[dev]) {
+    Gf* t;
+    DVP_HIP(hipMalloc((void**)&t, (size_t)3 * 30 * 256 * sizeof(Gf)));
+    hipLaunchKernelGGL(k_build_sqr_tables, dim3(cdiv(3 * 30 * 256, 256)), dim3(256), 0, st, t, t + 30 * 256, t + 2 * 30 * 256);
+    DVP_HIP(hipGetLastError());
+    DVP_HIP(hipStreamSynchronize(st));
+    g_sqr_tab[dev] = t;
+  }
+  out->t29 = g_sqr_tab[dev];
+  out->t58 = g_sqr_tab[dev] + 30 * 256;
+  out->t116 = g_sqr_tab[dev] + 2 * 30 * 256;
+  return DVP_OK;
+}
+
+// ---- batched-affine pair rounds --------------------------------------------------------------------
+// One round halves every bucket: output slot (key, j) = in[2j] + in[2j+1] (or in[2j] alone when the
+// count is odd), all in AFFINE coordinates.  An affine addition needs one field inversion; a thread owns
+// AFF_B consecutive output slots and shares ONE inversion among them (Montgomery's trick): per addition
+// 3 products for the trick + 2 products + 1 squaring for the chord/tangent formulas, against 8M + 5S for
+// a mixed projective addition.  Prefix products are parked in HBM ([slot-in-thread][thread] layout, so
+// the traffic is coalesced).  (0,0) -- not a curve point -- marks infinity.
+constexpr int AFF_B = 16;
+
+// slot descriptors live in the 16 KB of LDS left beside the multiplier tables: desc[k][thread]
+constexpr unsigned AFF_LDS = EC_LDS + AFF_B * EC_TPB * 4;
+
+template <bool FIRST>
+__device__ __forceinline__ const Aff* aff_ptr(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, uint32_t i) {
+  return FIRST ? pts + items[i] : pts + i;
+}
+
+// Thread t of T = ceil(total / AFF_B) owns output slots s = k*T + t, k < AFF_B (lane-consecutive slots:
+// coalesced outputs, prefix products and -- after the first round -- inputs).
+template <bool FIRST>
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
+               const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */,
+               uint32_t nkeys, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
+  uint32_t* desc = (uint32_t*)(lds_raw + EC_LDS) + threadIdx.x;  // stride EC_TPB
+  const uint32_t total = ooff[nkeys];
+  const uint32_t nthr = (total + AFF_B - 1) / AFF_B;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= nthr) return;
+  // pre-pass: slot -> (first input index, has-partner flag in bit 31); 0xffffffff = no slot
+#pragma unroll 1
+  for (int k = 0; k < AFF_B; ++k) {
+    uint32_t s = (uint32_t)k * nthr + tid, d = 0xffffffffu;
+    if (s < total) {
+      uint32_t key = find_key(ooff, nkeys, s);
+      uint32_t j = s - ooff[key];
+      d = (off[key] + 2 * j) | ((2 * j + 1 < cnt[key]) ? 0x80000000u : 0u);
+    }
+    desc[k * EC_TPB] = d;
+  }
+  const Gf one = gf_one();
+  // pass 1: denominators and running product (x-coordinates only; y is touched when x1 == x2)
+  Gf run = one;
+  {
+    uint32_t d = desc[0];
+    const Aff *pa = nullptr, *pb = nullptr;
+    Gf xa = gf_zero(), xb = gf_zero();
+    if (d != 0xffffffffu && (d >> 31)) {
+      pa = aff_ptr<FIRST>(pts, items, d & 0x7fffffffu);
+      pb = aff_ptr<FIRST>(pts, items, (d & 0x7fffffffu) + 1);
+      xa = pa->x; xb = pb->x;
+    }
+#pragma unroll 1
+    for (int k = 0; k < AFF_B; ++k) {
+      // prefetch the next slot while this one multiplies
+      uint32_t dn = (k + 1 < AFF_B) ? desc[(k + 1) * EC_TPB] : 0xffffffffu;
+      const Aff *na = nullptr, *nb = nullptr;
+      Gf nxa = gf_zero(), nxb = gf_zero();
+      if (dn != 0xffffffffu && (dn >> 31)) {
+        na = aff_ptr<FIRST>(pts, items, dn & 0x7fffffffu);
+        nb = aff_ptr<FIRST>(pts, items, (dn & 0x7fffffffu) + 1);
+        nxa = na->x; nxb = nb->x;
+      }
+      Gf den = one;
+      bool live = d != 0xffffffffu && (d >> 31) && !gf_is_zero(xa) && !gf_is_zero(xb);
+      if (live) {
+        Gf dd = gf_add(xa, xb);
+        if (!gf_is_zero(dd)) den = dd;
+        else if (gf_eq(pa->y, pb->y)) den = xa;  // doubling: lambda = x + y/x
+      }
+      prefix[(size_t)k * nthr + tid] = run;
+      run = gf_mul(run, den, L);
+      d = dn; pa = na; pb = nb; xa = nxa; xb = nxb;
+    }
+  }
+  Gf inv = gf_inv_fast(run, T, L);
+  // pass 2 (backwards): recover each inverse and finish the addition
+#pragma unroll 1
+  for (int k = AFF_B - 1; k >= 0; --k) {
+    uint32_t d = desc[k * EC_TPB];
+    if (d == 0xffffffffu) continue;
+    uint32_t s = (uint32_t)k * nthr + tid;
+    const Aff* pa = aff_ptr<FIRST>(pts, items, d & 0x7fffffffu);
+    Gf px = pa->x, py = pa->y;
+    if (!(d >> 31)) {  // odd leftover: pass through
+      out[s].x = px; out[s].y = py;
+      continue;
+    }
+    const Aff* pb = aff_ptr<FIRST>(pts, items, (d & 0x7fffffffu) + 1);
+    Gf qx = pb->x, qy = pb->y;
+    if (gf_is_zero(px)) { out[s].x = qx; out[s].y = qy; continue; }
+    if (gf_is_zero(qx)) { out[s].x = px; out[s].y = py; continue; }
+    Gf dd = gf_add(px, qx);
+    bool same_x = gf_is_zero(dd);
+    bool dbl = same_x && gf_eq(py, qy);
+    if (same_x && !dbl) {  // p == -q
+      out[s].x = gf_zero(); out[s].y = gf_zero();
+      continue;
+    }
+    Gf den = dbl ? px : dd;
+    Gf pre = prefix[(size_t)k * nthr + tid];
+    gf_tab_build(L, inv);
+    Gf dinv = gf_mul_tab(pre, L);  // 1/den
+    inv = gf_mul_tab(den, L);      // strip this slot's factor
+    Gf num = dbl ? py : gf_add(py, qy);
+    Gf lam = gf_mul(num, dinv, L);
+    if (dbl) lam = gf_add(lam, px);
+    Gf x3 = gf_add(gf_add(gf_sqr(lam), lam), dd);  // dd == 0 when doubling (curve a = 0)
+    // y3 = lam (x1 + x3) + x3 + y1   (the same expression covers the doubling)
+    Gf y3 = gf_add(gf_add(gf_mul(gf_add(px, x3), lam, L), x3), py);
+    out[s].x = x3; out[s].y = y3;
+  }
+}
+
+// dense bucket array from the last affine round: A[key] = (x, y, 1) or infinity
+__global__ void __launch_bounds__(256)
+k_bucket_gather_aff(const Aff* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                    uint32_t nkeys, Ld* __restrict__ A) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nkeys) return;
+  Ld r = ld_infinity();
+  if (cnt[k]) {
+    Aff p = in[off[k]];
+    if (!gf_is_zero(p.x)) r = ld_from_aff(p);  // x == 0 marks infinity (no point of E[r] has x = 0)
+  }
+  A[k] = r;
+}
+// same, straight from the sorted items (keys that never had more than one point)
+__global__ void __launch_bounds__(256)
+k_bucket_gather_items(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
+                      const uint32_t* __restrict__ off, uint32_t nkeys, Ld* __restrict__ A) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nkeys) return;
+  A[k] = cnt[k] ? ld_from_aff(bases[items[off[k]]]) : ld_infinity();
+}
+__global__ void __launch_bounds__(256) k_max_u32(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t m = i < n ? v[i] : 0;
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // dense bucket array: A[key] = the single remaining item of key, or infinity
@@ -389,9 +575,10 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
       attr_err = hipFuncSetAttribute((const void*)k_scatter_local, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_hist_local, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      const void* ec[] = {(const void*)k_accum_affine, (const void*)k_accum_proj, (const void*)k_merge};
+      const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge,
+                          (const void*)k_affine_round<true>, (const void*)k_affine_round<false>};
       for (const void* f : ec)
-        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS);
     });
     DVP_HIP(attr_err);
   }
@@ -416,6 +603,12 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   size_t o_choff = carve(sort_cells * 4);
   size_t o_bufA = carve(p.t1_max * sizeof(Ld));
   size_t o_bufB = carve(p.t2_max * sizeof(Ld));
+  const bool affine_mode = !(getenv("DVP_MSM_MODE") && !strcmp(getenv("DVP_MSM_MODE"), "proj"));
+  const size_t affA_n = p.e_max / 2 + p.nkeys + 1, affB_n = p.e_max / 4 + p.nkeys + 1;
+  const size_t aff_threads = (size_t)cdiv(cdiv(affA_n, AFF_B), EC_TPB) * EC_TPB;
+  size_t o_affA = carve(affine_mode ? affA_n * sizeof(Aff) : 16);
+  size_t o_affB = carve(affine_mode ? affB_n * sizeof(Aff) : 16);
+  size_t o_prefix = carve(affine_mode ? aff_threads * AFF_B * sizeof(Gf) : 16);
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_tail = carve((size_t)2 * p.W * p.c * sizeof(Ld));
   DVP_TRY(g_ws.ensure(o));
@@ -436,6 +629,9 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   Ld* bufA = (Ld*)(base + o_bufA);
   Ld* bufB = (Ld*)(base + o_bufB);
   Ld* bkt = (Ld*)(base + o_bkt);
+  Aff* affA = (Aff*)(base + o_affA);
+  Aff* affB = (Aff*)(base + o_affB);
+  Gf* prefix = (Gf*)(base + o_prefix);
   Ld* tail = (Ld*)(base + o_tail);
   const uint32_t nk = p.nkeys;
 
@@ -451,32 +647,77 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
   }
-  // level 1: affine gather
-  hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, cnt, ntask, nk, p.K);
-  DVP_TRY(scan_exclusive(ntask, toff, nk, bsum, st));
-  {
-    ProfScope ps(PROF_MSM_ACCUM_AFFINE, st);
-    hipLaunchKernelGGL(k_accum_affine, dim3(cdiv(p.t1_max, EC_TPB)), dim3(EC_TPB), EC_LDS, st, (const Aff*)d_bases, items, cnt, off, toff,
-                       nk, p.K, bufA);
-    ps.stop();
+  // ---- bucket accumulation: batched-affine pair rounds while a round still carries >= aff_min additions,
+  // then the projective fan-in-K reducer on what is left (it has a short critical path and balances skew)
+  uint32_t* d_max = (uint32_t*)(err + 1);
+  DVP_HIP(hipMemsetAsync(d_max, 0, 4, st));
+  hipLaunchKernelGGL(k_max_u32, dim3(cdiv(nk, 256)), dim3(256), 0, st, cnt, nk, d_max);
+  uint32_t max_cnt = 0;
+  DVP_HIP(hipMemcpyAsync(&max_cnt, d_max, 4, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  size_t aff_min = (size_t)1 << 20;
+  if (const char* e = getenv("DVP_MSM_AFF_MIN")) aff_min = (size_t)atoll(e);
+  int ra = 0;
+  if (affine_mode)
+    while (((uint64_t)1 << ra) < max_cnt && (p.e_max >> (ra + 1)) >= aff_min) ++ra;
+  uint32_t* pc[3] = {cnt, ntask, cnt2};
+  uint32_t* po[3] = {off, toff, off2};
+  int cur = 0;  // index of the live (cnt, off) pair
+  const Aff* pts_in = (const Aff*)d_bases;
+  size_t cap = p.e_max;
+  ProfScope ps_acc(PROF_MSM_ACCUM_AFFINE, st);
+  if (ra > 0) {
+    GfSqrTables T;
+    DVP_TRY(gf_sqr_tables(&T, st));
+    for (int r = 0; r < ra; ++r) {
+      int nxt = (cur + 1) % 3;
+      hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, 2u);
+      DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
+      size_t out_max = cap / 2 + nk + 1;
+      Aff* outp = (r & 1) ? affB : affA;
+      uint32_t grid = cdiv(cdiv(out_max, AFF_B), EC_TPB);
+      if (r == 0)
+        hipLaunchKernelGGL((k_affine_round<true>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, outp);
+      else
+        hipLaunchKernelGGL((k_affine_round<false>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, outp);
+      pts_in = outp;
+      cap = out_max;
+      cur = nxt;
+    }
   }
-  // further levels: (cnt, off) <- (ntask, toff)
-  uint32_t *c_cnt = ntask, *c_off = toff, *n_cnt = cnt2, *n_off = off2;
-  Ld *in = bufA, *outb = bufB;
-  size_t cap = p.t1_max;
-  for (uint32_t lvl = 1; lvl < p.levels; ++lvl) {
-    hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, c_cnt, n_cnt, nk, p.K);
-    DVP_TRY(scan_exclusive(n_cnt, n_off, nk, bsum, st));
+  uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
+  if (rem_max <= 1) {
+    ps_acc.stop();
+    if (ra == 0)
+      hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, nk, bkt);
+    else
+      hipLaunchKernelGGL(k_bucket_gather_aff, dim3(cdiv(nk, 256)), dim3(256), 0, st, pts_in, pc[cur], po[cur], nk, bkt);
+  } else {
+    // level 1: mixed additions from affine inputs
+    int nxt = (cur + 1) % 3;
+    hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, p.K);
+    DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
-    hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, c_cnt, c_off, n_off, nk, p.K, outb);
+    if (ra == 0)
+      hipLaunchKernelGGL((k_accum_affine<true>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, p.K, bufA);
+    else
+      hipLaunchKernelGGL((k_accum_affine<false>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, p.K, bufA);
+    ps_acc.stop();
+    cur = nxt;
     cap = tmax;
-    // rotate: the (cnt,off) arrays of two levels ago are free again
-    uint32_t* f_cnt = c_cnt; uint32_t* f_off = c_off;
-    c_cnt = n_cnt; c_off = n_off;
-    if (f_cnt == ntask) { n_cnt = cnt; n_off = off; } else { n_cnt = f_cnt; n_off = f_off; }
-    Ld* t = in; in = outb; outb = t;
+    Ld *in = bufA, *outb = bufB;
+    for (uint64_t left = (rem_max + p.K - 1) / p.K; left > 1; left = (left + p.K - 1) / p.K) {
+      nxt = (cur + 1) % 3;
+      hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, p.K);
+      DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
+      tmax = cap / p.K + nk + 1;
+      hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
+      cap = tmax;
+      cur = nxt;
+      Ld* t = in; in = outb; outb = t;
+    }
+    hipLaunchKernelGGL(k_bucket_gather, dim3(cdiv(nk, 256)), dim3(256), 0, st, in, pc[cur], po[cur], nk, bkt);
   }
-  hipLaunchKernelGGL(k_bucket_gather, dim3(cdiv(nk, 256)), dim3(256), 0, st, in, c_cnt, c_off, nk, bkt);
   for (int j = 0; j < p.c; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     hipLaunchKernelGGL(k_merge, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
