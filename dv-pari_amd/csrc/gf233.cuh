@@ -177,17 +177,24 @@ GF_DEV void gf_tab_build(const GfLds& c, const Gf& b) {
   gf_tab_store(c, 5, t4);
   gf_tab_store(c, 7, t6);
 }
-GF_DEV void gf_tab_row(uint32_t* acc, const Gf& a, const GfLds& c, int rsh, int lsh, bool skip7) {
+// one digit position: all table reads of the row are issued before the first xor consumes one (the
+// compiler otherwise waits on each lookup right after issuing it; +5% on the multiplier microbenchmark)
+template <int NW>
+GF_DEV void gf_tab_row(uint32_t* acc, const Gf& a, const GfLds& c, int rsh, int lsh) {
+  gf_u32x4 lo[NW], hi[NW];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j == 7 && skip7) continue;
+  for (int j = 0; j < NW; ++j) {
     uint32_t sh = (a.w[j] >> rsh) << lsh;
     uint32_t addr = (sh & 0x1C00u) | c.lane_base;
-    gf_u32x4 lo = *(const gf_u32x4*)(c.lds + addr);
-    gf_u32x4 hi = *(const gf_u32x4*)(c.lds + addr + 8192);
-    acc[j + 0] ^= lo.x; acc[j + 1] ^= lo.y; acc[j + 2] ^= lo.z; acc[j + 3] ^= lo.w;
-    acc[j + 4] ^= hi.x; acc[j + 5] ^= hi.y; acc[j + 6] ^= hi.z;
-    if (j + 7 < 15) acc[j + 7] ^= hi.w;
+    lo[j] = *(const gf_u32x4*)(c.lds + addr);
+    hi[j] = *(const gf_u32x4*)(c.lds + addr + 8192);
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    acc[j + 0] ^= lo[j].x; acc[j + 1] ^= lo[j].y; acc[j + 2] ^= lo[j].z; acc[j + 3] ^= lo[j].w;
+    acc[j + 4] ^= hi[j].x; acc[j + 5] ^= hi[j].y; acc[j + 6] ^= hi[j].z;
+    if (j + 7 < 15) acc[j + 7] ^= hi[j].w;
   }
 }
 GF_DEV void gf_acc_shl3(uint32_t* acc) {
@@ -201,18 +208,18 @@ GF_DEV Gf gf_mul_tab(const Gf& a, const GfLds& c) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0;
   // digit k of every word = bits [3k, 3k+3); k = 10 is the 2-bit top digit; a.w[7] has digits 0..2 only
-  gf_tab_row(acc, a, c, 20, 0, true);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
+  gf_tab_row<7>(acc, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
 #pragma unroll 1
   for (int k = 9; k >= 4; --k) {
     gf_acc_shl3(acc);
-    gf_tab_row(acc, a, c, 3 * k - 10, 0, true);
+    gf_tab_row<7>(acc, a, c, 3 * k - 10, 0);
   }
   gf_acc_shl3(acc);
-  gf_tab_row(acc, a, c, 0, 1, true);   // k = 3: bits 9..11 -> << 1
+  gf_tab_row<7>(acc, a, c, 0, 1);   // k = 3: bits 9..11 -> << 1
 #pragma unroll 1
   for (int k = 2; k >= 0; --k) {
     gf_acc_shl3(acc);
-    gf_tab_row(acc, a, c, 0, 10 - 3 * k, false);
+    gf_tab_row<8>(acc, a, c, 0, 10 - 3 * k);
   }
   return gf_reduce16(acc);
 }
