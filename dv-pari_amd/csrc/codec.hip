@@ -23,6 +23,7 @@ namespace dvp {
 
 int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy,
                    void* d_out_inf, hipStream_t st);
+int gf_sqr_tables(GfSqrTables* out, hipStream_t st);
 
 // NIST K-233 base point
 __constant__ uint32_t K233_GX[8] = {0xefad6126u, 0x0a4c9d6eu, 0x19c26bf5u, 0x149563a4u,
@@ -59,14 +60,16 @@ __device__ __forceinline__ Gf load30(const uint8_t* src, uint32_t* top_bits) {
 }
 
 __global__ void __launch_bounds__(256)
-k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n, uint8_t* __restrict__ out) {
+k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n, GfSqrTables T, uint8_t* __restrict__ out) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Gf w = gf_zero();
   if (!(inf && inf[i])) {
     Aff p = pts[i];
-    Gf lam1 = gf_add(gf_add(p.x, gf_mul(p.y, gf_inv(p.x))), gf_one());
-    w = gf_sqrt(lam1);
+    Gf lam1 = gf_add(gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L)), gf_one());
+    w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);  // sqrt = 232 squarings = two 116-step table passes
   }
   store30(out + i * 30, w);
 }
@@ -212,7 +215,9 @@ int mulgen_dev(const void* d_scalars, size_t n, Aff* d_out, uint8_t* d_inf, hipS
 }
 
 int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st) {
-  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 0, st, d_pts, d_inf, n, d_out);
+  GfSqrTables T;
+  DVP_TRY(gf_sqr_tables(&T, st));
+  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, d_pts, d_inf, n, T, d_out);
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }

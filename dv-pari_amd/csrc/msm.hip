@@ -438,8 +438,8 @@ k_bucket_gather_items(const Aff* __restrict__ bases, const uint32_t* __restrict_
   A[k] = cnt[k] ? ld_from_aff(bases[items[off[k]]]) : ld_infinity();
 }
 __global__ void __launch_bounds__(256) k_max_u32(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t m = i < n ? v[i] : 0;
+  uint32_t m = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
@@ -477,17 +477,30 @@ __global__ void __launch_bounds__(64) k_frob(const Ld* __restrict__ A, int c, in
 
 // out[i] = in[2i] + in[2i+1]   (in[count] treated as infinity when count is odd)
 __global__ void __launch_bounds__(64) k_pair_add(const Ld* __restrict__ in, uint32_t count, Ld* __restrict__ out) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (2 * i >= count) return;
   Ld a = in[2 * i];
-  if (2 * i + 1 < count) a = ld_add(a, in[2 * i + 1]);
+  if (2 * i + 1 < count) ld_add_ip(a, in[2 * i + 1], L);
   out[i] = a;
 }
 
-__global__ void k_finalize(const Ld* __restrict__ in, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
+__global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSqrTables T, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   Aff a;
-  bool fin = ld_to_aff(in[0], &a);
+  Ld p = in[0];
+  bool fin = !ld_is_inf(p);
+  a.x = gf_zero();
+  a.y = gf_zero();
+  if (fin) {
+    Gf zi = gf_inv_fast(p.Z, T, L);
+    gf_tab_build(L, zi);
+    a.x = gf_mul_tab(p.X, L);
+    a.y = gf_mul(p.Y, gf_sqr(zi), L);
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     out_xy[k] = a.x.w[k];
@@ -544,7 +557,7 @@ static MsmPlan msm_plan(size_t n) {
   p.e_max = n * (size_t)p.W;
   // fan-in: keep >= ~256k level-1 tasks in flight when the input allows it
   uint32_t K = (uint32_t)(p.e_max / 262144);
-  if (K < 2) K = 2;
+  if (K < 8) K = 8;
   if (K > 16) K = 16;
   if (const char* e = getenv("DVP_MSM_K")) { int k = atoi(e); if (k >= 2 && k <= 64) K = (uint32_t)k; }
   p.K = K;
@@ -651,7 +664,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   // then the projective fan-in-K reducer on what is left (it has a short critical path and balances skew)
   uint32_t* d_max = (uint32_t*)(err + 1);
   DVP_HIP(hipMemsetAsync(d_max, 0, 4, st));
-  hipLaunchKernelGGL(k_max_u32, dim3(cdiv(nk, 256)), dim3(256), 0, st, cnt, nk, d_max);
+  hipLaunchKernelGGL(k_max_u32, dim3(64), dim3(256), 0, st, cnt, nk, d_max);
   uint32_t max_cnt = 0;
   DVP_HIP(hipMemcpyAsync(&max_cnt, d_max, 4, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
@@ -666,9 +679,10 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   const Aff* pts_in = (const Aff*)d_bases;
   size_t cap = p.e_max;
   ProfScope ps_acc(PROF_MSM_ACCUM_AFFINE, st);
+  GfSqrTables Tsq;
+  DVP_TRY(gf_sqr_tables(&Tsq, st));
   if (ra > 0) {
-    GfSqrTables T;
-    DVP_TRY(gf_sqr_tables(&T, st));
+    const GfSqrTables& T = Tsq;
     for (int r = 0; r < ra; ++r) {
       int nxt = (cur + 1) % 3;
       hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, 2u);
@@ -728,11 +742,11 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, p.W, ta);
   while (cntT > 1) {
     uint32_t half = (cntT + 1) / 2;
-    hipLaunchKernelGGL(k_pair_add, dim3(cdiv(half, 64)), dim3(64), 0, st, ta, cntT, tb);
+    hipLaunchKernelGGL(k_pair_add, dim3(cdiv(half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
     Ld* t = ta; ta = tb; tb = t;
     cntT = half;
   }
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, st, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, Tsq, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
   ps_total.stop();
   DVP_HIP(hipGetLastError());
   // the scalar-range flag is the only thing that needs the host
