@@ -1,13 +1,14 @@
 // Fr: the 232-bit prime scalar field of sect233k1 (reference: src/curve.rs:16-22), as used by the
-// ECFFT and all pointwise prover math.  8 x 32-bit little-endian limbs, Montgomery radix R = 2^256.
+// ECFFT and all pointwise prover math.  8 x 32-bit little-endian limbs in memory, Montgomery radix
+// R = 2^232 (the multiplier re-slices into 8 x 29-bit limbs, see fr_mul).
 //
 // The C ABI carries canonical values; kernels keep *data* canonical and *constants* (twiddle
 // matrices, per-layer isogeny constants) in Montgomery form, because
 //     mont_mul(c*R, x) = c*x            (canonical result)
 // so a linear map applied with Montgomery-form constants needs no conversions on the data.
 //
-// p = 2^231 + 0x69d5bb915bcd46efb1ad5f173abdf: limbs 4..6 are zero and limb 7 is 0x80, which
-// the reduction half of the CIOS loop exploits (3 zero products folded, top limb is a shift).
+// p = 2^231 + 0x69d5bb915bcd46efb1ad5f173abdf: its 29-bit limbs 4..6 are zero, which the reduction half of
+// the multiplier exploits.
 #pragma once
 #include <stdint.h>
 
@@ -26,13 +27,17 @@ struct Fr {
 
 #define DVP_FR_P_LIMBS \
   { 0xf173abdfu, 0x6efb1ad5u, 0xb915bcd4u, 0x00069d5bu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000080u }
+// Montgomery radix R = 2^232 (8 limbs of 29 bits inside the multiplier, see fr_mul)
 #define DVP_FR_R1_LIMBS \
-  { 0x3373abdfu, 0xc318337eu, 0x1037c69eu, 0x489471e2u, 0xfffff2c5u, 0xffffffffu, 0xffffffffu, 0x0000007fu }
+  { 0x0e8c5421u, 0x9104e52au, 0x46ea432bu, 0xfff962a4u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0000007fu }
 #define DVP_FR_R2_LIMBS \
-  { 0x09468bb6u, 0x1710ac10u, 0xdb9a5b86u, 0xf7e3eb91u, 0xb5b58a0au, 0x93c813eeu, 0xbebed802u, 0x00000059u }
+  { 0xfd830525u, 0xf2ae10f8u, 0x70af2a02u, 0x13f123b3u, 0xd80293c8u, 0x7b59bebeu, 0x04193b9au, 0x0000002fu }
+#define DVP_FR_P29_LIMBS \
+  { 0x1173abdfu, 0x17d8d6afu, 0x056f351bu, 0x0d3ab772u, 0x00000000u, 0x00000000u, 0x00000000u, 0x10000000u }
 #define DVP_FR_PM2_LIMBS \
   { 0xf173abddu, 0x6efb1ad5u, 0xb915bcd4u, 0x00069d5bu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000080u }
-constexpr uint32_t FR_N0 = 0x8c382fe1u;  // -p^{-1} mod 2^32
+constexpr uint32_t FR_N0_29 = 0x0c382fe1u;  // -p^{-1} mod 2^29
+constexpr uint32_t FR_M29 = 0x1fffffffu;
 
 DVP_HD uint32_t fr_p_limb(int i) {
   constexpr uint32_t p[8] = DVP_FR_P_LIMBS;
@@ -131,43 +136,73 @@ DVP_HD Fr fr_sub(const Fr& a, const Fr& b) {
 
 DVP_HD Fr fr_neg(const Fr& a) { return fr_sub(fr_zero(), a); }
 
-// Montgomery product a*b/R mod p, fully reduced.  CIOS over 32-bit limbs; v_mad_u64_u32 on gfx950.
+// Montgomery product a*b/R mod p (R = 2^232), fully reduced.
+// p has exactly 232 bits, so the operands are re-sliced into 8 limbs of 29 bits: a column of the schoolbook
+// product (<= 8 terms of 58 bits) plus the reduction terms fits one 64-bit accumulator with NO carry
+// handling, i.e. one v_mad_u64_u32 (half rate on gfx950, measured) per limb product and nothing else --
+// the 32-bit-limb CIOS spent 4x more instructions shuffling carries than multiplying.  p's 29-bit limbs
+// 4..6 are zero, so the reduction half needs 5 products per column instead of 8.
+DVP_HD void fr_to29(const Fr& a, uint32_t* l) {
+  l[0] = a.v[0] & FR_M29;
+  l[1] = ((a.v[0] >> 29) | (a.v[1] << 3)) & FR_M29;
+  l[2] = ((a.v[1] >> 26) | (a.v[2] << 6)) & FR_M29;
+  l[3] = ((a.v[2] >> 23) | (a.v[3] << 9)) & FR_M29;
+  l[4] = ((a.v[3] >> 20) | (a.v[4] << 12)) & FR_M29;
+  l[5] = ((a.v[4] >> 17) | (a.v[5] << 15)) & FR_M29;
+  l[6] = ((a.v[5] >> 14) | (a.v[6] << 18)) & FR_M29;
+  l[7] = ((a.v[6] >> 11) | (a.v[7] << 21)) & FR_M29;  // a < 2^232: nothing above bit 231
+}
+DVP_HD Fr fr_from29(const uint32_t* l) {
+  Fr r;
+  r.v[0] = l[0] | (l[1] << 29);
+  r.v[1] = (l[1] >> 3) | (l[2] << 26);
+  r.v[2] = (l[2] >> 6) | (l[3] << 23);
+  r.v[3] = (l[3] >> 9) | (l[4] << 20);
+  r.v[4] = (l[4] >> 12) | (l[5] << 17);
+  r.v[5] = (l[5] >> 15) | (l[6] << 14);
+  r.v[6] = (l[6] >> 18) | (l[7] << 11);
+  r.v[7] = l[7] >> 21;
+  return r;
+}
 DVP_HD Fr fr_mul(const Fr& a, const Fr& b) {
-  constexpr uint32_t p[8] = DVP_FR_P_LIMBS;
-  uint32_t t[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) t[i] = 0;
+  constexpr uint32_t p[8] = DVP_FR_P29_LIMBS;
+  uint32_t x[8], y[8], m[8], r[8];
+  fr_to29(a, x);
+  fr_to29(b, y);
+  uint64_t t = 0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    uint64_t c = 0;
-    const uint32_t bi = b.v[i];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      c += (uint64_t)a.v[j] * bi + t[j];
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[8] = (uint32_t)c;
-    t[9] = (uint32_t)(c >> 32);
-    const uint32_t m = t[0] * FR_N0;
-    c = ((uint64_t)m * p[0] + t[0]) >> 32;
+    for (int j = 0; j <= i; ++j) t += (uint64_t)x[j] * y[i - j];
 #pragma unroll
-    for (int j = 1; j < 8; ++j) {
-      if (p[j] != 0) c += (uint64_t)m * p[j];
-      c += t[j];
-      t[j - 1] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t[8];
-    t[7] = (uint32_t)c;
-    t[8] = t[9] + (uint32_t)(c >> 32);
+    for (int j = 0; j < i; ++j)
+      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+    m[i] = ((uint32_t)t * FR_N0_29) & FR_M29;
+    t += (uint64_t)m[i] * p[0];
+    t >>= 29;
   }
-  Fr r;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) r.v[i] = t[i];
-  // a,b < p  =>  t < 2p and t[8] == 0
-  return fr_cond_sub_p(r);
+  for (int i = 8; i < 16; ++i) {
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j) t += (uint64_t)x[j] * y[i - j];
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j)
+      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+    r[i - 8] = (uint32_t)t & FR_M29;
+    t >>= 29;
+  }
+  // a,b < p  =>  result < 2p < 2^233: the last carry holds bit 232 and belongs to limb 7
+  r[7] |= (uint32_t)t << 29;
+  Fr out;
+  out.v[0] = r[0] | (r[1] << 29);
+  out.v[1] = (r[1] >> 3) | (r[2] << 26);
+  out.v[2] = (r[2] >> 6) | (r[3] << 23);
+  out.v[3] = (r[3] >> 9) | (r[4] << 20);
+  out.v[4] = (r[4] >> 12) | (r[5] << 17);
+  out.v[5] = (r[5] >> 15) | (r[6] << 14);
+  out.v[6] = (r[6] >> 18) | (r[7] << 11);
+  out.v[7] = r[7] >> 21;
+  return fr_cond_sub_p(out);
 }
 
 DVP_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
