@@ -12,11 +12,12 @@ index range over the ranks and combined by all-gather + local add (strong scalin
 fixed).  Rank 0 prints ONE JSON line; the proof of the last step is checked with the designated-
 verifier equation (src/srs.rs:374-428) outside the timed region.
 
-roofline: dominant kernel = dvp::k_accum_affine (bucket accumulation of the MSMs); algorithmic bytes =
-96 B per (scalar, base) pair x pairs per launch, divided by the launch time measured with
-HIP events on the launch stream (dvp_profile_*).  The kernel is integer-VALU bound (no carry-less
-multiply on gfx950), so the HBM fraction is expected to be tiny; the VALU-side model is reported next
-to it as "valu_model".
+roofline: dominant kernel = dvp::k_affine_round<true> (first batched-affine pair round of the MSM bucket
+accumulation: it gathers every base once per window); algorithmic bytes = 96 B per (scalar, base) pair
+ x pairs per launch, divided by the launch time measured with HIP events on the launch
+stream (dvp_profile_*).  The kernel is bound by GF(2^233) products (integer VALU + LDS; no carry-less
+multiply on gfx950), so the HBM fraction is tiny by construction; the product-rate model is reported
+next to it as "work_model".
 cpu_baseline: the C restatement with the reference's algorithmic shape (oracle/dvp_oracle.c: one
 tau-adic scalar multiplication per point + add tree) timed on this box's host cores on a bounded sample.
 """
@@ -120,7 +121,7 @@ def main():
         dvp.check(dvp.lib.dvp_profile_read(name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    acc_ms, acc_n = prof("msm_accum_affine")
+    acc_ms, acc_n = prof("msm_affine_round0")
     msm_ms, msm_n = prof("msm_total")
     ext_ms, ext_n = prof("extend_total")
 
@@ -137,14 +138,16 @@ def main():
     pairs_per_launch = pairs_total / max(acc_n, 1)
     acc_avg_ms = acc_ms / max(acc_n, 1)
     achieved = 96.0 * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 if acc_n else 0.0
-    # work model: W windows x (8M+5S ~ 8.65 field-multiplication equivalents) per pair; ceiling = the
-    # LDS-comb multiplier's own microbenchmark rate (scratch/ubench/gfmul_lds.hip: 25.6 G products/s chip-wide)
+    # work model of the dominant kernel (first batched-affine pair round): W windows per pair, half of the
+    # entries are additions, each 5 products + 1 squaring + 1/16 of a table-driven inversion ~ 6.1 field-
+    # multiplication equivalents; ceiling = the LDS-comb multiplier's own microbenchmark rate
+    # (scratch/ubench/gfmul_lds.hip: 28.1 G products/s chip-wide)
     W = -(-240 // 15)
-    mul_eq = pairs_per_launch * W * 8.65
-    mul_ceiling = 25.6e9
+    mul_eq = pairs_per_launch * W * 0.5 * 6.1
+    mul_ceiling = 28.1e9
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_accum_affine.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_affine_round0.json")))
         if log_m == 20 and world == 1:
             traffic = pmc["traffic_bytes_per_launch"]
     except Exception:
@@ -171,7 +174,7 @@ def main():
             "witness": "resident in HBM",
         },
         "roofline": {
-            "kernel": "dvp::k_accum_affine",
+            "kernel": "dvp::k_affine_round<true>",
             "bound": "hbm",
             "achieved": achieved,
             "peak": 8000.0,
@@ -183,7 +186,8 @@ def main():
             "algorithmic_bytes_per_launch": 96.0 * pairs_per_launch,
             "work_model": {
                 "note": "kernel is bound by GF(2^233) products (integer VALU + LDS table reads; gfx950 has no carry-less "
-                        "multiply): tau-adic windows x (8M+5S) per pair; ceiling = measured rate of the multiplier alone",
+                        "multiply): W/2 affine additions per pair at ~6.1 products each; ceiling = measured rate of the "
+                        "multiplier alone",
                 "mul_equivalents_per_launch": mul_eq,
                 "achieved_mul_per_s": mul_eq / (acc_avg_ms * 1e-3) if acc_n else 0.0,
                 "multiplier_microbench_mul_per_s": mul_ceiling,
@@ -192,7 +196,7 @@ def main():
         },
         "stages_ms_per_step": {
             "msm_total": msm_ms / args.steps,
-            "msm_accum_affine": acc_ms / args.steps,
+            "msm_affine_round0": acc_ms / args.steps,
             "extend_4x": ext_ms / args.steps,
         },
         "msm_mpoints_per_s": (pairs_total / (msm_ms * 1e-3) / 1e6) if msm_ms else None,

@@ -678,7 +678,6 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   int cur = 0;  // index of the live (cnt, off) pair
   const Aff* pts_in = (const Aff*)d_bases;
   size_t cap = p.e_max;
-  ProfScope ps_acc(PROF_MSM_ACCUM_AFFINE, st);
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
   if (ra > 0) {
@@ -690,9 +689,11 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
       size_t out_max = cap / 2 + nk + 1;
       Aff* outp = (r & 1) ? affB : affA;
       uint32_t grid = cdiv(cdiv(out_max, AFF_B), EC_TPB);
-      if (r == 0)
+      if (r == 0) {
+        ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // the dominant kernel: first pair round (gathers the bases)
         hipLaunchKernelGGL((k_affine_round<true>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, outp);
-      else
+        ps0.stop();
+      } else
         hipLaunchKernelGGL((k_affine_round<false>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, outp);
       pts_in = outp;
       cap = out_max;
@@ -701,7 +702,6 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   }
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
   if (rem_max <= 1) {
-    ps_acc.stop();
     if (ra == 0)
       hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, nk, bkt);
     else
@@ -712,11 +712,12 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, p.K);
     DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
-    if (ra == 0)
+    if (ra == 0) {
+      ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // small inputs: no pair rounds, this is the dominant kernel
       hipLaunchKernelGGL((k_accum_affine<true>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, p.K, bufA);
-    else
+      ps0.stop();
+    } else
       hipLaunchKernelGGL((k_accum_affine<false>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, p.K, bufA);
-    ps_acc.stop();
     cur = nxt;
     cap = tmax;
     Ld *in = bufA, *outb = bufB;

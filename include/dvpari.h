@@ -53,7 +53,8 @@ int dvp_set_device(int device_id);
 int64_t dvp_last_error_index(void);
 
 /* Per-kernel HIP-event timers for the measurement harness (bench.py): off by default.  Names:
- * "msm_accum_affine" (the dominant MSM kernel), "msm_total", "extend_total", "prove_total". */
+ * "msm_affine_round0" (k_affine_round<true>, the dominant MSM kernel), "msm_total", "extend_total",
+ * "prove_total". */
 void dvp_profile_enable(int on);
 void dvp_profile_reset(void);
 int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
