@@ -141,7 +141,7 @@ def main():
     # work model of the dominant kernel (first batched-affine pair round): W windows per pair, half of the
     # entries are additions, each 5 products + 1 squaring + 1/16 of a table-driven inversion ~ 6.1 field-
     # multiplication equivalents; ceiling = the LDS-comb multiplier's own microbenchmark rate
-    # (scratch/ubench/gfmul_lds.hip: 28.1 G products/s chip-wide)
+    # (tools/ubench/gfmul_lds.hip: 28.1 G products/s chip-wide)
     W = -(-240 // 15)
     mul_eq = pairs_per_launch * W * 0.5 * 6.1
     mul_ceiling = 28.1e9
