@@ -32,9 +32,10 @@ namespace dvp {
 
 // One thread per scalar: digits[w][i] (c-bit patterns) + bucket histogram.
 // Scalars >= r are rejected (flag); points flagged infinite contribute nothing.
+template <class DIGIT>
 __global__ void __launch_bounds__(256)
 k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W,
-         uint16_t* __restrict__ digits, unsigned long long* __restrict__ err) {
+         DIGIT* __restrict__ digits, unsigned long long* __restrict__ err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -57,7 +58,7 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
   for (int step = 0; step < W * c; ++step) {
     dig |= tau_step(r0, r1) << bitpos;
     if (++bitpos == c) {
-      digits[(size_t)w * n + i] = (uint16_t)dig;
+      digits[(size_t)w * n + i] = (DIGIT)dig;
       dig = 0;
       bitpos = 0;
       ++w;
@@ -201,6 +202,139 @@ k_scatter_local(const uint16_t* __restrict__ digits, uint32_t n, int c, const ui
   for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_TPB) {
     uint32_t d = dg[i];
     if (d) items[atomicAdd(&lds_cur[d], 1u)] = i;
+  }
+}
+
+// ---- two-level counting sort for the fixed-base mode (keys of FX_C = 20 bits) --------------------------
+// Level 1 partitions the entries by the top FX_HI bits (32 partitions, LDS cursors per block); level 2 is
+// the LDS counting sort above applied inside each partition on the low 15 bits.  An entry is the pair
+// (window w, scalar i); its id e = w * n_total + i0 + i indexes the pre-rotated base table directly.
+constexpr int FX_C = 20, FX_LO = 15, FX_HI = FX_C - FX_LO, FX_NP = 1 << FX_HI;
+constexpr int FX_W = TAU_DIGITS / FX_C;  // 12
+
+__global__ void __launch_bounds__(SORT_TPB)
+k_part_hist(const uint32_t* __restrict__ digits, size_t total, uint32_t* __restrict__ phist) {
+  __shared__ uint32_t h[FX_NP];
+  if (threadIdx.x < FX_NP) h[threadIdx.x] = 0;
+  __syncthreads();
+  size_t lo = (size_t)blockIdx.x * SORT_CHUNK, hi = min(total, lo + SORT_CHUNK);
+  for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
+    uint32_t d = digits[e];
+    if (d) atomicAdd(&h[d >> FX_LO], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < FX_NP) phist[(size_t)blockIdx.x * FX_NP + threadIdx.x] = h[threadIdx.x];
+}
+// per partition: prefix over blocks; then partition starts and the global chunk index of each partition
+__global__ void __launch_bounds__(64)
+k_part_scan(const uint32_t* __restrict__ phist, uint32_t nblk, uint32_t* __restrict__ pbase, uint32_t* __restrict__ pstart,
+            uint32_t* __restrict__ cstart) {
+  __shared__ uint32_t cnt[FX_NP];
+  uint32_t t = threadIdx.x;
+  if (t < FX_NP) {
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nblk; ++b) {
+      pbase[(size_t)b * FX_NP + t] = run;
+      run += phist[(size_t)b * FX_NP + t];
+    }
+    cnt[t] = run;
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t ps = 0, cs = 0;
+    for (int k = 0; k < FX_NP; ++k) {
+      pstart[k] = ps;
+      cstart[k] = cs;
+      ps += cnt[k];
+      cs += (cnt[k] + SORT_CHUNK - 1) / SORT_CHUNK;
+    }
+    pstart[FX_NP] = ps;
+    cstart[FX_NP] = cs;
+  }
+}
+__global__ void __launch_bounds__(SORT_TPB)
+k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, uint32_t n_total, uint32_t i0,
+               const uint32_t* __restrict__ pbase, const uint32_t* __restrict__ pstart, uint16_t* __restrict__ plo,
+               uint32_t* __restrict__ pid) {
+  __shared__ uint32_t cur[FX_NP];
+  if (threadIdx.x < FX_NP) cur[threadIdx.x] = pstart[threadIdx.x] + pbase[(size_t)blockIdx.x * FX_NP + threadIdx.x];
+  __syncthreads();
+  size_t lo = (size_t)blockIdx.x * SORT_CHUNK, hi = min(total, lo + SORT_CHUNK);
+  for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
+    uint32_t d = digits[e];
+    if (!d) continue;
+    uint32_t w = (uint32_t)(e / n), i = (uint32_t)(e - (size_t)w * n);
+    uint32_t pos = atomicAdd(&cur[d >> FX_LO], 1u);
+    plo[pos] = (uint16_t)(d & ((1u << FX_LO) - 1));
+    pid[pos] = w * n_total + i0 + i;
+  }
+}
+__device__ __forceinline__ uint32_t fx_chunk_partition(const uint32_t* __restrict__ cstart, uint32_t g) {
+  uint32_t hi = 0;
+  while (hi + 1 < (uint32_t)FX_NP && cstart[hi + 1] <= g) ++hi;
+  return hi;
+}
+// level 2, per global chunk g (partition hi, local chunk g - cstart[hi])
+__global__ void __launch_bounds__(SORT_TPB)
+k_hist_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ cstart,
+              uint16_t* __restrict__ hist) {
+  extern __shared__ uint32_t lds_cnt[];  // 2^(FX_LO-1) words (two u16 counters per word)
+  const uint32_t g = blockIdx.x, nb = 1u << FX_LO;
+  if (g >= cstart[FX_NP]) return;
+  for (uint32_t k = threadIdx.x; k < (nb >> 1); k += SORT_TPB) lds_cnt[k] = 0;
+  __syncthreads();
+  uint32_t hi = fx_chunk_partition(cstart, g);
+  uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * SORT_CHUNK, hi_e = min(pstart[hi + 1], lo_e + SORT_CHUNK);
+  for (uint32_t j = lo_e + threadIdx.x; j < hi_e; j += SORT_TPB) {
+    uint32_t d = plo[j];
+    atomicAdd(&lds_cnt[d >> 1], 1u << (16 * (d & 1)));
+  }
+  __syncthreads();
+  uint32_t* out = (uint32_t*)(hist + (size_t)g * nb);
+  for (uint32_t k = threadIdx.x; k < (nb >> 1); k += SORT_TPB) out[k] = lds_cnt[k];
+}
+__global__ void __launch_bounds__(256)
+k_hist_scan2(const uint16_t* __restrict__ hist, const uint32_t* __restrict__ cstart, uint32_t* __restrict__ chunk_off,
+             uint32_t* __restrict__ cnt) {
+  uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;  // < 2^FX_C
+  const uint32_t nb = 1u << FX_LO;
+  uint32_t hi = key >> FX_LO, b = key & (nb - 1);
+  uint32_t run = 0;
+  for (uint32_t g = cstart[hi]; g < cstart[hi + 1]; ++g) {
+    size_t idx = (size_t)g * nb + b;
+    uint32_t v = hist[idx];
+    chunk_off[idx] = run;
+    run += v;
+  }
+  cnt[key] = run;
+}
+__global__ void __launch_bounds__(SORT_TPB)
+k_scatter_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ pid, const uint32_t* __restrict__ pstart,
+                 const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ off, const uint32_t* __restrict__ chunk_off,
+                 uint32_t* __restrict__ items) {
+  extern __shared__ uint32_t lds_cur[];  // 2^FX_LO words
+  const uint32_t g = blockIdx.x, nb = 1u << FX_LO;
+  if (g >= cstart[FX_NP]) return;
+  uint32_t hi = fx_chunk_partition(cstart, g);
+  const uint32_t* co = chunk_off + (size_t)g * nb;
+  const uint32_t* of = off + ((size_t)hi << FX_LO);
+  for (uint32_t k = threadIdx.x; k < nb; k += SORT_TPB) lds_cur[k] = of[k] + co[k];
+  __syncthreads();
+  uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * SORT_CHUNK, hi_e = min(pstart[hi + 1], lo_e + SORT_CHUNK);
+  for (uint32_t j = lo_e + threadIdx.x; j < hi_e; j += SORT_TPB) items[atomicAdd(&lds_cur[plo[j]], 1u)] = pid[j];
+}
+
+// pre-rotated base table for the fixed-base mode: T[w][i] = tau^(FX_C w)(P_i)
+__global__ void __launch_bounds__(256) k_frob_table(const Aff* __restrict__ bases, uint32_t n, Aff* __restrict__ table) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff p = bases[i];
+  table[i] = p;
+#pragma unroll 1
+  for (int w = 1; w < FX_W; ++w) {
+    p.x = gf_sqr_n(p.x, FX_C);
+    p.y = gf_sqr_n(p.y, FX_C);
+    table[(size_t)w * n + i] = p;
   }
 }
 
@@ -540,7 +674,7 @@ struct MsmPlan {
   size_t e_max, t1_max, t2_max;
 };
 
-static MsmPlan msm_plan(size_t n) {
+static MsmPlan msm_plan(size_t n, bool fixed) {
   MsmPlan p;
   p.n = (uint32_t)n;
   // cost model: ceil(240/c) * (8.4 n + 28 * 2^c) field multiplications
@@ -554,6 +688,11 @@ static MsmPlan msm_plan(size_t n) {
   if (const char* e = getenv("DVP_MSM_C")) { int c = atoi(e); if (c >= 2 && c <= 15) p.c = c; }
   p.W = (TAU_DIGITS + p.c - 1) / p.c;
   p.nkeys = (uint32_t)p.W << p.c;
+  if (fixed) {  // all windows share one bucket set (bases pre-rotated by tau^(c w))
+    p.c = FX_C;
+    p.W = FX_W;
+    p.nkeys = 1u << FX_C;
+  }
   p.e_max = n * (size_t)p.W;
   // fan-in: keep >= ~256k level-1 tasks in flight when the input allows it
   uint32_t K = (uint32_t)(p.e_max / 262144);
@@ -571,8 +710,15 @@ static MsmPlan msm_plan(size_t n) {
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy,
-                   void* d_out_inf, hipStream_t st) {
+struct MsmFixedCtx {
+  Aff* table = nullptr;  // [FX_W][n_total]
+  uint32_t n_total = 0;
+};
+
+// fx == nullptr: one-shot MSM over (d_scalars, d_bases).  fx != nullptr: fixed-base mode, the scalars
+// d_scalars[0..n) belong to bases i0 .. i0+n of the pre-rotated table and d_inf is already offset by i0.
+static int msm_core(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, const MsmFixedCtx* fx, uint32_t i0,
+                    void* d_out_xy, void* d_out_inf, hipStream_t st) {
   if (n == 0) {
     DVP_HIP(hipMemsetAsync(d_out_xy, 0, 64, st));
     uint32_t one = 1;
@@ -588,6 +734,10 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
       attr_err = hipFuncSetAttribute((const void*)k_scatter_local, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_hist_local, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute((const void*)k_scatter_local2, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute((const void*)k_hist_local2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge,
                           (const void*)k_affine_round<true>, (const void*)k_affine_round<false>};
       for (const void* f : ec)
@@ -595,13 +745,20 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     });
     DVP_HIP(attr_err);
   }
-  MsmPlan p = msm_plan(n);
+  MsmPlan p = msm_plan(n, fx != nullptr);
   std::lock_guard<std::mutex> g(g_ws.mu);
   // carve the workspace
   size_t o = 0;
   auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
   size_t o_err = carve(16);
-  size_t o_digits = carve((size_t)p.W * n * 2);
+  size_t o_digits = carve(fx ? 16 : (size_t)p.W * n * 2);
+  const uint32_t fx_nblk = cdiv(p.e_max, SORT_CHUNK);
+  size_t o_digits32 = carve(fx ? p.e_max * 4 : 16);
+  size_t o_plo = carve(fx ? p.e_max * 2 : 16);
+  size_t o_pid = carve(fx ? p.e_max * 4 : 16);
+  size_t o_phist = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
+  size_t o_pbase = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
+  size_t o_pstart = carve((FX_NP + 1) * 4 * 2);
   size_t o_cnt = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_cursor = carve(((size_t)p.nkeys + 1) * 4);
@@ -611,7 +768,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   size_t o_off2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_bsum = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);
   size_t o_items = carve(p.e_max * 4);
-  const size_t sort_cells = (size_t)p.W * cdiv(n, SORT_CHUNK) << p.c;
+  const size_t sort_cells = fx ? ((size_t)(fx_nblk + FX_NP + 1) << FX_LO) : ((size_t)p.W * cdiv(n, SORT_CHUNK) << p.c);
   size_t o_hist16 = carve(sort_cells * 2);
   size_t o_choff = carve(sort_cells * 4);
   size_t o_bufA = carve(p.t1_max * sizeof(Ld));
@@ -628,6 +785,13 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   char* base = (char*)g_ws.p;
   auto* err = (unsigned long long*)(base + o_err);
   auto* digits = (uint16_t*)(base + o_digits);
+  auto* digits32 = (uint32_t*)(base + o_digits32);
+  auto* plo = (uint16_t*)(base + o_plo);
+  auto* pid = (uint32_t*)(base + o_pid);
+  auto* phist = (uint32_t*)(base + o_phist);
+  auto* pbase = (uint32_t*)(base + o_pbase);
+  auto* pstart = (uint32_t*)(base + o_pstart);
+  auto* cstart = pstart + FX_NP + 1;
   auto* cnt = (uint32_t*)(base + o_cnt);
   auto* off = (uint32_t*)(base + o_off);
   auto* cursor = (uint32_t*)(base + o_cursor);
@@ -651,9 +815,23 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
   (void)cursor;
-  hipLaunchKernelGGL(k_recode, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
-                     (uint32_t)n, p.c, p.W, digits, err);
-  {
+  if (fx)
+    hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
+                       (uint32_t)n, p.c, p.W, digits32, err);
+  else
+    hipLaunchKernelGGL((k_recode<uint16_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
+                       (uint32_t)n, p.c, p.W, digits, err);
+  if (fx) {
+    const uint32_t gmax = fx_nblk + FX_NP;  // upper bound on the number of level-2 chunks
+    hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, phist);
+    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(64), 0, st, phist, fx_nblk, pbase, pstart, cstart);
+    hipLaunchKernelGGL(k_part_scatter, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, (uint32_t)n, fx->n_total, i0, pbase,
+                       pstart, plo, pid);
+    hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << FX_LO) * 2, st, plo, pstart, cstart, hist16);
+    hipLaunchKernelGGL(k_hist_scan2, dim3(nk / 256), dim3(256), 0, st, hist16, cstart, chunk_off, cnt);
+    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
+    hipLaunchKernelGGL(k_scatter_local2, dim3(gmax), dim3(SORT_TPB), (1u << FX_LO) * 4, st, plo, pid, pstart, cstart, off, chunk_off, items);
+  } else {
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
     hipLaunchKernelGGL(k_hist_scan, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, nchunks, p.c, p.W, chunk_off, cnt);
@@ -676,7 +854,8 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
-  const Aff* pts_in = (const Aff*)d_bases;
+  const Aff* bases0 = fx ? fx->table : (const Aff*)d_bases;
+  const Aff* pts_in = bases0;
   size_t cap = p.e_max;
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
@@ -703,7 +882,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
   if (rem_max <= 1) {
     if (ra == 0)
-      hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, (const Aff*)d_bases, items, cnt, off, nk, bkt);
+      hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, bases0, items, cnt, off, nk, bkt);
     else
       hipLaunchKernelGGL(k_bucket_gather_aff, dim3(cdiv(nk, 256)), dim3(256), 0, st, pts_in, pc[cur], po[cur], nk, bkt);
   } else {
@@ -737,10 +916,11 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     hipLaunchKernelGGL(k_merge, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
   }
-  uint32_t cntT = (uint32_t)(p.W * p.c);
+  const int w_tail = fx ? 1 : p.W;  // fixed-base mode has a single bucket set
+  uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;
   Ld* tb = tail + cntT;
-  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, p.W, ta);
+  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, ta);
   while (cntT > 1) {
     uint32_t half = (cntT + 1) / 2;
     hipLaunchKernelGGL(k_pair_add, dim3(cdiv(half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
@@ -759,6 +939,34 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
     return DVP_EINVAL;
   }
   return DVP_OK;
+}
+
+int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy,
+                   void* d_out_inf, hipStream_t st) {
+  return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st);
+}
+
+// ---- fixed-base contexts (the prover's SRS vectors) -----------------------------------------------
+int msm_fixed_create(const Aff* d_bases, uint32_t n_total, MsmFixedCtx** out) {
+  MsmFixedCtx* c = new MsmFixedCtx();
+  c->n_total = n_total;
+  DVP_HIP(hipMalloc((void**)&c->table, (size_t)FX_W * n_total * sizeof(Aff)));
+  hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->table);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipDeviceSynchronize());
+  *out = c;
+  return DVP_OK;
+}
+void msm_fixed_destroy(MsmFixedCtx* c) {
+  if (!c) return;
+  if (c->table) (void)hipFree(c->table);
+  delete c;
+}
+// partial sum over bases [lo, hi) of the context; d_scalars / d_inf point at element lo
+int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
+                  void* d_out_inf, hipStream_t st) {
+  if (!c || lo > hi || hi > c->n_total) return DVP_EINVAL;
+  return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st);
 }
 
 }  // namespace dvp

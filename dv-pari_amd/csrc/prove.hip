@@ -16,6 +16,7 @@
 // The prover-side precomputes of prover_prepares_precomputes (:225-325) -- barycentric weights and
 // 1/Z_D on D' -- are regenerated on the device from the isogeny chain (k_domain_tables), so neither
 // z_poly nor the FFTR tree cache is needed.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,6 +37,11 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipStream_t st);
 int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st);
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
+struct MsmFixedCtx;
+int msm_fixed_create(const Aff* d_bases, uint32_t n_total, MsmFixedCtx** out);
+void msm_fixed_destroy(MsmFixedCtx* c);
+int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
+                  void* d_out_inf, hipStream_t st);
 
 // ---- domain tables from the isogeny chain ---------------------------------------------------------
 // For S = even leaves (D) of the 2m-leaf tree, Z_S = U - c0 V with (U,V) the projective image under
@@ -231,6 +237,9 @@ struct dvp_prover {
   Aff* bases_k = nullptr;      // [g_k0 | g_k1 | g_k2] 4m
   uint8_t* inf_k = nullptr;
   bool have_srs[5] = {false, false, false, false, false};
+  // fixed-base MSM contexts over [g_m | g_q] and [g_k_0 | g_k_1 | g_k_2]: bases pre-rotated by tau^(20 w), built
+  // lazily once the SRS is complete (12 x the base storage: 4.8 GB at m = 2^20 -- HBM is not the scarce resource)
+  MsmFixedCtx* fx[2] = {nullptr, nullptr};
   // work buffers
   Fr *w = nullptr, *E = nullptr, *E2 = nullptr, *r2 = nullptr, *SA = nullptr /* [w | q2] */, *den = nullptr, *den2 = nullptr,
      *SK = nullptr, *partial = nullptr, *abir0 = nullptr;
@@ -326,6 +335,8 @@ extern "C" void dvp_prover_destroy(dvp_prover* p) {
     if (mt.wire) (void)hipFree(mt.wire);
     if (mt.coeff) (void)hipFree(mt.coeff);
   }
+  msm_fixed_destroy(p->fx[0]);
+  msm_fixed_destroy(p->fx[1]);
   dvp_ecfft_destroy(p->tree);
   delete p;
 }
@@ -393,6 +404,9 @@ extern "C" int dvp_prover_set_srs_encoded(dvp_prover* p, int which, const uint8_
   DVP_HIP(hipMemcpy(de.p, enc, n * 30, hipMemcpyHostToDevice));
   DVP_TRY(decode_dev(de.as<uint8_t>(), n, base, inf, 0));
   p->have_srs[which] = true;
+  int slot = which < 2 ? 0 : 1;
+  msm_fixed_destroy(p->fx[slot]);
+  p->fx[slot] = nullptr;
   return DVP_OK;
 }
 extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_t* xy, const uint8_t* inf_in, size_t n) {
@@ -404,6 +418,9 @@ extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_
   if (inf_in) DVP_HIP(hipMemcpy(inf, inf_in, n, hipMemcpyHostToDevice));
   else DVP_HIP(hipMemset(inf, 0, n));
   p->have_srs[which] = true;
+  int slot = which < 2 ? 0 : 1;
+  msm_fixed_destroy(p->fx[slot]);
+  p->fx[slot] = nullptr;
   return DVP_OK;
 }
 // device-to-device flavour (bases produced on the GPU, e.g. by dvp_mulgen on the same device)
@@ -416,6 +433,9 @@ extern "C" int dvp_prover_set_srs_affine_dev(dvp_prover* p, int which, const voi
   if (d_inf) DVP_HIP(hipMemcpy(inf, d_inf, n, hipMemcpyDeviceToDevice));
   else DVP_HIP(hipMemset(inf, 0, n));
   p->have_srs[which] = true;
+  int slot = which < 2 ? 0 : 1;
+  msm_fixed_destroy(p->fx[slot]);
+  p->fx[slot] = nullptr;
   return DVP_OK;
 }
 
@@ -505,6 +525,13 @@ extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_
   const Fr* sc = which ? p->SK : p->SA;
   const Aff* bs = which ? p->bases_k : p->bases_a;
   const uint8_t* inf = which ? p->inf_k : p->inf_a;
+  // fixed-base mode pays off once the shared 2^20-bucket set is well filled
+  size_t fixed_min = (size_t)1 << 18;
+  if (const char* e = getenv("DVP_MSM_FIXED_MIN")) fixed_min = (size_t)atoll(e);
+  if (total >= fixed_min && total < ((size_t)1 << 27)) {
+    if (!p->fx[which]) DVP_TRY(msm_fixed_create(bs, (uint32_t)total, &p->fx[which]));
+    return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)lo, (uint32_t)hi, d_out_xy, d_out_inf, (hipStream_t)stream);
+  }
   return msm_affine_dev(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, (hipStream_t)stream);
 }
 extern "C" size_t dvp_prover_msm_size(const dvp_prover* p, int which) {
