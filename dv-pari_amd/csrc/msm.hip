@@ -225,32 +225,41 @@ k_part_hist(const uint32_t* __restrict__ digits, size_t total, uint32_t* __restr
   __syncthreads();
   if (threadIdx.x < FX_NP) phist[(size_t)blockIdx.x * FX_NP + threadIdx.x] = h[threadIdx.x];
 }
-// per partition: prefix over blocks; then partition starts and the global chunk index of each partition
-__global__ void __launch_bounds__(64)
-k_part_scan(const uint32_t* __restrict__ phist, uint32_t nblk, uint32_t* __restrict__ pbase, uint32_t* __restrict__ pstart,
-            uint32_t* __restrict__ cstart) {
-  __shared__ uint32_t cnt[FX_NP];
-  uint32_t t = threadIdx.x;
-  if (t < FX_NP) {
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < nblk; ++b) {
-      pbase[(size_t)b * FX_NP + t] = run;
-      run += phist[(size_t)b * FX_NP + t];
-    }
-    cnt[t] = run;
-  }
+// per partition (one block each): exclusive prefix over the level-1 blocks
+__global__ void __launch_bounds__(256)
+k_part_scan(const uint32_t* __restrict__ phist, uint32_t nblk, uint32_t* __restrict__ pbase, uint32_t* __restrict__ pcount) {
+  __shared__ uint32_t sh[256];
+  const uint32_t part = blockIdx.x, t = threadIdx.x;
+  const uint32_t per = (nblk + 255) / 256, b0 = t * per, b1 = min(nblk, b0 + per);
+  uint32_t s = 0;
+  for (uint32_t b = b0; b < b1; ++b) s += phist[(size_t)b * FX_NP + part];
+  sh[t] = s;
   __syncthreads();
-  if (t == 0) {
-    uint32_t ps = 0, cs = 0;
-    for (int k = 0; k < FX_NP; ++k) {
-      pstart[k] = ps;
-      cstart[k] = cs;
-      ps += cnt[k];
-      cs += (cnt[k] + SORT_CHUNK - 1) / SORT_CHUNK;
-    }
-    pstart[FX_NP] = ps;
-    cstart[FX_NP] = cs;
+  for (int o = 1; o < 256; o <<= 1) {
+    uint32_t x = (t >= (uint32_t)o) ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
   }
+  uint32_t run = sh[t] - s;
+  for (uint32_t b = b0; b < b1; ++b) {
+    pbase[(size_t)b * FX_NP + part] = run;
+    run += phist[(size_t)b * FX_NP + part];
+  }
+  if (t == 255) pcount[part] = sh[255];
+}
+// partition starts and the global level-2 chunk index of each partition
+__global__ void k_part_starts(const uint32_t* __restrict__ pcount, uint32_t* __restrict__ pstart, uint32_t* __restrict__ cstart) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint32_t ps = 0, cs = 0;
+  for (int k = 0; k < FX_NP; ++k) {
+    pstart[k] = ps;
+    cstart[k] = cs;
+    ps += pcount[k];
+    cs += (pcount[k] + SORT_CHUNK - 1) / SORT_CHUNK;
+  }
+  pstart[FX_NP] = ps;
+  cstart[FX_NP] = cs;
 }
 __global__ void __launch_bounds__(SORT_TPB)
 k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, uint32_t n_total, uint32_t i0,
@@ -758,7 +767,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_pid = carve(fx ? p.e_max * 4 : 16);
   size_t o_phist = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
   size_t o_pbase = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
-  size_t o_pstart = carve((FX_NP + 1) * 4 * 2);
+  size_t o_pstart = carve((FX_NP + 1) * 4 * 3);
   size_t o_cnt = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_cursor = carve(((size_t)p.nkeys + 1) * 4);
@@ -792,6 +801,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto* pbase = (uint32_t*)(base + o_pbase);
   auto* pstart = (uint32_t*)(base + o_pstart);
   auto* cstart = pstart + FX_NP + 1;
+  auto* pcount = cstart + FX_NP + 1;
   auto* cnt = (uint32_t*)(base + o_cnt);
   auto* off = (uint32_t*)(base + o_off);
   auto* cursor = (uint32_t*)(base + o_cursor);
@@ -824,7 +834,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   if (fx) {
     const uint32_t gmax = fx_nblk + FX_NP;  // upper bound on the number of level-2 chunks
     hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, phist);
-    hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(64), 0, st, phist, fx_nblk, pbase, pstart, cstart);
+    hipLaunchKernelGGL(k_part_scan, dim3(FX_NP), dim3(256), 0, st, phist, fx_nblk, pbase, pcount);
+    hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(64), 0, st, pcount, pstart, cstart);
     hipLaunchKernelGGL(k_part_scatter, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, (uint32_t)n, fx->n_total, i0, pbase,
                        pstart, plo, pid);
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << FX_LO) * 2, st, plo, pstart, cstart, hist16);
