@@ -174,3 +174,33 @@ def synthetic_dense(log_m: int, seed: int = 0x5EED0004, n_coeffs: int = 256):
     o = Csr(rp1, ow, zeros.copy())
     inst = R1CSInstance(m, 2, m, m, l, r, o, fr.vec(coeffs))
     return inst, w[1:3], w[3:]
+
+
+def synthetic_sparse(log_m: int, n_wires: int = None, max_terms: int = 8, seed: int = 0x5EED0005, n_coeffs: int = 64,
+                     n_public: int = 2):
+    """BASELINE config #5 stand-in: SP1-like sparse R1CS in the dump format's own terms -- every row is
+    (sum_k c_k w[a_k]) * (sum_k c'_k w[b_k]) = w[o] with 1..max_terms terms per side, rows < 2^log_m so
+    the instance is padded.  Returns (R1CSInstance, public, private); witness by forward evaluation."""
+    m = 1 << log_m
+    n_rows = m - m // 8 - 3  # deliberately not a power of two: exercises the zero-row padding
+    if n_wires is None:
+        n_wires = n_rows + 1 + n_public + 4
+    rng = np.random.default_rng(seed)
+    coeffs = [1] + [int.from_bytes(rng.bytes(28), "little") for _ in range(n_coeffs - 1)]
+    n_free = 1 + n_public + 4
+    assert n_wires >= n_free + n_rows
+    w = [1] + [int.from_bytes(rng.bytes(28), "little") for _ in range(n_free - 1)] + [0] * (n_wires - n_free)
+    rows = []
+    for i in range(n_rows):
+        o = n_free + i
+        sides = []
+        vals = []
+        for _ in range(2):
+            k = int(rng.integers(1, max_terms + 1))
+            terms = [(int(rng.integers(0, o)), int(rng.integers(0, n_coeffs))) for _ in range(k)]
+            sides.append(terms)
+            vals.append(sum(coeffs[c] * w[a] for a, c in terms) % P)
+        w[o] = vals[0] * vals[1] % P
+        rows.append((sides[0], sides[1], [(o, 0)]))
+    inst = R1CSInstance.from_rows(rows, coeffs, n_public, n_wires=n_wires)
+    return inst, w[1:1 + n_public], w[1 + n_public:]
