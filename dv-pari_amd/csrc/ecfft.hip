@@ -170,6 +170,46 @@ __global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const 
   }
 }
 
+// Fused bottom of an extend: the last `lb` decompose layers and the first `lb` recombine layers only mix
+// elements inside aligned blocks of 2^lb <= 2048 values, so a workgroup keeps 2048 consecutive values
+// (64 KB) in LDS and runs all 2*lb butterfly layers on them in ONE launch and ONE HBM round trip (the
+// per-layer kernels above then cover only the top layers of long vectors).  The matrices of these layers
+// total < 0.5 MB per tree and are served from L2.  `data` is the concatenation of the batch vectors.
+constexpr int FUSE_LOG = 11;
+constexpr uint32_t FUSE_ELEMS = 1u << FUSE_LOG;
+
+__device__ __forceinline__ void lds_bfly(Fr* x, const Fr* __restrict__ mats, int lh, uint32_t pairs) {
+  const uint32_t h = 1u << lh;
+  for (uint32_t q = threadIdx.x; q < pairs; q += blockDim.x) {
+    uint32_t i = q & (h - 1);
+    uint32_t i0 = ((q >> lh) << (lh + 1)) | i, i1 = i0 + h;
+    const Fr* m = mats + 4 * (size_t)i;
+    Fr e0 = x[i0], e1 = x[i1];
+    x[i0] = fr_add(fr_mul(m[0], e0), fr_mul(m[1], e1));
+    x[i1] = fr_add(fr_mul(m[2], e0), fr_mul(m[3], e1));
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256)
+k_extend_fused(Fr* __restrict__ data, const Fr* __restrict__ dec, const Fr* __restrict__ rec, uint32_t n, int ln, int lb,
+               size_t total) {
+  __shared__ Fr x[FUSE_ELEMS];
+  const size_t base = (size_t)blockIdx.x * FUSE_ELEMS;
+  const uint32_t elems = (uint32_t)min((size_t)FUSE_ELEMS, total - base);
+  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) x[k] = data[base + k];
+  __syncthreads();
+  for (int L = 0; L < lb; ++L) {  // decompose, sub-block size 2^(lb-L)
+    int d = ln - lb + L;
+    lds_bfly(x, dec + 4 * (size_t)(n - (n >> d)), lb - L - 1, elems >> 1);
+  }
+  for (int L = lb - 1; L >= 0; --L) {  // recombine
+    int d = ln - lb + L;
+    lds_bfly(x, rec + 4 * (size_t)(n - (n >> d)), lb - L - 1, elems >> 1);
+  }
+  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) data[base + k] = x[k];
+}
+
 // enter combine (one recursion level, all sub-problems at once):
 //   lo/hi evaluations u0,v0 (even leaves) and u1,v1 (odd leaves) -> res[2i]   = u0 + xnn[2i]  *v0
 //                                                                   res[2i+1] = u1 + xnn[2i+1]*v1
@@ -258,8 +298,13 @@ int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, 
     else if (batch == 2) launch_bfly<2>(data, mats, lh, n, st);
     else launch_bfly<1>(data, mats, lh, (uint32_t)((size_t)batch * n), st);
   };
-  for (int d = 0; d < ln; ++d) pass(ms->dec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
-  for (int d = ln - 1; d >= 0; --d) pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+  const int lb = ln < FUSE_LOG ? ln : FUSE_LOG;  // layers handled inside LDS
+  for (int d = 0; d < ln - lb; ++d) pass(ms->dec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+  {
+    size_t total = (size_t)batch * n;
+    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, data, ms->dec, ms->rec, n, ln, lb, total);
+  }
+  for (int d = ln - lb - 1; d >= 0; --d) pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
