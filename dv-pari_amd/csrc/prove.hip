@@ -38,7 +38,7 @@ int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipSt
 int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st);
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
 struct MsmFixedCtx;
-int msm_fixed_create(const Aff* d_bases, uint32_t n_total, MsmFixedCtx** out);
+int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out);
 void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
@@ -526,10 +526,10 @@ extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_
   const Aff* bs = which ? p->bases_k : p->bases_a;
   const uint8_t* inf = which ? p->inf_k : p->inf_a;
   // fixed-base mode pays off once the shared 2^20-bucket set is well filled
-  size_t fixed_min = (size_t)1 << 18;
+  size_t fixed_min = (size_t)1 << 16;
   if (const char* e = getenv("DVP_MSM_FIXED_MIN")) fixed_min = (size_t)atoll(e);
-  if (total >= fixed_min && total < ((size_t)1 << 27)) {
-    if (!p->fx[which]) DVP_TRY(msm_fixed_create(bs, (uint32_t)total, &p->fx[which]));
+  if (hi - lo >= fixed_min && total < ((size_t)1 << 27)) {
+    if (!p->fx[which]) DVP_TRY(msm_fixed_create(bs, (uint32_t)total, hi - lo, &p->fx[which]));
     return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)lo, (uint32_t)hi, d_out_xy, d_out_inf, (hipStream_t)stream);
   }
   return msm_affine_dev(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, (hipStream_t)stream);

@@ -119,14 +119,20 @@ def test_synthetic_2_14_verifies(dvp):
     tampered = dvp.proving.Proof(proof.commit_p, proof.kzg_k, (int.from_bytes(proof.a0, "little") ^ 1).to_bytes(29, "little"), proof.b0)
     assert not dvp.srs.verify(td, pub, tampered)
     assert not dvp.srs.verify(td, [pub[0], (pub[1] + 1) % o.P], proof)
-    # fixed-base MSM mode (pre-rotated bases, one shared 2^20-bucket set) must give the same bytes
+    # fixed-base MSM mode (bases pre-rotated by tau^(c w), one shared 2^c-bucket set): same bytes for the
+    # model-chosen window (single-level sort) and for forced c = 17 / 20 (two-level sort)
     os.environ["DVP_MSM_FIXED_MIN"] = "1"
     try:
-        pv3 = dvp.proving.Prover(inst)
-        pv3.set_srs(dvp.srs.verifier_runs_setup(pv3, inst, td))
-        assert pv3.prove(pub, prv) == proof
+        for forced in (None, "17", "20"):
+            if forced:
+                os.environ["DVP_MSM_FIXED_C"] = forced
+            pv3 = dvp.proving.Prover(inst)
+            pv3.set_srs(dvp.srs.verifier_runs_setup(pv3, inst, td))
+            assert pv3.prove(pub, prv) == proof, forced
+            pv3.close()
     finally:
         del os.environ["DVP_MSM_FIXED_MIN"]
+        os.environ.pop("DVP_MSM_FIXED_C", None)
     # SRS handed over in the reference's file format (30-byte encodings) gives the same proof
     pv2 = dvp.proving.Prover(inst)
     srs = dvp.srs.verifier_runs_setup(pv2, inst, td)
