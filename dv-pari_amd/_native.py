@@ -46,6 +46,10 @@ _SIGS = {
     "dvp_barycentric_eval": (C.c_int, [u64p, u64p, u64p, u64p, sz, u64p, u64p]),
     "dvp_msm_affine": (C.c_int, [u64p, u64p, u8p, sz, u64p, C.POINTER(C.c_int)]),
     "dvp_msm_affine_dev": (C.c_int, [vp, vp, vp, sz, vp, vp, vp]),
+    "dvp_msm_ctx_create": (C.c_int, [u64p, u8p, sz, sz, C.POINTER(vp)]),
+    "dvp_msm_ctx_destroy": (None, [vp]),
+    "dvp_msm_ctx_run": (C.c_int, [vp, u64p, sz, sz, u64p, C.POINTER(C.c_int)]),
+    "dvp_msm_ctx_run_dev": (C.c_int, [vp, vp, sz, sz, vp, vp, vp]),
     "dvp_msm_xsk233": (C.c_int, [u8p, u8p, sz, u8p]),
     "dvp_mulgen_batch": (C.c_int, [u64p, sz, u8p]),
     "dvp_mulgen_batch_affine": (C.c_int, [u64p, sz, u64p, u8p]),

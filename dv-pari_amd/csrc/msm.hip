@@ -1043,3 +1043,51 @@ extern "C" int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy,
   *out_is_infinity = (int)inf;
   return DVP_OK;
 }
+
+// ---- public fixed-base MSM context: many MSMs over one base vector (an SRS) -----------------------------
+struct dvp_msm_ctx {
+  MsmFixedCtx* fx = nullptr;
+  uint8_t* d_inf = nullptr;
+  size_t n = 0;
+};
+
+extern "C" int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out) {
+  if (!bases_xy || !out || !n || n >= ((size_t)1 << 27)) return DVP_EINVAL;
+  if (!range_hint || range_hint > n) range_hint = n;
+  DevBuf db;
+  DVP_TRY(db.alloc(n * sizeof(Aff)));
+  DVP_HIP(hipMemcpy(db.p, bases_xy, n * sizeof(Aff), hipMemcpyHostToDevice));
+  dvp_msm_ctx* c = new dvp_msm_ctx();
+  c->n = n;
+  DVP_HIP(hipMalloc((void**)&c->d_inf, n));
+  if (bases_inf) DVP_HIP(hipMemcpy(c->d_inf, bases_inf, n, hipMemcpyHostToDevice));
+  else DVP_HIP(hipMemset(c->d_inf, 0, n));
+  int rc = msm_fixed_create(db.as<Aff>(), (uint32_t)n, range_hint, &c->fx);
+  if (rc != DVP_OK) { (void)hipFree(c->d_inf); delete c; return rc; }
+  *out = c;
+  return DVP_OK;
+}
+extern "C" void dvp_msm_ctx_destroy(dvp_msm_ctx* c) {
+  if (!c) return;
+  msm_fixed_destroy(c->fx);
+  if (c->d_inf) (void)hipFree(c->d_inf);
+  delete c;
+}
+// sum_{i in [lo,hi)} scalars[i - lo] * base[i]; d_scalars holds hi - lo canonical scalars (device)
+extern "C" int dvp_msm_ctx_run_dev(dvp_msm_ctx* c, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
+  if (!c || !d_scalars || !d_out_xy || !d_out_inf || lo > hi || hi > c->n) return DVP_EINVAL;
+  return msm_fixed_dev(c->fx, d_scalars, c->d_inf + lo, (uint32_t)lo, (uint32_t)hi, d_out_xy, d_out_inf, (hipStream_t)stream);
+}
+extern "C" int dvp_msm_ctx_run(dvp_msm_ctx* c, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity) {
+  if (!c || !scalars || !out_xy || !out_is_infinity || lo > hi || hi > c->n) return DVP_EINVAL;
+  DevBuf ds, dout;
+  DVP_TRY(ds.alloc((hi - lo) * 32));
+  DVP_TRY(dout.alloc(80));
+  if (hi > lo) DVP_HIP(hipMemcpy(ds.p, scalars, (hi - lo) * 32, hipMemcpyHostToDevice));
+  DVP_TRY(msm_fixed_dev(c->fx, ds.p, c->d_inf + lo, (uint32_t)lo, (uint32_t)hi, dout.p, (char*)dout.p + 64, 0));
+  uint32_t inf;
+  DVP_HIP(hipMemcpy(out_xy, dout.p, 64, hipMemcpyDeviceToHost));
+  DVP_HIP(hipMemcpy(&inf, (char*)dout.p + 64, 4, hipMemcpyDeviceToHost));
+  *out_is_infinity = (int)inf;
+  return DVP_OK;
+}

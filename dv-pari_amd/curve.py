@@ -83,3 +83,34 @@ def multi_scalar_mul_bytes(scalars32: np.ndarray, bases30: np.ndarray) -> bytes:
     out = np.zeros(30, dtype=np.uint8)
     check(lib.dvp_msm_xsk233(ptr(s), ptr(b), s.shape[0], ptr(out)), "dvp_msm_xsk233")
     return out.tobytes()
+
+
+class FixedBaseMsm:
+    """multi_scalar_mul against a fixed base vector (an SRS vector): dvp_msm_ctx_* in include/dvpari.h."""
+
+    def __init__(self, points_xy: np.ndarray, points_inf: np.ndarray = None, range_hint: int = 0):
+        b = np.ascontiguousarray(points_xy, dtype=np.uint64).reshape(-1, 8)
+        self.n = b.shape[0]
+        inf_p = None
+        if points_inf is not None:
+            pi = np.ascontiguousarray(points_inf, dtype=np.uint8)
+            inf_p = ptr(pi)
+        h = C.c_void_p()
+        check(lib.dvp_msm_ctx_create(ptr(b), inf_p, self.n, range_hint, C.byref(h)), "dvp_msm_ctx_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.dvp_msm_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def run(self, scalars: np.ndarray, lo: int = 0, hi: int = None):
+        hi = self.n if hi is None else hi
+        s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        assert s.shape[0] == hi - lo
+        out = np.zeros(8, dtype=np.uint64)
+        is_inf = C.c_int(0)
+        check(lib.dvp_msm_ctx_run(self._h, ptr(s), lo, hi, ptr(out), C.byref(is_inf)), "dvp_msm_ctx_run")
+        return out, bool(is_inf.value)

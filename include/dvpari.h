@@ -116,6 +116,15 @@ int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint
                    uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void* d_bases_inf, size_t n,
                        void* d_out_xy /*8 x u64*/, void* d_out_inf /*u32*/, void* stream);
+/* Fixed-base flavour of the same seam: the reference calls multi_scalar_mul with the SAME bases (the SRS
+ * vectors g_m, g_q, g_k_*) in every proof, so the bases can be pre-rotated by powers of the Frobenius once
+ * (W x the storage) and all windows then share one bucket set.  range_hint = bases a typical call covers
+ * (the per-GPU shard; 0 = n).  run: sum over i in [lo, hi) of scalars[i - lo] * base[i]. */
+typedef struct dvp_msm_ctx dvp_msm_ctx;
+int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out);
+void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
+int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
+int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 /* same seam with the reference's own wire formats: scalars n x 32 B canonical LE, bases n x 30 B
  * xsk233 encodings (read_point_vec_from_file payload, src/io_utils.rs:187-239). */
 int dvp_msm_xsk233(const uint8_t* scalars, const uint8_t* bases_enc, size_t n, uint8_t out_enc[30]);

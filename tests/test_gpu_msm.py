@@ -123,3 +123,38 @@ def test_msm_wire_format(dvp):
     enc = dvp.curve.point_scalar_mul_gen_batch_bytes(k)
     out = dvp.curve.multi_scalar_mul_bytes(s.view(np.uint8).reshape(n, 32), enc)
     assert out == co.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)))
+
+
+@pytest.mark.parametrize("hint", [0, 1 << 10, 1 << 24])
+def test_fixed_base_msm_context(dvp, hint):
+    """dvp_msm_ctx_*: pre-rotated bases, shared bucket set; full range, sub-ranges (the per-GPU shards) and a
+    neutral base, for several window sizes (range_hint drives the choice; 2^24 forces c = 20, two-level sort)."""
+    n = 6000
+    k, s = rand_fr_np(n, 61), rand_fr_np(n, 62)
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[5] = 1
+    fb = dvp.curve.FixedBaseMsm(bases, inf, hint if hint <= n else 0) if hint <= n else None
+    if fb is None:
+        os.environ["DVP_MSM_FIXED_C"] = "20"
+        try:
+            fb = dvp.curve.FixedBaseMsm(bases, inf, 0)
+        finally:
+            del os.environ["DVP_MSM_FIXED_C"]
+    ks, ss = from_limbs(k), from_limbs(s)
+
+    def expect(lo, hi):
+        return co.k233_mulgen(sum(ss[i] * ks[i] for i in range(lo, hi) if i != 5) % o.P)
+
+    xy, is_inf = fb.run(s)
+    assert np_to_pt(xy, is_inf) == expect(0, n)
+    parts = []
+    for lo, hi in ((0, 1500), (1500, 1501), (1501, 6000), (10, 10)):
+        xy, is_inf = fb.run(s[lo:hi], lo, hi)
+        got = np_to_pt(xy, is_inf)
+        assert got == (expect(lo, hi) if hi > lo else None)
+        parts.append(got)
+    acc = None
+    for pt in parts:
+        acc = o.k233_add(acc, pt)
+    assert acc == expect(0, n)  # the shards add up to the whole (what the all-gather + local add relies on)
