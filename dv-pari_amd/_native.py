@@ -7,6 +7,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvpari_hip.so")
 
+# PyTorch-ROCm wheels bundle their own libamdhip64; if this library pulls in /opt/rocm's copy first, torch
+# later finds "No HIP GPUs".  Loading torch first makes both share one HIP runtime (torch is plumbing here:
+# device memory, streams, torch.distributed -- never the compute path).
+if not os.environ.get("DVP_NO_TORCH_PRELOAD"):
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional for the ctypes path
+        pass
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -158,3 +158,18 @@ def test_fixed_base_msm_context(dvp, hint):
     for pt in parts:
         acc = o.k233_add(acc, pt)
     assert acc == expect(0, n)  # the shards add up to the whole (what the all-gather + local add relies on)
+
+
+def test_msm_heavy_skew_2_18(dvp):
+    """2^18 scalars drawn from {0, 1, 2, 3}: a handful of buckets receive ~2^16 points each (R1CS witnesses
+    look like this: mostly bits and small values).  Exercises ~17 pair rounds and the skew-balanced reducer."""
+    n = 1 << 18
+    k = rand_fr_np(n, 71)
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
+    rng = np.random.default_rng(72)
+    s = np.zeros((n, 4), dtype=np.uint64)
+    s[:, 0] = rng.integers(0, 4, size=n)
+    assert gpu_msm(dvp, s, bases) == co.k233_mulgen(np_dot_mod(s, k))
+    fb = dvp.curve.FixedBaseMsm(bases)
+    xy, is_inf = fb.run(s)
+    assert np_to_pt(xy, is_inf) == co.k233_mulgen(np_dot_mod(s, k))

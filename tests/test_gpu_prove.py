@@ -170,3 +170,35 @@ def test_sparse_r1cs_via_dump_format(dvp):
     # witness file format (u32-BE count, 32-byte BE elements; src/gnark_r1cs.rs:58-77,188-198)
     blob = len(w).to_bytes(4, "big") + b"".join(x.to_bytes(32, "big") for x in w)
     assert dvp.gnark_r1cs.load_witness_bytes(blob) == w
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_prove_simulated_ranks(dvp, world):
+    """The multi-GPU decomposition on ONE GPU: every 'rank' computes the partial MSM of its index range through
+    dvp_prover_msm_partial, the partial points are combined exactly as GpuBackend.combine does after the
+    all-gather, and the proof must be byte-identical to the single-GPU proof (only the RCCL call itself is
+    not exercised here; tests/test_distributed_cpu.py covers the collective with gloo)."""
+    import torch
+
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(13)
+    rnd = random.Random(77)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    ref = pv.prove(pub, prv)
+    dev = torch.device("cuda", 0)
+    be = dvp.distributed.GpuBackend(pv, dev)
+    assignment = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
+    be.begin(assignment)
+    proof = None
+    for which in (0, 1):
+        parts = []
+        for r in range(world):
+            lo, hi = dvp.distributed.shard_range(be.msm_size(which), r, world)
+            parts.append(be.msm_partial(which, lo, hi).clone())
+        point = be.combine(torch.stack(parts))
+        if which == 0:
+            be.challenge(point)
+        else:
+            proof = be.finish(point)
+    assert proof == ref and dvp.srs.verify(td, pub, proof)
