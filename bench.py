@@ -142,8 +142,11 @@ def main():
     # entries are additions, each 5 products + 1 squaring + 1/16 of a table-driven inversion ~ 6.1 field-
     # multiplication equivalents; ceiling = the LDS-comb multiplier's own microbenchmark rate
     # (tools/ubench/gfmul_lds.hip: 28.1 G products/s chip-wide)
-    W = -(-240 // 15)
-    mul_eq = pairs_per_launch * W * 0.5 * 6.1
+    plans = [pv.msm_plan(0), pv.msm_plan(1)]
+    sizes = [pv.msm_size(0), pv.msm_size(1)]
+    # effective windows: tau-adic expansions are ~234 digits long, the last allocated window is mostly empty
+    w_eff = sum(-(-234 // max(c, 1)) * n for (c, _), n in zip(plans, sizes)) / max(sum(sizes), 1) if all(c for c, _ in plans) else 16
+    mul_eq = pairs_per_launch * w_eff * 0.5 * 6.1
     mul_ceiling = 28.1e9
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
@@ -171,6 +174,7 @@ def main():
             "n_wires": inst.n_wires,
             "msm_pairs_per_proof": inst.n_wires + 5 * m,
             "sharding": "MSM index ranges per rank, all-gather of partial points + local add" if world > 1 else "single GPU",
+            "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1]}, "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1]}},
             "witness": "resident in HBM",
         },
         "roofline": {

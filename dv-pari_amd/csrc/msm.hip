@@ -999,6 +999,12 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
   *out = c;
   return DVP_OK;
 }
+int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows) {
+  if (!c) return DVP_EINVAL;
+  *cbits = c->c;
+  *windows = c->W;
+  return DVP_OK;
+}
 void msm_fixed_destroy(MsmFixedCtx* c) {
   if (!c) return;
   if (c->table) (void)hipFree(c->table);

@@ -40,6 +40,7 @@ int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
 struct MsmFixedCtx;
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out);
 void msm_fixed_destroy(MsmFixedCtx* c);
+int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
 
@@ -533,6 +534,14 @@ extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_
     return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)lo, (uint32_t)hi, d_out_xy, d_out_inf, (hipStream_t)stream);
   }
   return msm_affine_dev(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, (hipStream_t)stream);
+}
+// window size / window count the fixed-base context of MSM `which` settled on (0,0 before its first use)
+extern "C" int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows) {
+  if (!p || (which != 0 && which != 1) || !c_bits || !windows) return DVP_EINVAL;
+  *c_bits = 0;
+  *windows = 0;
+  if (p->fx[which]) return msm_fixed_info(p->fx[which], c_bits, windows);
+  return DVP_OK;
 }
 extern "C" size_t dvp_prover_msm_size(const dvp_prover* p, int which) {
   if (!p) return 0;

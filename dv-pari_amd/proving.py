@@ -152,6 +152,12 @@ class Prover:
     def msm_size(self, which: int) -> int:
         return int(lib.dvp_prover_msm_size(self._h, which))
 
+    def msm_plan(self, which: int):
+        """(window bits, windows) of the fixed-base MSM `which`, (0, 0) before its first use"""
+        c, w = C.c_int(0), C.c_int(0)
+        check(lib.dvp_prover_msm_plan(self._h, which, C.byref(c), C.byref(w)), "dvp_prover_msm_plan")
+        return c.value, w.value
+
     def msm_partial(self, which: int, lo: int, hi: int, d_out_xy: int, d_out_inf: int, stream: int = 0):
         check(lib.dvp_prover_msm_partial(self._h, which, lo, hi, d_out_xy, d_out_inf, stream), "dvp_prover_msm_partial")
 

@@ -171,6 +171,8 @@ int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t proof[118], v
  *   begin -> msm_partial(0, lo, hi) -> challenge(commit point) -> msm_partial(1, lo, hi) -> finish */
 int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream);
 size_t dvp_prover_msm_size(const dvp_prover* p, int which);
+/* window bits / window count chosen for MSM `which` (0,0 until its fixed-base tables exist) */
+int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows);
 int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream);
 int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream);
