@@ -327,11 +327,24 @@ static int get_xnn(dvp_ecfft* c, int sl, Fr** out, hipStream_t st) {
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------
+static int ecfft_init(dvp_ecfft* c, uint32_t log_n, int shifted, uint32_t base_log);
+extern "C" void dvp_ecfft_destroy(dvp_ecfft* c);
+
 extern "C" int dvp_ecfft_create(uint32_t log_n, int shifted, uint32_t base_log, dvp_ecfft** out) {
   if (!out || log_n < 1 || log_n > (uint32_t)ECFFT_LOG_ORDER) return DVP_EINVAL;
   if (base_log == 0) base_log = log_n;
   if (base_log < log_n || base_log > (uint32_t)ECFFT_LOG_ORDER) return DVP_EINVAL;
   dvp_ecfft* c = new dvp_ecfft();
+  int rc = ecfft_init(c, log_n, shifted, base_log);
+  if (rc != DVP_OK) {
+    dvp_ecfft_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return DVP_OK;
+}
+
+static int ecfft_init(dvp_ecfft* c, uint32_t log_n, int shifted, uint32_t base_log) {
   c->log_n = (int)log_n;
   c->n_leaves = 1u << log_n;
   DVP_HIP(hipGetDevice(&c->device));
@@ -351,10 +364,7 @@ extern "C" int dvp_ecfft_create(uint32_t log_n, int shifted, uint32_t base_log, 
   std::vector<SwPt> tab(log_n);
   tab[0] = g;
   for (uint32_t j = 1; j < log_n; ++j) tab[j] = sw_add(tab[j - 1], tab[j - 1], a);
-  if (!fr_is_zero(tab[log_n - 1].y)) {  // order-2 point must have y == 0
-    delete c;
-    return DVP_EINVAL;
-  }
+  if (!fr_is_zero(tab[log_n - 1].y)) return DVP_EINVAL;  // order-2 point must have y == 0
   // q[j-1] = x of the point of order 2^j; pushed through the isogenies as we go
   std::vector<Fr> q(log_n);
   for (uint32_t j = 1; j <= log_n; ++j) q[j - 1] = tab[log_n - j].x;
@@ -397,7 +407,6 @@ extern "C" int dvp_ecfft_create(uint32_t log_n, int shifted, uint32_t base_log, 
     DVP_HIP(hipGetLastError());
     DVP_HIP(hipDeviceSynchronize());
   }
-  *out = c;
   return DVP_OK;
 }
 

@@ -205,8 +205,8 @@ k_scatter_local(const uint16_t* __restrict__ digits, uint32_t n, int c, const ui
   }
 }
 
-// ---- two-level counting sort for the fixed-base mode (keys of FX_C = 20 bits) --------------------------
-// Level 1 partitions the entries by the top FX_HI bits (32 partitions, LDS cursors per block); level 2 is
+// ---- two-level counting sort for the fixed-base mode (keys of up to 20 bits) ----------------------------
+// Level 1 partitions the entries by the top c - 15 bits (up to 32 partitions, LDS cursors per block); level 2 is
 // the LDS counting sort above applied inside each partition on the low 15 bits.  An entry is the pair
 // (window w, scalar i); its id e = w * n_total + i0 + i indexes the pre-rotated base table directly.
 constexpr int FX_LO_MAX = 15, FX_C_MAX = 20, FX_NP_MAX = 1 << (FX_C_MAX - FX_LO_MAX);  // c = lo + hi bits, chosen per context
@@ -692,7 +692,7 @@ static MsmWorkspace g_ws;
 struct MsmPlan {
   uint32_t n;
   int c, W;
-  uint32_t K, nkeys, levels;
+  uint32_t K, nkeys;
   size_t e_max, t1_max, t2_max;
 };
 
@@ -732,9 +732,6 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   p.K = K;
   p.t1_max = p.e_max / K + p.nkeys + 1;
   p.t2_max = p.t1_max / K + p.nkeys + 1;
-  // levels needed so that K^levels >= n (worst case: every point in one bucket)
-  p.levels = 1;
-  for (double cap = K; cap < (double)n; cap *= K) ++p.levels;
   return p;
 }
 
@@ -788,7 +785,6 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_pstart = carve((FX_NP_MAX + 1) * 4 * 3);
   size_t o_cnt = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off = carve(((size_t)p.nkeys + 1) * 4);
-  size_t o_cursor = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_ntask = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_toff = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_cnt2 = carve(((size_t)p.nkeys + 1) * 4);
@@ -822,7 +818,6 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto* pcount = cstart + FX_NP_MAX + 1;
   auto* cnt = (uint32_t*)(base + o_cnt);
   auto* off = (uint32_t*)(base + o_off);
-  auto* cursor = (uint32_t*)(base + o_cursor);
   auto* ntask = (uint32_t*)(base + o_ntask);
   auto* toff = (uint32_t*)(base + o_toff);
   auto* cnt2 = (uint32_t*)(base + o_cnt2);
@@ -842,7 +837,6 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
 
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
-  (void)cursor;
   if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
                        (uint32_t)n, p.c, p.W, digits32, err);

@@ -272,9 +272,22 @@ static Fr host_vanish(const dvp_prover* p, int which, const Fr& x_m) {
   return fr_sub(u, fr_mul(p->ctop_host[which], v));
 }
 
+static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32_t n_wires);
+extern "C" void dvp_prover_destroy(dvp_prover* p);
+
 extern "C" int dvp_prover_create(uint32_t log2_m, uint32_t n_public, uint32_t n_wires, dvp_prover** out) {
   if (!out || log2_m < 1 || log2_m > 26 || n_wires < 1 + n_public) return DVP_EINVAL;
   dvp_prover* p = new dvp_prover();
+  int rc = prover_init(p, log2_m, n_public, n_wires);
+  if (rc != DVP_OK) {
+    dvp_prover_destroy(p);  // releases whatever was allocated before the failure
+    return rc;
+  }
+  *out = p;
+  return DVP_OK;
+}
+
+static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32_t n_wires) {
   p->log_m = log2_m;
   p->m = 1u << log2_m;
   p->n_pub = n_public;
@@ -311,16 +324,12 @@ extern "C" int dvp_prover_create(uint32_t log2_m, uint32_t n_public, uint32_t n_
   dvp_ecfft* t = p->tree;
   int kk = (int)log2_m;
   hipLaunchKernelGGL(k_split_domains, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, p->dD, p->dD2);
-  Fr* dummy;
-  DVP_TRY(A((void**)&dummy, m * sizeof(Fr)));
   // bar weights of D and 1/Z_D on D'
   hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, kk,
                      t->layer(kk), 0, p->barw, p->z2inv);
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(p->ctop_host, t->layer(kk), 2 * sizeof(Fr), hipMemcpyDeviceToHost));
   DVP_HIP(hipDeviceSynchronize());
-  (void)hipFree(dummy);
-  *out = p;
   return DVP_OK;
 }
 
@@ -338,7 +347,7 @@ extern "C" void dvp_prover_destroy(dvp_prover* p) {
   }
   msm_fixed_destroy(p->fx[0]);
   msm_fixed_destroy(p->fx[1]);
-  dvp_ecfft_destroy(p->tree);
+  if (p->tree) dvp_ecfft_destroy(p->tree);
   delete p;
 }
 
