@@ -201,7 +201,7 @@ def main():
         "stages_ms_per_step": {
             "msm_total": msm_ms / args.steps,
             "msm_affine_round0": acc_ms / args.steps,
-            "extend_4x": ext_ms / args.steps,
+            "extend": ext_ms / args.steps,
         },
         "msm_mpoints_per_s": (pairs_total / (msm_ms * 1e-3) / 1e6) if msm_ms else None,
     }

@@ -82,6 +82,18 @@ _SIGS = {
     "dvp_prover_debug_read": (C.c_int, [vp, C.c_char_p, u64p, sz]),
     "dvp_prover_domains": (C.c_int, [vp, u64p, u64p]),
     "dvp_prover_domain_tables": (C.c_int, [vp, C.c_int, u64p, u64p]),
+    "dvp_ecfft_domain_tables": (C.c_int, [vp, C.c_int, u64p, u64p]),
+    "dvp_file_fr_vec_write": (C.c_int, [C.c_char_p, u64p, sz]),
+    "dvp_file_fr_vec_read": (C.c_int, [C.c_char_p, u64p, sz, C.POINTER(C.c_size_t)]),
+    "dvp_file_point_vec_write": (C.c_int, [C.c_char_p, u8p, sz]),
+    "dvp_file_point_vec_read": (C.c_int, [C.c_char_p, u8p, sz, C.POINTER(C.c_size_t)]),
+    "dvp_file_witness_read": (C.c_int, [C.c_char_p, u64p, sz, C.POINTER(C.c_size_t)]),
+    "dvp_file_witness_write": (C.c_int, [C.c_char_p, u64p, sz]),
+    "dvp_r1cs_dump_sizes": (C.c_int, [u8p, sz, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64 * 3), C.POINTER(u32)]),
+    "dvp_r1cs_dump_fill": (C.c_int, [u8p, sz, u64p, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3)]),
+    "dvp_prover_open_cache_dir": (C.c_int, [C.c_char_p, u32, C.POINTER(vp)]),
+    "dvp_prove_cache_dir": (C.c_int, [C.c_char_p, u64p, u32, u64p, u32, u8p]),
+    "dvp_cache_dir_release": (None, [C.c_char_p]),
     "dvp_transcript_challenge": (C.c_int, [u8p, u64p, u32, u64p]),
     "dvp_blake3": (C.c_int, [u8p, sz, u8p]),
 }

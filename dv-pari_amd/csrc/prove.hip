@@ -119,11 +119,23 @@ k_r1cs_eval(Csr A, Csr B, Csr C, const Fr* __restrict__ coeffs_m, const Fr* __re
 }
 
 // r2 = a2 b2 - i2 ; q2 = (r2 - c2) * z2inv        (src/proving.rs:492-508)
+// HORNER: i has only npub coefficients, so for a short public input i2 = i(d'_i) is evaluated directly (the same
+// canonical value the extend of i's evaluations yields, at npub products instead of an ECFFT pass).
+template <bool HORNER>
 __global__ void __launch_bounds__(256)
-k_quotient(const Fr* __restrict__ E2, const Fr* __restrict__ z2inv_m, uint32_t m, Fr* __restrict__ r2, Fr* __restrict__ q2) {
+k_quotient(Fr* __restrict__ E2, const Fr* __restrict__ z2inv_m, uint32_t m, const Fr* __restrict__ w, const Fr* __restrict__ dom2_m,
+           uint32_t npub, Fr* __restrict__ r2, Fr* __restrict__ q2) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  Fr a = E2[i], b = E2[(size_t)m + i], c = E2[2 * (size_t)m + i], iv = E2[3 * (size_t)m + i];
+  Fr a = E2[i], b = E2[(size_t)m + i], c = E2[2 * (size_t)m + i], iv;
+  if (HORNER) {
+    Fr d = dom2_m[i];
+    iv = fr_zero();
+    for (int j = (int)npub - 1; j >= 0; --j) iv = fr_add(fr_mul(d, iv), w[1 + j]);
+    E2[3 * (size_t)m + i] = iv;
+  } else {
+    iv = E2[3 * (size_t)m + i];
+  }
   Fr r = fr_sub(fr_mul(fr_to_mont(a), b), iv);
   r2[i] = r;
   q2[i] = fr_mul(z2inv_m[i], fr_sub(r, c));
@@ -257,6 +269,7 @@ struct dvp_prover {
 };
 
 static const int PT = 256;
+static const uint32_t HORNER_MAX_PUB = 48;  // ~ the Fr products per element of one extend pass
 
 static Fr host_vanish(const dvp_prover* p, int which, const Fr& x_m) {
   const dvp_ecfft* c = p->tree;
@@ -506,14 +519,22 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
   Csr C{p->mat[2].row_ptr, p->mat[2].wire, p->mat[2].coeff, p->mat[2].n_rows};
   dim3 gm(cdiv(m, PT)), bt(PT);
   hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, p->n_pub, m, p->E, p->flags);
-  DVP_HIP(hipMemcpyAsync(p->E2, p->E, 4 * (size_t)m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  // extend_evals (src/proving.rs:410-422): a, b, c' always; i only when its degree makes Horner the dearer route
+  uint32_t hmax = HORNER_MAX_PUB;
+  if (const char* e = getenv("DVP_HORNER_MAX_PUB")) hmax = (uint32_t)atoi(e);  // tests force either route
+  const bool horner = p->n_pub <= hmax;
+  const uint32_t n_ext = horner ? 3 : 4;
+  DVP_HIP(hipMemcpyAsync(p->E2, p->E, n_ext * (size_t)m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   {
     ProfScope pe(PROF_EXTEND_TOTAL, st);
-    DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2, 4, st));
+    DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2, n_ext, st));
     pe.stop();
   }
   DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(k_quotient, gm, bt, 0, st, p->E2, p->z2inv, m, p->r2, p->SA + nw);
+  if (horner)
+    hipLaunchKernelGGL(k_quotient<true>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
+  else
+    hipLaunchKernelGGL(k_quotient<false>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
   DVP_HIP(hipGetLastError());
   unsigned long long f[2];
   DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
@@ -678,23 +699,28 @@ extern "C" int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* 
 
 // Domain tables for setup-side callers (compute_barycentric_weights / evaluate_vanishing_poly_at_domain +
 // batch_inversion, src/ec_fft.rs:284-335,407-419): which = 0 -> (1/Z_D'(D), 1/Z_D(D')), which = 1 -> mirrored.
-extern "C" int dvp_prover_domain_tables(dvp_prover* p, int which, uint64_t* bar_weights, uint64_t* zinv_other) {
-  if (!p || !bar_weights || !zinv_other || (which != 0 && which != 1)) return DVP_EINVAL;
-  const size_t m = p->m;
-  dvp_ecfft* t = p->tree;
+extern "C" int dvp_ecfft_domain_tables(dvp_ecfft* t, int which, uint64_t* bar_weights, uint64_t* zinv_other) {
+  if (!t || !bar_weights || !zinv_other || (which != 0 && which != 1) || t->log_n < 2) return DVP_EINVAL;
+  const size_t m = t->n_leaves / 2;
+  const int kk = t->log_n - 1;
+  DVP_TRY(ecfft_device_consts(t));
   DevBuf bw, zi, o1, o2;
   DVP_TRY(bw.alloc(m * sizeof(Fr)));
   DVP_TRY(zi.alloc(m * sizeof(Fr)));
   DVP_TRY(o1.alloc(m * sizeof(Fr)));
   DVP_TRY(o2.alloc(m * sizeof(Fr)));
-  hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, (int)p->log_m,
-                     t->layer((int)p->log_m), which, bw.as<Fr>(), zi.as<Fr>());
+  hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, kk, t->layer(kk),
+                     which, bw.as<Fr>(), zi.as<Fr>());
   hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, 0, bw.as<Fr>(), o1.as<Fr>(), m);
   hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, 0, zi.as<Fr>(), o2.as<Fr>(), m);
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(bar_weights, o1.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
   DVP_HIP(hipMemcpy(zinv_other, o2.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
   return DVP_OK;
+}
+extern "C" int dvp_prover_domain_tables(dvp_prover* p, int which, uint64_t* bar_weights, uint64_t* zinv_other) {
+  if (!p) return DVP_EINVAL;
+  return dvp_ecfft_domain_tables(p->tree, which, bar_weights, zinv_other);
 }
 
 extern "C" int dvp_prover_domains(dvp_prover* p, uint64_t* d, uint64_t* d2) {

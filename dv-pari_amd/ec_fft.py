@@ -72,3 +72,39 @@ class FFTree:
 
     def exit_dev(self, d_in: int, d_out: int, stream: int = 0):
         check(lib.dvp_ecfft_exit_dev(self._h, d_in, d_out, stream), "dvp_ecfft_exit_dev")
+
+    # ---- setup-side operations -------------------------------------------------------
+    def vanish_at(self, which: int, x: int) -> int:
+        """Z_D(x) (which = 0, D = even leaves) or Z_D'(x) (which = 1) through the isogeny chain: the value
+        DensePolynomial::evaluate gives on z_poly / z_polyd (src/ec_fft.rs:362, 424-437)"""
+        from . import fr
+
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib.dvp_ecfft_vanish_at(self._h, which, ptr(fr.limbs(x)), ptr(out)), "dvp_ecfft_vanish_at")
+        return fr.to_int(out)
+
+    def domain_tables(self, which: int = 0):
+        """On a 2m-leaf tree (TREE_2N): (bar_wts, z_vals2inv) for which = 0, (bar_wtsd, z_vals2dinv) for which = 1
+        -- compute_barycentric_weights + evaluate_vanishing_poly_at_domain/batch_inversion, src/ec_fft.rs:284-335,
+        407-419, src/srs.rs:267-311 -- straight from the isogeny chain, no vanishing-polynomial coefficients needed."""
+        m = self.n // 2
+        a = np.zeros((m, 4), dtype=np.uint64)
+        b = np.zeros((m, 4), dtype=np.uint64)
+        check(lib.dvp_ecfft_domain_tables(self._h, which, ptr(a), ptr(b)), "dvp_ecfft_domain_tables")
+        return a, b
+
+
+def compute_vanishing_polynomial(tree2n: FFTree, which: int = 0) -> np.ndarray:
+    """compute_vanishing_polynomial, src/ec_fft.rs:241-282: the m+1 coefficients of Z_D (which = 0) or Z_D'
+    (which = 1), m = leaves/2.  Z on the 2m leaves (zero on its own half, 1/z_vals2inv on the other) -> FFTree::exit
+    on the GPU -> truncate; the upper m-1 coefficients must vanish and the polynomial must be monic."""
+    from . import fr
+
+    m = tree2n.n // 2
+    _, zinv = tree2n.domain_tables(which)
+    ev = np.zeros((2 * m, 4), dtype=np.uint64)
+    ev[(1 - which)::2] = fr.batch_inverse(zinv)
+    co = tree2n.exit(ev)
+    if co[m + 1:].any() or fr.to_int(co[m]) != 1:
+        raise ArithmeticError("vanishing polynomial is not monic of degree m")
+    return np.ascontiguousarray(co[: m + 1])

@@ -1,11 +1,13 @@
 """Host mirror of src/gnark_r1cs.rs: the sparse R1CS (rows of (wire_id, coeff_id) terms over a
 coefficient table), kept as three CSR matrices so it can be handed to the GPU prover unchanged."""
+import ctypes as C
 import struct
 from dataclasses import dataclass
 
 import numpy as np
 
 from . import fr
+from ._native import lib, check, ptr
 
 P = fr.P
 
@@ -62,48 +64,82 @@ class R1CSInstance:
 
     # ---- the SP1/gnark dump format, src/gnark_r1cs.rs:84-91,121-185 (writer mirrors :405-438) -------------
     def to_dump_bytes(self) -> bytes:
-        out = [struct.pack("<I", self.coeffs.shape[0])]
-        for c in fr.to_ints(self.coeffs):
-            out.append(c.to_bytes(32, "big"))
-        out.append(struct.pack("<I", self.n_rows))
-        for i in range(self.n_rows):
-            parts = []
-            for m in (self.l, self.r, self.o):
-                a, b = int(m.row_ptr[i]), int(m.row_ptr[i + 1])
-                parts.append((m.wire[a:b], m.coeff[a:b]))
-            out.append(struct.pack("<III", *(len(p[0]) for p in parts)))
-            for w, c in parts:
-                inter = np.empty(2 * len(w), dtype="<u4")
-                inter[0::2], inter[1::2] = w, c
-                out.append(inter.tobytes())
-        return b"".join(out)
+        nr = self.n_rows
+        cnt = [np.diff(m.row_ptr[: nr + 1].astype(np.int64)) for m in (self.l, self.r, self.o)]
+        words = 3 + 2 * (cnt[0] + cnt[1] + cnt[2])
+        start = np.zeros(nr + 1, dtype=np.int64)
+        start[1:] = np.cumsum(words)
+        body = np.zeros(int(start[-1]), dtype="<u4")
+        before = np.zeros(nr, dtype=np.int64)
+        for k, m in enumerate((self.l, self.r, self.o)):
+            body[start[:-1] + k] = cnt[k]
+            nnz = int(m.row_ptr[nr])
+            row_of = np.repeat(np.arange(nr, dtype=np.int64), cnt[k])
+            local = np.arange(nnz, dtype=np.int64) - m.row_ptr[:nr].astype(np.int64)[row_of]
+            dst = start[:-1][row_of] + 3 + 2 * (before[row_of] + local)
+            body[dst] = m.wire[:nnz]
+            body[dst + 1] = m.coeff[:nnz]
+            before += cnt[k]
+        coeff_be = np.ascontiguousarray(self.coeffs, dtype="<u8").view(np.uint8).reshape(-1, 32)[:, ::-1]
+        return b"".join([struct.pack("<I", self.coeffs.shape[0]), coeff_be.tobytes(), struct.pack("<I", nr), body.tobytes()])
+
+    def write_dump_file(self, path):
+        with open(path, "wb") as f:
+            f.write(self.to_dump_bytes())
 
     @staticmethod
     def from_dump_bytes(buf: bytes, num_public_inputs: int):
-        """load_sparse_r1cs_from_file + from_dump, src/gnark_r1cs.rs:121-185,282-296."""
-        (nc,) = struct.unpack_from("<I", buf, 0)
-        off = 4
-        coeffs = [int.from_bytes(buf[off + 32 * i: off + 32 * (i + 1)], "big") % P for i in range(nc)]
-        off += 32 * nc
-        (nr,) = struct.unpack_from("<I", buf, off)
-        off += 4
-        rows = []
-        for _ in range(nr):
-            nl, nrr, no = struct.unpack_from("<III", buf, off)
-            off += 12
-            row = []
-            for cnt in (nl, nrr, no):
-                arr = np.frombuffer(buf, dtype="<u4", count=2 * cnt, offset=off)
-                off += 8 * cnt
-                row.append([(int(arr[2 * k]), int(arr[2 * k + 1])) for k in range(cnt)])
-            rows.append(tuple(row))
-        return R1CSInstance.from_rows(rows, coeffs, num_public_inputs)
+        """load_sparse_r1cs_from_file + from_dump, src/gnark_r1cs.rs:121-185,282-296 (native parser,
+        dvp_r1cs_dump_*): n_wires = max wire id + 1 as in accumulate_m_values, src/srs.rs:56-62."""
+        b = np.frombuffer(buf, dtype=np.uint8)
+        nc, nr, nw = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        nnz = (C.c_uint64 * 3)()
+        check(lib.dvp_r1cs_dump_sizes(ptr(b), b.shape[0], C.byref(nc), C.byref(nr), C.byref(nnz), C.byref(nw)), "dvp_r1cs_dump_sizes")
+        coeffs = np.zeros((nc.value, 4), dtype=np.uint64)
+        rp = [np.zeros(nr.value + 1, dtype=np.uint32) for _ in range(3)]
+        wi = [np.zeros(max(int(nnz[k]), 1), dtype=np.uint32) for k in range(3)]
+        ci = [np.zeros(max(int(nnz[k]), 1), dtype=np.uint32) for k in range(3)]
+        arr = lambda xs: (C.c_void_p * 3)(*[x.ctypes.data for x in xs])
+        a_rp, a_wi, a_ci = arr(rp), arr(wi), arr(ci)
+        check(lib.dvp_r1cs_dump_fill(ptr(b), b.shape[0], ptr(coeffs), C.byref(a_rp), C.byref(a_wi), C.byref(a_ci)), "dvp_r1cs_dump_fill")
+        m = 1
+        while m < nr.value:
+            m *= 2
+        mats = [Csr(rp[k], wi[k][: int(nnz[k])], ci[k][: int(nnz[k])]) for k in range(3)]
+        return R1CSInstance(m, num_public_inputs, nr.value, nw.value, mats[0], mats[1], mats[2], coeffs)
+
+    @staticmethod
+    def from_dump_file(path, num_public_inputs: int):
+        with open(path, "rb") as f:
+            return R1CSInstance.from_dump_bytes(f.read(), num_public_inputs)
 
 
 def load_witness_bytes(buf: bytes):
     """witness file: u32-BE count || count x 32-byte BE elements (src/gnark_r1cs.rs:58-77,188-198)."""
     (n,) = struct.unpack_from(">I", buf, 0)
     return [int.from_bytes(buf[4 + 32 * i: 4 + 32 * (i + 1)], "big") % P for i in range(n)]
+
+
+def load_witness_from_file(path) -> np.ndarray:
+    """load_witness_from_file, src/gnark_r1cs.rs:188-210 -> uint64 [n,4] canonical (values reduced mod p)"""
+    import os
+
+    pth = os.fspath(path).encode()
+    n = C.c_size_t(0)
+    check(lib.dvp_file_witness_read(pth, None, 0, C.byref(n)), f"load_witness_from_file({path})")
+    out = np.zeros((n.value, 4), dtype=np.uint64)
+    if n.value:
+        check(lib.dvp_file_witness_read(pth, ptr(out), n.value, C.byref(n)), f"load_witness_from_file({path})")
+    return out
+
+
+def write_witness_to_file(path, values):
+    """the writer side of the witness format (the reference only reads it; used by the synthetic generators)"""
+    import os
+
+    v = values if isinstance(values, np.ndarray) else fr.vec(values)
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    check(lib.dvp_file_witness_write(os.fspath(path).encode(), ptr(v), v.shape[0]), f"write_witness_to_file({path})")
 
 
 def evaluate_monomial_basis_poly(public_inputs, alpha):

@@ -39,6 +39,20 @@ class Proof:
         by = bytes(sum(bits[8 * i + j] << j for j in range(8)) for i in range(118))
         return Proof.from_bytes(by)
 
+    @staticmethod
+    def prove(cache_dir, public_inputs, private_inputs) -> "Proof":
+        """Proof::prove(cache_dir, public_inputs, private_inputs), src/proving.rs:426-688, with the reference's own
+        signature: the R1CS dump and the SRS point files are read from cache_dir on the first call and stay in HBM
+        (dvp_prove_cache_dir); release_cache_dir() frees them."""
+        import os
+
+        pub = _fr_arg(public_inputs)
+        prv = _fr_arg(private_inputs)
+        out = np.zeros(118, dtype=np.uint8)
+        check(lib.dvp_prove_cache_dir(os.fspath(cache_dir).encode(), ptr(pub), pub.shape[0], ptr(prv), prv.shape[0], ptr(out)),
+              "dvp_prove_cache_dir")
+        return Proof.from_bytes(out.tobytes())
+
     def a0_fr(self):
         v = int.from_bytes(self.a0, "little")
         return (v, True) if v < P else (0, False)  # FrBits::to_fr, src/curve.rs:43-59
@@ -46,6 +60,47 @@ class Proof:
     def b0_fr(self):
         v = int.from_bytes(self.b0, "little")
         return (v, True) if v < P else (0, False)
+
+
+def _fr_arg(v) -> np.ndarray:
+    a = v if isinstance(v, np.ndarray) else (fr.vec(v) if len(v) else np.zeros((0, 4), dtype=np.uint64))
+    return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+
+
+def release_cache_dir(cache_dir=None):
+    """drop the prover(s) dvp_prove_cache_dir keeps for cache_dir (None: all)"""
+    import os
+
+    lib.dvp_cache_dir_release(None if cache_dir is None else os.fspath(cache_dir).encode())
+
+
+def prover_prepares_precomputes(cache_dir, validate_precompute: bool = False):
+    """prover_prepares_precomputes, src/proving.rs:225-325: needs z_poly in cache_dir (its length fixes m) and
+    produces bar_wts and z_vals2inv when they are missing -- here from the isogeny chain in milliseconds.  The GPU
+    prover itself regenerates all three on the device and reads none of these files; this exists so that a cache_dir
+    prepared here is complete for a reference prover as well.  validate_precompute checks that z_poly is the
+    vanishing polynomial of D (the reference evaluates it on D, :281-296)."""
+    import os
+
+    from . import artifacts as A, io_utils
+    from .ec_fft import FFTree, compute_vanishing_polynomial
+
+    zpoly = io_utils.read_fr_vec_from_file(os.path.join(cache_dir, A.Z_POLY))
+    m = zpoly.shape[0] - 1
+    assert m >= 2 and m & (m - 1) == 0, "z_poly must hold m+1 coefficients, m a power of two"
+    tree2n = FFTree(2 * m)
+    try:
+        if validate_precompute and not np.array_equal(zpoly, compute_vanishing_polynomial(tree2n, 0)):
+            raise ValueError("vanishing poly does not evaluate to zero at all points in domain")
+        bw_path, zi_path = os.path.join(cache_dir, A.BAR_WTS), os.path.join(cache_dir, A.Z_VALS2_INV)
+        if not (os.path.exists(bw_path) and os.path.exists(zi_path)):
+            bar, zinv = tree2n.domain_tables(0)
+            if not os.path.exists(bw_path):
+                io_utils.write_fr_vec_to_file(bw_path, bar)
+            if not os.path.exists(zi_path):
+                io_utils.write_fr_vec_to_file(zi_path, zinv)
+    finally:
+        tree2n.close()
 
 
 def transcript_challenge(commit_p: bytes, public_inputs) -> int:
@@ -124,10 +179,7 @@ class Prover:
     # ---- prove -------------------------------------------------------------------------------------
     def prove(self, public_inputs, private_inputs) -> Proof:
         """Proof::prove(cache_dir, public_inputs, private_inputs), src/proving.rs:426-688."""
-        pub = public_inputs if isinstance(public_inputs, np.ndarray) else fr.vec(public_inputs)
-        prv = private_inputs if isinstance(private_inputs, np.ndarray) else fr.vec(private_inputs)
-        pub = np.ascontiguousarray(pub, dtype=np.uint64).reshape(-1, 4)
-        prv = np.ascontiguousarray(prv, dtype=np.uint64).reshape(-1, 4)
+        pub, prv = _fr_arg(public_inputs), _fr_arg(private_inputs)
         out = np.zeros(118, dtype=np.uint8)
         check(lib.dvp_prove(self._h, ptr(pub), pub.shape[0], ptr(prv), prv.shape[0], ptr(out)), "dvp_prove")
         return Proof.from_bytes(out.tobytes())

@@ -1,6 +1,8 @@
-"""Host mirror of src/srs.rs: Trapdoor, SRS, verifier_runs_setup (its arithmetic; the cache-dir file
-plumbing of the reference is out of scope) and verify.  Every vector stage runs on the GPU through
-the C ABI; python ints only appear for the handful of trapdoor scalars."""
+"""Host mirror of src/srs.rs: Trapdoor, SRS, verifier_runs_setup (in memory, and the cache_dir flavour that
+reads the R1CS dump and writes the reference's SRS / precompute files) and verify.  Every vector stage runs
+on the GPU through the C ABI; python ints only appear for the handful of trapdoor scalars."""
+import os
+
 from dataclasses import dataclass
 
 import numpy as np
@@ -63,6 +65,35 @@ def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
     g_q = fr.scale(l_taud, z_tau * delta2 % P * td.epsilon % P)
     g_k = [l_tau, fr.scale(l_tau, td.delta), fr.scale(l_taul, delta2)]
     return g_m, g_q, g_k
+
+
+def verifier_runs_setup_cache_dir(td: Trapdoor, cache_dir, num_public_inputs: int, write_precomputes: bool = True):
+    """SRS::verifier_runs_setup(trapdoor, cache_dir, num_public_inputs, ..), src/srs.rs:177-361, as the reference
+    runs it: reads cache_dir/r1cs_to_dvsnark, writes g_m, g_q, g_k_0..2 as point-vector files
+    (compute_srs_matrices -> write_point_vec_to_file) and, with write_precomputes, the domain files a reference
+    prover/verifier would otherwise spend hours on (z_poly, z_polyd, bar_wts, bar_wtsd, z_vals2inv, z_vals2dinv).
+    Returns (instance, prover context with the SRS loaded)."""
+    from . import artifacts as A, io_utils
+    from .ec_fft import FFTree, compute_vanishing_polynomial
+    from .proving import Prover
+
+    os.makedirs(cache_dir, exist_ok=True)
+    inst = R1CSInstance.from_dump_file(os.path.join(cache_dir, A.R1CS_CONSTRAINTS_FILE), num_public_inputs)
+    pv = Prover(inst)
+    g_m, g_q, g_k = srs_scalars(pv, inst, td)
+    for name, sc in zip(A.SRS_FILES, (g_m, g_q, g_k[0], g_k[1], g_k[2])):
+        io_utils.write_point_vec_to_file(os.path.join(cache_dir, name), curve.point_scalar_mul_gen_batch_bytes(sc))
+    if write_precomputes:
+        tree2n = FFTree(2 * inst.num_constraints)
+        for which, (zp, bw, zi) in enumerate(((A.Z_POLY, A.BAR_WTS, A.Z_VALS2_INV), (A.Z_POLYD, A.BAR_WTSD, A.Z_VALS2D_INV))):
+            bar, zinv = tree2n.domain_tables(which)
+            io_utils.write_fr_vec_to_file(os.path.join(cache_dir, zp), compute_vanishing_polynomial(tree2n, which))
+            io_utils.write_fr_vec_to_file(os.path.join(cache_dir, bw), bar)
+            io_utils.write_fr_vec_to_file(os.path.join(cache_dir, zi), zinv)
+        tree2n.close()
+    for which, name in enumerate(A.SRS_FILES):
+        pv.set_srs_encoded(which, io_utils.read_point_vec_payload(os.path.join(cache_dir, name)))
+    return inst, pv
 
 
 def _t(csr, n_wires):

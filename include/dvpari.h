@@ -184,9 +184,41 @@ int dvp_prover_domains(dvp_prover* p, uint64_t* d, uint64_t* d2);
  * (bar_wtsd, z_vals2d_inv) -- compute_barycentric_weights / prepare_z_inv, src/srs.rs:267-311 */
 int dvp_prover_domain_tables(dvp_prover* p, int which, uint64_t* bar_weights, uint64_t* zinv_other);
 
+/* the same tables from a stand-alone 2m-leaf tree (TREE_2N): bar_weights[m], zinv_other[m], canonical */
+int dvp_ecfft_domain_tables(dvp_ecfft* tree2n, int which, uint64_t* bar_weights, uint64_t* zinv_other);
+
 /* Transcript::output, src/proving.rs:164-197, and the BLAKE3 hash it is built on */
 int dvp_transcript_challenge(const uint8_t commit_p[30], const uint64_t* public_inputs, uint32_t n_public, uint64_t out[4]);
 int dvp_blake3(const uint8_t* data, size_t len, uint8_t out[32]);
+
+/* ------------------------------------------------------------------------------------------ */
+/* cache_dir formats: the files the reference's setup / prover exchange.          */
+/* Host-only code; the counted readers take out == NULL to query the element count.            */
+/* ------------------------------------------------------------------------------------------ */
+/* u64-LE n || n x 29 B canonical LE: write_fr_vec_to_file / read_fr_vec_from_file, src/io_utils.rs:42-70,122-179 */
+int dvp_file_fr_vec_write(const char* path, const uint64_t* limbs, size_t n);
+int dvp_file_fr_vec_read(const char* path, uint64_t* out, size_t cap, size_t* n);
+/* u64-LE n || n x 30 B: write_point_vec_to_file / read_point_vec_from_file, src/io_utils.rs:83-111,187-239 */
+int dvp_file_point_vec_write(const char* path, const uint8_t* enc, size_t n);
+int dvp_file_point_vec_read(const char* path, uint8_t* out, size_t cap, size_t* n);
+/* u32-BE n || n x 32 B big-endian, reduced mod p: load_witness_from_file, src/gnark_r1cs.rs:58-77,188-210 */
+int dvp_file_witness_read(const char* path, uint64_t* out, size_t cap, size_t* n);
+int dvp_file_witness_write(const char* path, const uint64_t* limbs, size_t n);
+/* gnark/SP1 sparse R1CS dump (src/gnark_r1cs.rs:84-91,121-185) -> coefficient table (from_be_bytes_mod_order,
+ * :282-289) + L/R/O as CSR.  n_wires = max wire id + 1 (accumulate_m_values, src/srs.rs:56-62).  Two calls: sizes,
+ * then fill caller-allocated arrays (row_ptr[k]: n_rows+1, wire[k]/coeff_id[k]: nnz[k]). */
+int dvp_r1cs_dump_sizes(const uint8_t* buf, size_t len, uint32_t* n_coeffs, uint32_t* n_rows, uint64_t nnz[3], uint32_t* n_wires);
+int dvp_r1cs_dump_fill(const uint8_t* buf, size_t len, uint64_t* coeffs, uint32_t* const row_ptr[3], uint32_t* const wire[3],
+                       uint32_t* const coeff_id[3]);
+/* The loading half of Proof::prove (src/proving.rs:435-470,509-511,666-672): reads cache_dir/r1cs_to_dvsnark and the
+ * SRS vectors g_m, g_q, g_k_0, g_k_1, g_k_2 (src/artifacts.rs:18-27,76), decodes the points on the GPU
+ * (DVP_EDECODE = the reference's assert!(valid)) and returns a ready prover; the witness length is |g_m|. */
+int dvp_prover_open_cache_dir(const char* cache_dir, uint32_t n_public, dvp_prover** out);
+/* Proof::prove(cache_dir, public_inputs, private_inputs) itself: opens cache_dir on first use and keeps the prover in
+ * a process-wide table keyed by (cache_dir, n_public); dvp_cache_dir_release(NULL) drops every entry. */
+int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
+                        uint32_t n_private, uint8_t proof[118]);
+void dvp_cache_dir_release(const char* cache_dir);
 
 #ifdef __cplusplus
 }

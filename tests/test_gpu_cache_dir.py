@@ -1,0 +1,182 @@
+"""GPU tests (-m gpu) of the cache_dir drop-in: setup writes the reference's files, Proof::prove
+reads them back with the reference's own signature; vanishing-polynomial / barycentric precomputes on the GPU."""
+import json
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import pyref as o
+from util import to_limbs, from_limbs
+
+pytestmark = pytest.mark.gpu
+VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+
+
+def poly_from_roots(roots):
+    c = [1]
+    for r in roots:
+        n = [0] * (len(c) + 1)
+        for i, v in enumerate(c):
+            n[i + 1] = (n[i + 1] + v) % o.P
+            n[i] = (n[i] - r * v) % o.P
+        c = n
+    return c
+
+
+def horner(c, x):
+    acc = 0
+    for v in reversed(c):
+        acc = (acc * x + v) % o.P
+    return acc
+
+
+@pytest.mark.parametrize("log_m", [1, 3, 6])
+def test_vanishing_polynomial_vs_product(dvp, log_m):
+    """compute_vanishing_polynomial (src/ec_fft.rs:241-282) == prod (X - s_i), the reference's own test
+    (src/ec_fft.rs:820-880); barycentric weights == 1 / Z'(s_i) (src/ec_fft.rs:284-335)"""
+    t = dvp.ec_fft.FFTree(2 << log_m)
+    d, d2 = (from_limbs(x) for x in t.get_both_domains())
+    for which, dom, other in ((0, d, d2), (1, d2, d)):
+        z = from_limbs(dvp.ec_fft.compute_vanishing_polynomial(t, which))
+        assert z == poly_from_roots(dom)
+        bar, zinv = (from_limbs(x) for x in t.domain_tables(which))
+        dz = [(i * c) % o.P for i, c in enumerate(z)][1:]
+        assert bar == [pow(horner(dz, s), o.P - 2, o.P) for s in dom]
+        assert zinv == [pow(horner(z, s), o.P - 2, o.P) for s in other]
+    t.close()
+
+
+def test_vanishing_polynomial_2_12_properties(dvp):
+    m = 1 << 12
+    t = dvp.ec_fft.FFTree(2 * m)
+    rnd = random.Random(12)
+    for which in (0, 1):
+        z = dvp.ec_fft.compute_vanishing_polynomial(t, which)  # monic / degree checked inside
+        zi = from_limbs(z)
+        for _ in range(3):
+            x = rnd.randrange(o.P)
+            assert horner(zi, x) == t.vanish_at(which, x)
+        # evaluate_vanishing_poly_at_domain (src/ec_fft.rs:407-419): zero on its own domain via enter on the 2m tree
+        co = np.zeros((2 * m, 4), dtype=np.uint64)
+        co[: m + 1] = z
+        ev = t.enter(co)
+        assert not ev[which::2].any()
+        _, zinv = t.domain_tables(which)
+        assert np.array_equal(dvp.fr.mul(ev[(1 - which)::2], zinv), to_limbs([1] * m))
+    t.close()
+
+
+def py_dump(rows, coeffs):
+    out = [struct.pack("<I", len(coeffs))] + [int(c).to_bytes(32, "big") for c in coeffs] + [struct.pack("<I", len(rows))]
+    for l, r, oo in rows:
+        out.append(struct.pack("<III", len(l), len(r), len(oo)))
+        for part in (l, r, oo):
+            for w, c in part:
+                out.append(struct.pack("<II", w, c))
+    return b"".join(out)
+
+
+def test_toy_cache_dir_end_to_end(dvp, tmp_path):
+    """test_dvsnark_prover_over_toy_r1cs (src/dvsnark_test.rs:131-180) through files: dump -> verifier_runs_setup
+    (writes the SRS) -> Proof::prove(cache_dir, public, private) -> verify; bytes equal the golden toy proof."""
+    A, g = dvp.artifacts, dvp.gnark_r1cs
+    toy = VEC["toy"]
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    (cache / A.R1CS_CONSTRAINTS_FILE).write_bytes(py_dump(g.TOY_ROWS, g.TOY_COEFFS))
+    td = dvp.srs.Trapdoor(*(int(x, 16) for x in toy["trapdoor"]))
+    inst, pv = dvp.srs.verifier_runs_setup_cache_dir(td, cache, 2)
+    assert inst.num_constraints == 8
+    for name, n in zip(A.SRS_FILES, (8, 8, 8, 8, 16)):
+        raw = (cache / name).read_bytes()
+        assert struct.unpack("<Q", raw[:8])[0] == n and len(raw) == 8 + 30 * n
+    for name, n in ((A.Z_POLY, 9), (A.Z_POLYD, 9), (A.BAR_WTS, 8), (A.BAR_WTSD, 8), (A.Z_VALS2_INV, 8), (A.Z_VALS2D_INV, 8)):
+        assert len((cache / name).read_bytes()) == 8 + 29 * n
+    # the precompute files hold what the oracle's brute-force setup computes
+    tree = o.FFTree(4)
+    tabs = o.domain_tables(tree) if hasattr(o, "domain_tables") else None
+    if tabs:
+        assert from_limbs(dvp.io_utils.read_fr_vec_from_file(cache / A.BAR_WTS)) == tabs["bar_wts"]
+        assert from_limbs(dvp.io_utils.read_fr_vec_from_file(cache / A.Z_VALS2_INV)) == tabs["z_vals2inv"]
+    proof = dvp.proving.Proof.prove(cache, g.TOY_PUBLIC, g.TOY_PRIVATE)
+    assert proof.commit_p.hex() == toy["commit_p"] and proof.kzg_k.hex() == toy["kzg_k"]
+    assert proof == pv.prove(g.TOY_PUBLIC, g.TOY_PRIVATE)
+    assert dvp.srs.verify(td, g.TOY_PUBLIC, proof)
+    # second call reuses the opened prover; an unsatisfied witness is reported with its row
+    assert dvp.proving.Proof.prove(cache, g.TOY_PUBLIC, g.TOY_PRIVATE) == proof
+    bad = list(g.TOY_PRIVATE)
+    bad[3] += 1
+    with pytest.raises(dvp.DvpError) as e:
+        dvp.proving.Proof.prove(cache, g.TOY_PUBLIC, bad)
+    assert e.value.status == -3 and e.value.index == 2
+    # prover_prepares_precomputes regenerates the same files from z_poly alone, and validates z_poly
+    before = {n: (cache / n).read_bytes() for n in (A.BAR_WTS, A.Z_VALS2_INV)}
+    for n in before:
+        os.remove(cache / n)
+    dvp.proving.prover_prepares_precomputes(cache, validate_precompute=True)
+    assert {n: (cache / n).read_bytes() for n in before} == before
+    z = dvp.io_utils.read_fr_vec_from_file(cache / A.Z_POLY)
+    z[0, 0] ^= 1
+    dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, z)
+    with pytest.raises(ValueError):
+        dvp.proving.prover_prepares_precomputes(cache, validate_precompute=True)
+    # a corrupted SRS point is refused at load time (assert!(valid), src/io_utils.rs:223)
+    dvp.proving.release_cache_dir(cache)
+    raw = bytearray((cache / A.SRS_G_Q).read_bytes())
+    good = bytes(raw)
+    hit = False
+    for probe in range(256):  # find a byte value that makes point 3 undecodable
+        raw[8 + 30 * 3 + 1] = probe
+        (cache / A.SRS_G_Q).write_bytes(bytes(raw))
+        try:
+            dvp.proving.Proof.prove(cache, g.TOY_PUBLIC, g.TOY_PRIVATE)
+            dvp.proving.release_cache_dir(cache)
+        except dvp.DvpError as err:
+            assert err.status == -2 and err.index == 3
+            hit = True
+            break
+    assert hit
+    (cache / A.SRS_G_Q).write_bytes(good)
+    assert dvp.proving.Proof.prove(cache, g.TOY_PUBLIC, g.TOY_PRIVATE) == proof
+    dvp.proving.release_cache_dir()
+    pv.close()
+
+
+def test_sparse_cache_dir_with_witness_file(dvp, tmp_path):
+    """BASELINE config #5 stand-in at 2^12: SP1-format dump + witness file in, proof out, verifier accepts; the
+    Horner and the extend route for i(X) on D' give the same bytes."""
+    A, g = dvp.artifacts, dvp.gnark_r1cs
+    inst0, pub, prv = g.synthetic_sparse(12)
+    cache = tmp_path / "c5"
+    cache.mkdir()
+    inst0.write_dump_file(cache / A.R1CS_CONSTRAINTS_FILE)
+    g.write_witness_to_file(cache / A.R1CS_WITNESS_FILE, [1] + pub + prv)
+    rnd = random.Random(5)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    inst, pv = dvp.srs.verifier_runs_setup_cache_dir(td, cache, len(pub), write_precomputes=False)
+    assert inst.n_rows == inst0.n_rows and inst.num_constraints == 1 << 12
+    w = g.load_witness_from_file(cache / A.R1CS_WITNESS_FILE)
+    assert from_limbs(w[:1]) == [1]
+    wpub, wprv = w[1:1 + len(pub)], w[1 + len(pub):]
+    # the dump knows wires only up to the highest one used; g_m has that many entries and so must the witness
+    n_wires = struct.unpack("<Q", (cache / A.SRS_G_M).read_bytes()[:8])[0]
+    assert n_wires == inst.n_wires <= w.shape[0]
+    wprv = wprv[: n_wires - 1 - len(pub)]
+    proof = dvp.proving.Proof.prove(cache, wpub, wprv)
+    assert dvp.srs.verify(td, pub, proof)
+    dvp.proving.release_cache_dir(cache)
+    os.environ["DVP_HORNER_MAX_PUB"] = "0"
+    try:
+        assert dvp.proving.Proof.prove(cache, wpub, wprv) == proof
+    finally:
+        del os.environ["DVP_HORNER_MAX_PUB"]
+        dvp.proving.release_cache_dir()
+    # wrong witness length: |assignment| != |g_m| (assert_eq!, src/curve.rs:142)
+    with pytest.raises(dvp.DvpError) as e:
+        dvp.proving.Proof.prove(cache, wpub, wprv[:-1])
+    assert e.value.status == -1
+    dvp.proving.release_cache_dir()
+    pv.close()

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-phase time of ONE rank of a W-way sharded prove, measured on a single GPU (projection of bench.py --gpus W:
+the ranks are symmetric, the exchange is one 80-byte all-gather per MSM).  python tools/shard_profile.py [log_m]"""
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+dvp = importlib.import_module("dv-pari_amd")
+log_m = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda", 0)
+inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
+td = dvp.srs.Trapdoor(0x1234567 + (1 << 200), 0x7654321 + (1 << 190), 0xABCDEF + (1 << 180))
+pv = dvp.proving.Prover(inst)
+pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+assignment = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
+be = dvp.distributed.GpuBackend(pv, dev)
+
+
+def timed(f):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = f()
+    torch.cuda.synchronize()
+    return r, (time.perf_counter() - t) * 1e3
+
+
+for world in (1, 2, 4, 8):
+    acc = None
+    for rep in range(4):
+        ph = {}
+        _, ph["begin"] = timed(lambda: be.begin(assignment))
+        lo, hi = dvp.distributed.shard_range(be.msm_size(0), 0, world)
+        _, ph["msmA_part"] = timed(lambda: be.msm_partial(0, lo, hi))
+        full, _ = timed(lambda: be.msm_partial(0, 0, be.msm_size(0)).clone())
+        _, ph["challenge"] = timed(lambda: be.challenge(full))
+        lo, hi = dvp.distributed.shard_range(be.msm_size(1), 0, world)
+        _, ph["msmB_part"] = timed(lambda: be.msm_partial(1, lo, hi))
+        full, _ = timed(lambda: be.msm_partial(1, 0, be.msm_size(1)).clone())
+        _, ph["finish"] = timed(lambda: be.finish(full))
+        if rep:
+            acc = ph if acc is None else {k: min(acc[k], v) for k, v in ph.items()}
+    tot = sum(acc.values())
+    print(f"world {world}: " + "  ".join(f"{k} {v:6.2f}" for k, v in acc.items()) + f"   sum {tot:6.2f} ms  ({(1 << log_m) / tot / 1e3:.1f} M constraints/s projected)", flush=True)
