@@ -66,16 +66,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a one-GPU box (never set by the driver): DVP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # DVP_DIST_BACKEND=gloo replaces RCCL, so the sharded path can be exercised end to end without a second GPU
+    share_gpu = os.environ.get("DVP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("DVP_DIST_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     dvp = importlib.import_module("dv-pari_amd")
-    dvp.check(dvp.lib.dvp_set_device(local_rank), "dvp_set_device")
+    dvp.check(dvp.lib.dvp_set_device(dev_index), "dvp_set_device")
     log_m = args.log_m
     m = 1 << log_m
 
@@ -93,6 +101,11 @@ def main():
 
     def step():
         return dvp.distributed.prove_sharded(backend, assignment)
+
+    if world > 1:  # communicator set-up is not part of a proof: one throw-away exchange even with --warmup 0
+        probe = torch.zeros(10, dtype=torch.int64, device=dev)
+        dist.all_gather([torch.empty_like(probe) for _ in range(world)], probe)
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         proof = step()

@@ -30,7 +30,7 @@ def timed(f):
     return r, (time.perf_counter() - t) * 1e3
 
 
-for world in (1, 2, 4, 8):
+for world in [int(x) for x in os.environ.get("SHARD_WORLDS", "1,2,4,8").split(",")]:
     acc = None
     for rep in range(4):
         ph = {}
