@@ -228,6 +228,70 @@ GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLds& c) {
   return gf_mul_tab(a, c);
 }
 
+// ---- quad-cooperative product (latency-bound stages: deep merge levels, the Frobenius tail) ------------------
+// The 4 lanes of a DPP quad hold the SAME operands and compute ONE product together: lane r scans only the comb
+// digits k = 3r..3r+2 of every word of a (24 table lookups instead of 88), shifts its partial sum by 9r bits, and the
+// quad XOR-reduces the four partial sums with two v_xor_dpp quad_perm steps per word.  ~0.4x the instructions of
+// gf_mul_tab on the critical path; all four lanes end up with the full product.  Every lane of the quad must be
+// active (callers retire whole quads).  Each lane still keeps its own table copy, so the LDS layout is unchanged.
+struct GfLdsQ {
+  GfLds l;
+  uint32_t r;  // lane within the quad
+};
+GF_DEV GfLdsQ gf_ldsq_init(char* lds_base) {
+  GfLdsQ q;
+  q.l = gf_lds_init(lds_base);
+  q.r = threadIdx.x & 3u;
+  return q;
+}
+GF_DEV uint32_t gf_quad_xor(uint32_t x) {
+  x ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  x ^= (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  return x;
+}
+GF_DEV void gf_tab_build(const GfLdsQ& c, const Gf& b) { gf_tab_build(c.l, b); }
+GF_DEV Gf gf_mul_tab(const Gf& a, const GfLdsQ& c) {
+  uint32_t acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+  for (int t = 2; t >= 0; --t) {
+    if (t != 2) gf_acc_shl3(acc);
+    const uint32_t bit = 9u * c.r + 3u * (uint32_t)t;          // 3k; k = 11 (lane 3, t = 2) does not exist
+    const uint32_t mask = (t == 2 && c.r == 3u) ? 0u : 0x1C00u;
+    gf_u32x4 lo[8], hi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      uint32_t addr = (((a.w[j] >> (bit & 31u)) << 10) & mask) | c.l.lane_base;
+      lo[j] = *(const gf_u32x4*)(c.l.lds + addr);
+      hi[j] = *(const gf_u32x4*)(c.l.lds + addr + 8192);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[j + 0] ^= lo[j].x; acc[j + 1] ^= lo[j].y; acc[j + 2] ^= lo[j].z; acc[j + 3] ^= lo[j].w;
+      acc[j + 4] ^= hi[j].x; acc[j + 5] ^= hi[j].y; acc[j + 6] ^= hi[j].z;
+      if (j + 7 < 15) acc[j + 7] ^= hi[j].w;
+    }
+  }
+  // partial sum of lane r sits 9r bits up
+  const uint32_t sh = 32u - 9u * c.r;
+  const bool r0 = c.r == 0u;
+#pragma unroll
+  for (int i = 14; i > 0; --i) {
+    uint32_t v = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], sh);
+    acc[i] = r0 ? acc[i] : v;
+  }
+  acc[0] = r0 ? acc[0] : (acc[0] << (9u * c.r));
+#pragma unroll
+  for (int i = 0; i < 15; ++i) acc[i] = gf_quad_xor(acc[i]);
+  return gf_reduce16(acc);
+}
+GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLdsQ& c) {
+  gf_tab_build(c.l, b);
+  return gf_mul_tab(a, c);
+}
+
 // 16 bits -> 32 bits with zeros interleaved
 GF_DEV uint32_t gf_spread16(uint32_t x) {
   x = (x | (x << 8)) & 0x00FF00FFu;
@@ -284,7 +348,8 @@ GF_DEV Gf gf_sqr_tab(const Gf& a, const Gf* __restrict__ T) {
   return r;
 }
 // a^(2^233-2) with table-driven runs; products through the LDS multiplier.  a == 0 -> 0.
-GF_DEV Gf gf_inv_fast(const Gf& a, const GfSqrTables& T, const GfLds& L) {
+template <class LT>
+GF_DEV Gf gf_inv_fast(const Gf& a, const GfSqrTables& T, const LT& L) {
   Gf b1 = a;
   gf_tab_build(L, b1);
   Gf b2 = gf_mul_tab(gf_sqr(b1), L);

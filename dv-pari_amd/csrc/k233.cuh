@@ -107,7 +107,8 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q) {
 // ---- LDS-comb flavours (hot kernels): same formulas, products through the LDS table multiplier
 // (gf233.cuh), with the table of a repeated operand built once: 6 builds for the 8 products of the mixed
 // addition (Z1 and C are used twice), 9 builds for the 13 products of the full addition. ----------------
-GF_DEV Ld ld_dbl(const Ld& p, const GfLds& L) {
+template <class LT>
+GF_DEV Ld ld_dbl(const Ld& p, const LT& L) {
   Gf z1s = gf_sqr(p.Z), x1s = gf_sqr(p.X);
   Ld r;
   r.Z = gf_mul(x1s, z1s, L);
@@ -159,7 +160,9 @@ GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const GfLds& L) {
   return r;
 }
 
-GF_DEV void ld_add_ip(Ld& p, const Ld& q, const GfLds& L) {
+// LT = GfLds (one lane per addition) or GfLdsQ (the four lanes of a quad compute one addition together)
+template <class LT>
+GF_DEV void ld_add_ip(Ld& p, const Ld& q, const LT& L) {
   if (ld_is_inf(q)) return;
   if (ld_is_inf(p)) {
     p.X = q.X; p.Y = q.Y; p.Z = q.Z;
@@ -200,7 +203,8 @@ GF_DEV void ld_add_ip(Ld& p, const Ld& q, const GfLds& L) {
   p.X = X3;
   p.Z = Z3;
 }
-GF_DEV Ld ld_add(const Ld& p, const Ld& q, const GfLds& L) {
+template <class LT>
+GF_DEV Ld ld_add(const Ld& p, const Ld& q, const LT& L) {
   Ld r = p;
   ld_add_ip(r, q, L);
   return r;

@@ -34,7 +34,7 @@ namespace dvp {
 // Scalars >= r are rejected (flag); points flagged infinite contribute nothing.
 template <class DIGIT>
 __global__ void __launch_bounds__(256)
-k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W,
+k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow,
          DIGIT* __restrict__ digits, unsigned long long* __restrict__ err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -53,15 +53,17 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
     for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
   }
   // expansion: u = r0 & 1; r0 -= u; h = r0 >> 1 (arithmetic); (r0, r1) = (r1 - h, -h)
+  // windows 0 .. n_narrow-1 are c-1 digits wide, the rest c (fixed-base mode evens the windows out, see MsmFixedCtx)
   uint32_t dig = 0;
-  int bitpos = 0, w = 0;
-  for (int step = 0; step < W * c; ++step) {
+  int bitpos = 0, w = 0, width = n_narrow > 0 ? c - 1 : c;
+  for (int step = 0; step < W * c - n_narrow; ++step) {
     dig |= tau_step(r0, r1) << bitpos;
-    if (++bitpos == c) {
+    if (++bitpos == width) {
       digits[(size_t)w * n + i] = (DIGIT)dig;
       dig = 0;
       bitpos = 0;
       ++w;
+      width = w < n_narrow ? c - 1 : c;
     }
   }
   uint32_t rest = 0;
@@ -346,16 +348,19 @@ k_scatter_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ 
   for (uint32_t j = lo_e + threadIdx.x; j < hi_e; j += SORT_TPB) items[atomicAdd(&lds_cur[plo[j]], 1u)] = pid[j];
 }
 
-// pre-rotated base table for the fixed-base mode: T[w][i] = tau^(c w)(P_i)
-__global__ void __launch_bounds__(256) k_frob_table(const Aff* __restrict__ bases, uint32_t n, int FX_C, int FX_W, Aff* __restrict__ table) {
+// pre-rotated base table for the fixed-base mode: T[w][i] = tau^(o_w)(P_i), o_w = first digit of window w
+// (windows 0 .. n_narrow-1 are c-1 digits wide, the rest c)
+__global__ void __launch_bounds__(256)
+k_frob_table(const Aff* __restrict__ bases, uint32_t n, int FX_C, int FX_W, int n_narrow, Aff* __restrict__ table) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Aff p = bases[i];
   table[i] = p;
 #pragma unroll 1
   for (int w = 1; w < FX_W; ++w) {
-    p.x = gf_sqr_n(p.x, FX_C);
-    p.y = gf_sqr_n(p.y, FX_C);
+    int width = (w - 1) < n_narrow ? FX_C - 1 : FX_C;
+    p.x = gf_sqr_n(p.x, width);
+    p.y = gf_sqr_n(p.y, width);
     table[(size_t)w * n + i] = p;
   }
 }
@@ -363,6 +368,7 @@ __global__ void __launch_bounds__(256) k_frob_table(const Aff* __restrict__ base
 // EC kernels on the LDS multiplier: 256-thread blocks, 4 x 16 KB of tables (512-thread blocks measured 5% slower end to end)
 constexpr int EC_TPB = 256;
 constexpr unsigned EC_LDS = (EC_TPB / 64) * GF_LDS_BYTES_PER_WAVE;
+constexpr uint32_t MERGE_QUAD_MAX = 16384;  // additions per level up to which 4 lanes per addition win (measured: 35 us vs 41 us at 16384)
 
 // ---- segmented reduction by fan-in K ----------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ntask(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ ntask, uint32_t nkeys, uint32_t K) {
@@ -611,16 +617,29 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 
 // ---- pruned sum-over-subsets merge (see file header, step 4) ---------------------------------------
 // level j: blocks of 2^(j+1) buckets; slot s <= j: A[base+s] += A[base+2^j+s]; slot j+1 <- T_right
+// QUAD: the deep levels have far fewer additions than the chip has lanes and are pure latency; there the four lanes
+// of a quad share one addition (gf233.cuh, quad-cooperative product), 2.2x shorter per level.
+template <bool QUAD>
 __global__ void __launch_bounds__(EC_TPB, 2) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (QUAD) tid >>= 2;
   if (tid >= total) return;
   uint32_t blk = tid / (uint32_t)(j + 1), s = tid - blk * (uint32_t)(j + 1);
   size_t base = (size_t)blk << (j + 1);
   Ld l = A[base + s], r = A[base + ((size_t)1 << j) + s];
-  if (s == 0 && j >= 2) A[base + 1 + j] = r;
-  A[base + s] = ld_add(l, r, L);
+  if (QUAD) {
+    GfLdsQ L = gf_ldsq_init(lds_raw);
+    ld_add_ip(l, r, L);
+    if (L.r == 0) {
+      if (s == 0 && j >= 2) A[base + 1 + j] = r;
+      A[base + s] = l;
+    }
+  } else {
+    GfLds L = gf_lds_init(lds_raw);
+    if (s == 0 && j >= 2) A[base + 1 + j] = r;
+    A[base + s] = ld_add(l, r, L);
+  }
 }
 
 // E[w*c+t] = tau^(w*c+t)( A[w*2^c + 1 + t] )
@@ -632,20 +651,21 @@ __global__ void __launch_bounds__(64) k_frob(const Ld* __restrict__ A, int c, in
 }
 
 // out[i] = in[2i] + in[2i+1]   (in[count] treated as infinity when count is odd)
+// (one addition per quad of lanes, see k_merge<true>)
 __global__ void __launch_bounds__(64) k_pair_add(const Ld* __restrict__ in, uint32_t count, Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  GfLdsQ L = gf_ldsq_init(lds_raw);
+  uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   if (2 * i >= count) return;
   Ld a = in[2 * i];
   if (2 * i + 1 < count) ld_add_ip(a, in[2 * i + 1], L);
-  out[i] = a;
+  if (L.r == 0) out[i] = a;
 }
 
 __global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSqrTables T, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  GfLdsQ L = gf_ldsq_init(lds_raw);
+  if (threadIdx.x >= 4 || blockIdx.x != 0) return;  // one quad: the inversion's 11 products are a serial chain
   Aff a;
   Ld p = in[0];
   bool fin = !ld_is_inf(p);
@@ -657,6 +677,7 @@ __global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSq
     a.x = gf_mul_tab(p.X, L);
     a.y = gf_mul(p.Y, gf_sqr(zi), L);
   }
+  if (threadIdx.x != 0) return;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     out_xy[k] = a.x.w[k];
@@ -697,10 +718,22 @@ struct MsmPlan {
 };
 
 static MsmPlan msm_plan(size_t n, const struct MsmFixedCtx* fx);
+// Windows of the fixed-base mode.  tau-adic expansions of reduced scalars are at most 234 digits long (measured: 229-233
+// typical) and their top 3-4 digits are mostly zero.  A uniform split leaves a short top window (234 mod c digits) whose
+// entries pile into a few hundred buckets of the shared set -- n/2^7 entries per bucket for c = 16 -- and the reducer
+// then runs 15-long serial chains.  So the 234 digits are split into W_main = ceil(234/c) windows whose widths differ by
+// at most one (the n_narrow low windows are c-1 digits wide, the entropy-poor top windows c), plus one overflow window
+// for digits >= 234 that exists only for completeness (the recode flags anything longer than it covers).
 struct MsmFixedCtx {
   Aff* table = nullptr;  // [W][n_total]
   uint32_t n_total = 0;
-  int c = FX_C_MAX, W = TAU_DIGITS / FX_C_MAX;
+  int c = FX_C_MAX, W = TAU_DIGITS / FX_C_MAX, n_narrow = 0;
+  void set_c(int cc) {
+    c = cc;
+    int w_main = (234 + cc - 1) / cc;
+    n_narrow = w_main * cc - 234;
+    W = w_main + 1;
+  }
   FxBits bits() const { FxBits b; b.lo = c < FX_LO_MAX ? c : FX_LO_MAX; b.hi = c - b.lo; return b; }
 };
 static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
@@ -760,7 +793,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_hist_local2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge,
+      const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
                           (const void*)k_affine_round<true>, (const void*)k_affine_round<false>};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS);
@@ -839,10 +872,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
   if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
-                       (uint32_t)n, p.c, p.W, digits32, err);
+                       (uint32_t)n, p.c, p.W, fx->n_narrow, digits32, err);
   else
     hipLaunchKernelGGL((k_recode<uint16_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
-                       (uint32_t)n, p.c, p.W, digits, err);
+                       (uint32_t)n, p.c, p.W, 0, digits, err);
   if (fx) {
     const uint32_t gmax = fx_nblk + FX_NP;  // upper bound on the number of level-2 chunks
     hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
@@ -871,9 +904,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipStreamSynchronize(st));
   size_t aff_min = (size_t)1 << 20;
   if (const char* e = getenv("DVP_MSM_AFF_MIN")) aff_min = (size_t)atoll(e);
+  const size_t e_est = fx ? (size_t)n * (size_t)(p.W - 1) : p.e_max;  // the overflow window of the fixed-base split is empty
   int ra = 0;
   if (affine_mode)
-    while (((uint64_t)1 << ra) < max_cnt && (p.e_max >> (ra + 1)) >= aff_min) ++ra;
+    while (((uint64_t)1 << ra) < max_cnt && (e_est >> (ra + 1)) >= aff_min) ++ra;
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -937,7 +971,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   for (int j = 0; j < p.c; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
-    hipLaunchKernelGGL(k_merge, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
+    if (total <= MERGE_QUAD_MAX)
+      hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
+    else
+      hipLaunchKernelGGL(k_merge<false>, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
   }
   const int w_tail = fx ? 1 : p.W;  // fixed-base mode has a single bucket set
   uint32_t cntT = (uint32_t)(w_tail * p.c);
@@ -946,7 +983,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, ta);
   while (cntT > 1) {
     uint32_t half = (cntT + 1) / 2;
-    hipLaunchKernelGGL(k_pair_add, dim3(cdiv(half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
+    hipLaunchKernelGGL(k_pair_add, dim3(cdiv(4 * half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
     Ld* t = ta; ta = tb; tb = t;
     cntT = half;
   }
@@ -975,19 +1012,17 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
-  // tau-adic expansions are ~234 digits long (240 are allocated), so the last window of a 240/c split is
-  // often almost empty: count windows on 234 digits.  c = 19 is skipped: it measured 7% slower than both
-  // neighbours on MI355X at 2^21-2^22 points (c = 18: 34.5 ms, 19: 37.9 ms, 20: 35.2 ms per 2^20 proof).
   double best = 1e300;
+  int best_c = 8;
   for (int cc = 8; cc <= FX_C_MAX; ++cc) {
-    if (cc == 19) continue;
-    int Weff = (234 + cc - 1) / cc;
-    double cost = (double)Weff * (double)range_hint * 6.1 + 40.0 * (double)(1u << cc);
-    if (cost < best) { best = cost; c->c = cc; c->W = (TAU_DIGITS + cc - 1) / cc; }
+    int w_main = (234 + cc - 1) / cc;
+    double cost = (double)w_main * (double)range_hint * 6.1 + 40.0 * (double)(1u << cc);
+    if (cost < best) { best = cost; best_c = cc; }
   }
-  if (const char* e = getenv("DVP_MSM_FIXED_C")) { int cc = atoi(e); if (cc >= 4 && cc <= FX_C_MAX) { c->c = cc; c->W = (TAU_DIGITS + cc - 1) / cc; } }
+  if (const char* e = getenv("DVP_MSM_FIXED_C")) { int cc = atoi(e); if (cc >= 8 && cc <= FX_C_MAX) best_c = cc; }
+  c->set_c(best_c);
   DVP_HIP(hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff)));
-  hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->table);
+  hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipDeviceSynchronize());
   *out = c;
