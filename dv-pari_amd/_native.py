@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvpari_hip.so")
+LIB_PATH = os.environ.get("DVP_LIB") or os.path.join(_HERE, "libdvpari_hip.so")  # DVP_LIB: A/B-test another build
 
 # PyTorch-ROCm wheels bundle their own libamdhip64; if this library pulls in /opt/rocm's copy first, torch
 # later finds "No HIP GPUs".  Loading torch first makes both share one HIP runtime (torch is plumbing here:

@@ -295,6 +295,7 @@ int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, 
   // structure; the BATCH template only buys matrix reuse when the batch is small and n is large.
   auto pass = [&](const Fr* mats, int lh) {
     if (batch == 4) launch_bfly<4>(data, mats, lh, n, st);
+    else if (batch == 3) launch_bfly<3>(data, mats, lh, n, st);
     else if (batch == 2) launch_bfly<2>(data, mats, lh, n, st);
     else launch_bfly<1>(data, mats, lh, (uint32_t)((size_t)batch * n), st);
   };

@@ -493,16 +493,45 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
   const uint32_t nthr = (total + AFF_B - 1) / AFF_B;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nthr) return;
-  // pre-pass: slot -> (first input index, has-partner flag in bit 31); 0xffffffff = no slot
-#pragma unroll 1
-  for (int k = 0; k < AFF_B; ++k) {
-    uint32_t s = (uint32_t)k * nthr + tid, d = 0xffffffffu;
-    if (s < total) {
-      uint32_t key = find_key(ooff, nkeys, s);
-      uint32_t j = s - ooff[key];
-      d = (off[key] + 2 * j) | ((2 * j + 1 < cnt[key]) ? 0x80000000u : 0u);
+  // pre-pass: slot -> (first input index, has-partner flag in bit 31); 0xffffffff = no slot.  The AFF_B binary
+  // searches over the key offsets advance in lockstep, so each step has AFF_B independent loads in flight instead of
+  // one (18 dependent L2 round trips per slot, one slot after the other, used to cost as much as the additions).
+  {
+    uint32_t lo[AFF_B], hi[AFF_B], sv[AFF_B];
+#pragma unroll
+    for (int k = 0; k < AFF_B; ++k) {
+      sv[k] = min((uint32_t)k * nthr + tid, total - 1);
+      lo[k] = 0;
+      hi[k] = nkeys;  // invariant: ooff[lo] <= s < ooff[hi]
     }
-    desc[k * EC_TPB] = d;
+    const int steps = nkeys > 1 ? 32 - __builtin_clz(nkeys - 1) : 0;
+#pragma unroll 1
+    for (int it = 0; it < steps; ++it) {
+      uint32_t v[AFF_B];
+#pragma unroll
+      for (int k = 0; k < AFF_B; ++k) v[k] = ooff[(lo[k] + hi[k]) >> 1];
+#pragma unroll
+      for (int k = 0; k < AFF_B; ++k) {
+        uint32_t mid = (lo[k] + hi[k]) >> 1;  // hi - lo == 1 gives mid == lo: a no-op step
+        if (v[k] <= sv[k]) lo[k] = mid; else hi[k] = mid;
+      }
+    }
+    uint32_t o0[AFF_B], o1[AFF_B], cn[AFF_B];
+#pragma unroll
+    for (int k = 0; k < AFF_B; ++k) {
+      o0[k] = ooff[lo[k]];
+      o1[k] = off[lo[k]];
+      cn[k] = cnt[lo[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < AFF_B; ++k) {
+      uint32_t sk = (uint32_t)k * nthr + tid, d = 0xffffffffu;
+      if (sk < total) {
+        uint32_t j = sk - o0[k];
+        d = (o1[k] + 2 * j) | ((2 * j + 1 < cn[k]) ? 0x80000000u : 0u);
+      }
+      desc[k * EC_TPB] = d;
+    }
   }
   const Gf one = gf_one();
   // pass 1: denominators and running product (x-coordinates only; y is touched when x1 == x2)
