@@ -117,8 +117,11 @@ __global__ void __launch_bounds__(256) k_next_layer(const Fr* __restrict__ cur, 
 //   decompose  (from leaves 2i+src, 2i+src+nd):  inverse of [[v0, s0 v0],[v1, s1 v1]]
 //   recombine  (from leaves 2i+dst, 2i+dst+nd):            [[v0, s0 v0],[v1, s1 v1]]
 // with v = (s - x0)^(nd/2 - 1).
+// Matrix entries are consumed only by fr_dot2, so they are stored pre-sliced into 29-bit limbs (same 32 bytes).
+__device__ __forceinline__ Fr29 mat_store(const Fr& a) { return fr29_from(a); }
+
 __global__ void __launch_bounds__(256) k_build_mats(const Fr* __restrict__ Ld, int sl, uint32_t nd, Fr x0, int src, int dst,
-                             Fr* __restrict__ dec, Fr* __restrict__ rec) {
+                             Fr29* __restrict__ dec, Fr29* __restrict__ rec) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t h = nd >> 1;
   if (i >= h) return;
@@ -131,20 +134,20 @@ __global__ void __launch_bounds__(256) k_build_mats(const Fr* __restrict__ Ld, i
     Fr det = fr_mul(fr_mul(v0, v1), fr_sub(s1, s0));
     Fr inv = fr_inv(det);
     Fr iv0 = fr_mul(inv, v0), iv1 = fr_mul(inv, v1);
-    dec[4 * (size_t)i + 0] = fr_mul(s1, iv1);
-    dec[4 * (size_t)i + 1] = fr_neg(fr_mul(s0, iv0));
-    dec[4 * (size_t)i + 2] = fr_neg(iv1);
-    dec[4 * (size_t)i + 3] = iv0;
+    dec[4 * (size_t)i + 0] = mat_store(fr_mul(s1, iv1));
+    dec[4 * (size_t)i + 1] = mat_store(fr_neg(fr_mul(s0, iv0)));
+    dec[4 * (size_t)i + 2] = mat_store(fr_neg(iv1));
+    dec[4 * (size_t)i + 3] = mat_store(iv0);
   }
   {
     Fr s0 = Ld[(size_t)(2 * i + dst) << sl];
     Fr s1 = Ld[(size_t)(2 * i + dst + nd) << sl];
     Fr v0 = fr_pow_u64(fr_sub(s0, x0), e);
     Fr v1 = fr_pow_u64(fr_sub(s1, x0), e);
-    rec[4 * (size_t)i + 0] = v0;
-    rec[4 * (size_t)i + 1] = fr_mul(s0, v0);
-    rec[4 * (size_t)i + 2] = v1;
-    rec[4 * (size_t)i + 3] = fr_mul(s1, v1);
+    rec[4 * (size_t)i + 0] = mat_store(v0);
+    rec[4 * (size_t)i + 1] = mat_store(fr_mul(s0, v0));
+    rec[4 * (size_t)i + 2] = mat_store(v1);
+    rec[4 * (size_t)i + 3] = mat_store(fr_mul(s1, v1));
   }
 }
 
@@ -152,21 +155,21 @@ __global__ void __launch_bounds__(256) k_build_mats(const Fr* __restrict__ Ld, i
 // inside each block uses matrix i of this layer.  One thread = one pair for all batch vectors, so
 // the 128-byte matrix is read once per pair and reused `batch` times.
 template <int BATCH>
-__global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const Fr* __restrict__ mats, int lh, uint32_t n) {
+__global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const Fr29* __restrict__ mats, int lh, uint32_t n) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (n >> 1)) return;
   uint32_t h = 1u << lh;
   uint32_t i = tid & (h - 1);
   uint32_t i0 = ((tid >> lh) << (lh + 1)) | i;
   uint32_t i1 = i0 + h;
-  const Fr* m = mats + 4 * (size_t)i;
-  Fr m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
+  const Fr29* m = mats + 4 * (size_t)i;
+  Fr29 m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
 #pragma unroll
   for (int b = 0; b < BATCH; ++b) {
     Fr* v = data + (size_t)b * n;
-    Fr e0 = v[i0], e1 = v[i1];
-    v[i0] = fr_add(fr_mul(m00, e0), fr_mul(m01, e1));
-    v[i1] = fr_add(fr_mul(m10, e0), fr_mul(m11, e1));
+    Fr29 e0 = fr29_from(v[i0]), e1 = fr29_from(v[i1]);
+    v[i0] = fr_dot2(m00, e0, m01, e1);
+    v[i1] = fr_dot2(m10, e0, m11, e1);
   }
 }
 
@@ -178,21 +181,21 @@ __global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const 
 constexpr int FUSE_LOG = 11;
 constexpr uint32_t FUSE_ELEMS = 1u << FUSE_LOG;
 
-__device__ __forceinline__ void lds_bfly(Fr* x, const Fr* __restrict__ mats, int lh, uint32_t pairs) {
+__device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ mats, int lh, uint32_t pairs) {
   const uint32_t h = 1u << lh;
   for (uint32_t q = threadIdx.x; q < pairs; q += blockDim.x) {
     uint32_t i = q & (h - 1);
     uint32_t i0 = ((q >> lh) << (lh + 1)) | i, i1 = i0 + h;
-    const Fr* m = mats + 4 * (size_t)i;
-    Fr e0 = x[i0], e1 = x[i1];
-    x[i0] = fr_add(fr_mul(m[0], e0), fr_mul(m[1], e1));
-    x[i1] = fr_add(fr_mul(m[2], e0), fr_mul(m[3], e1));
+    const Fr29* m = mats + 4 * (size_t)i;
+    Fr29 e0 = fr29_from(x[i0]), e1 = fr29_from(x[i1]);
+    x[i0] = fr_dot2(m[0], e0, m[1], e1);
+    x[i1] = fr_dot2(m[2], e0, m[3], e1);
   }
   __syncthreads();
 }
 
 __global__ void __launch_bounds__(256)
-k_extend_fused(Fr* __restrict__ data, const Fr* __restrict__ dec, const Fr* __restrict__ rec, uint32_t n, int ln, int lb,
+k_extend_fused(Fr* __restrict__ data, const Fr29* __restrict__ dec, const Fr29* __restrict__ rec, uint32_t n, int ln, int lb,
                size_t total) {
   __shared__ Fr x[FUSE_ELEMS];
   const size_t base = (size_t)blockIdx.x * FUSE_ELEMS;
@@ -280,7 +283,7 @@ static int build_matset(dvp_ecfft* c, int sl, int to_even, MatSet** out, hipStre
 }
 
 template <int B>
-static void launch_bfly(Fr* data, const Fr* mats, int lh, uint32_t n, hipStream_t st) {
+static void launch_bfly(Fr* data, const Fr29* mats, int lh, uint32_t n, hipStream_t st) {
   hipLaunchKernelGGL((k_butterfly<B>), dim3(cdiv(n >> 1, TPB)), dim3(TPB), 0, st, data, mats, lh, n);
 }
 
@@ -293,7 +296,7 @@ int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, 
   int ln = 31 - __builtin_clz(n);
   // Blocks are contiguous, so `batch` vectors of n behave like one vector of batch*n for the block
   // structure; the BATCH template only buys matrix reuse when the batch is small and n is large.
-  auto pass = [&](const Fr* mats, int lh) {
+  auto pass = [&](const Fr29* mats, int lh) {
     if (batch == 4) launch_bfly<4>(data, mats, lh, n, st);
     else if (batch == 3) launch_bfly<3>(data, mats, lh, n, st);
     else if (batch == 2) launch_bfly<2>(data, mats, lh, n, st);

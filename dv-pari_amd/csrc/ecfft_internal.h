@@ -8,10 +8,11 @@
 #include "fr.cuh"
 
 using dvp::Fr;
+using dvp::Fr29;
 
 struct MatSet {
-  Fr* dec = nullptr;  // (n-1) x 4 Fr, layer d at offset 4*(n - (n>>d))
-  Fr* rec = nullptr;
+  Fr29* dec = nullptr;  // (n-1) x 4 entries (Montgomery form, pre-sliced for fr_dot2), layer d at offset 4*(n - (n>>d))
+  Fr29* rec = nullptr;
 };
 
 struct dvp_ecfft {

@@ -205,6 +205,55 @@ DVP_HD Fr fr_mul(const Fr& a, const Fr& b) {
   return fr_cond_sub_p(out);
 }
 
+// ---- fused 2-term dot product (the ECFFT butterfly: out = m0*e0 + m1*e1) -------------------------------------------
+// Both schoolbook products share the column accumulators (16 terms of 58 bits + the reduction terms stay below
+// 2^63) and ONE Montgomery reduction serves the sum: 160 limb products instead of 192, no modular addition, and the
+// matrix operand arrives pre-sliced (Fr29) so only the data is re-sliced, once per butterfly.
+struct Fr29 {
+  uint32_t l[8];  // 29-bit limbs of a value < p
+};
+DVP_HD Fr29 fr29_from(const Fr& a) {
+  Fr29 r;
+  fr_to29(a, r.l);
+  return r;
+}
+// (a0*b0 + a1*b1) / R mod p, fully reduced.  T < 2p^2 gives (T + m p)/R < 3p (p/R is a hair above 1/2), hence the two
+// conditional subtractions.
+DVP_HD Fr fr_dot2(const Fr29& a0, const Fr29& b0, const Fr29& a1, const Fr29& b1) {
+  constexpr uint32_t p[8] = DVP_FR_P29_LIMBS;
+  uint32_t m[8], r[8];
+  uint64_t t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      t += (uint64_t)a0.l[j] * b0.l[i - j];
+      t += (uint64_t)a1.l[j] * b1.l[i - j];
+    }
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+    m[i] = ((uint32_t)t * FR_N0_29) & FR_M29;
+    t += (uint64_t)m[i] * p[0];
+    t >>= 29;
+  }
+#pragma unroll
+  for (int i = 8; i < 16; ++i) {
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j) {
+      t += (uint64_t)a0.l[j] * b0.l[i - j];
+      t += (uint64_t)a1.l[j] * b1.l[i - j];
+    }
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j)
+      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+    r[i - 8] = (uint32_t)t & FR_M29;
+    t >>= 29;
+  }
+  r[7] |= (uint32_t)t << 29;  // result < 3p < 2^234: the carry belongs to limb 7
+  return fr_cond_sub_p(fr_cond_sub_p(fr_from29(r)));
+}
+
 DVP_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 DVP_HD Fr fr_to_mont(const Fr& a) { return fr_mul(a, fr_r2()); }
 DVP_HD Fr fr_from_mont(const Fr& a) { return fr_mul(a, fr_one_canon()); }
