@@ -231,6 +231,21 @@ int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipSt
   return read_err(err.as<unsigned long long>(), st, DVP_EDECODE);
 }
 
+// CurvePoint::add over two vectors (src/curve.rs:84-90): out[i] = a[i] + b[i] on the E[r] representative; complete
+// (doubling, inverses and the neutral element are handled), register-only arithmetic -- a convenience entry, not a hot path.
+__global__ void __launch_bounds__(128)
+k_points_add(const Aff* __restrict__ a, const uint8_t* __restrict__ ainf, const Aff* __restrict__ b, const uint8_t* __restrict__ binf,
+             size_t n, Aff* __restrict__ out, uint8_t* __restrict__ oinf) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ld acc = (ainf && ainf[i]) ? ld_infinity() : ld_from_aff(a[i]);
+  if (!(binf && binf[i])) acc = ld_madd(acc, b[i]);
+  Aff r;
+  bool fin = ld_to_aff(acc, &r);
+  out[i] = r;
+  oinf[i] = fin ? 0 : 1;
+}
+
 }  // namespace dvp
 
 using namespace dvp;
@@ -277,6 +292,33 @@ extern "C" int dvp_points_encode(const uint64_t* xy, const uint8_t* inf, size_t 
   }
   DVP_TRY(encode_dev(dp.as<Aff>(), di.as<uint8_t>(), n, de.as<uint8_t>(), 0));
   DVP_HIP(hipMemcpy(out_enc, de.p, n * 30, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+
+extern "C" int dvp_points_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, size_t n,
+                              uint64_t* out_xy, uint8_t* out_inf) {
+  if (!n) return DVP_OK;
+  if (!a_xy || !b_xy || !out_xy || !out_inf) return DVP_EINVAL;
+  DevBuf da, db, dai, dbi, dout, doi;
+  DVP_TRY(da.alloc(n * 64));
+  DVP_TRY(db.alloc(n * 64));
+  DVP_TRY(dout.alloc(n * 64));
+  DVP_TRY(doi.alloc(n));
+  DVP_HIP(hipMemcpy(da.p, a_xy, n * 64, hipMemcpyHostToDevice));
+  DVP_HIP(hipMemcpy(db.p, b_xy, n * 64, hipMemcpyHostToDevice));
+  if (a_inf) {
+    DVP_TRY(dai.alloc(n));
+    DVP_HIP(hipMemcpy(dai.p, a_inf, n, hipMemcpyHostToDevice));
+  }
+  if (b_inf) {
+    DVP_TRY(dbi.alloc(n));
+    DVP_HIP(hipMemcpy(dbi.p, b_inf, n, hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(k_points_add, dim3(cdiv(n, 128)), dim3(128), 0, 0, da.as<Aff>(), dai.as<uint8_t>(), db.as<Aff>(), dbi.as<uint8_t>(), n,
+                     dout.as<Aff>(), doi.as<uint8_t>());
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out_xy, dout.p, n * 64, hipMemcpyDeviceToHost));
+  DVP_HIP(hipMemcpy(out_inf, doi.p, n, hipMemcpyDeviceToHost));
   return DVP_OK;
 }
 

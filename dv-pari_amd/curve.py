@@ -76,6 +76,21 @@ def from_bytes(enc: np.ndarray):
     return xy, inf
 
 
+def add(a_xy, b_xy, a_inf=None, b_inf=None):
+    """CurvePoint::add over two vectors, src/curve.rs:84-90.  Returns (xy [n,8], inf [n])."""
+    a = np.ascontiguousarray(a_xy, dtype=np.uint64).reshape(-1, 8)
+    b = np.ascontiguousarray(b_xy, dtype=np.uint64).reshape(-1, 8)
+    n = a.shape[0]
+    assert b.shape[0] == n
+    ai = None if a_inf is None else np.ascontiguousarray(a_inf, dtype=np.uint8)
+    bi = None if b_inf is None else np.ascontiguousarray(b_inf, dtype=np.uint8)
+    xy = np.zeros((n, 8), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    check(lib.dvp_points_add(ptr(a), None if ai is None else ptr(ai), ptr(b), None if bi is None else ptr(bi), n, ptr(xy), ptr(inf)),
+          "dvp_points_add")
+    return xy, inf
+
+
 def multi_scalar_mul_bytes(scalars32: np.ndarray, bases30: np.ndarray) -> bytes:
     s = np.ascontiguousarray(scalars32, dtype=np.uint8).reshape(-1, 32)
     b = np.ascontiguousarray(bases30, dtype=np.uint8).reshape(-1, 30)

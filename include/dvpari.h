@@ -137,6 +137,10 @@ int dvp_mulgen_batch_affine(const uint64_t* scalars, size_t n, uint64_t* out_xy 
 /* CurvePoint::to_bytes / from_bytes over vectors (src/curve.rs:93-109, src/io_utils.rs:217-226) */
 int dvp_points_encode(const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* out_enc);
 int dvp_points_decode(const uint8_t* enc, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* CurvePoint::add over two vectors (src/curve.rs:84-90; complete: doubling, inverses, neutral).  Equality of two
+ * CurvePoints (src/curve.rs:69-76) is equality of (x, y, infinity) on this representation. */
+int dvp_points_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, size_t n, uint64_t* out_xy,
+                   uint8_t* out_inf);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Prover -- Proof::prove(cache_dir, public_inputs, private_inputs), src/proving.rs:426-688,      */

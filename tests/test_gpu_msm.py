@@ -173,3 +173,20 @@ def test_msm_heavy_skew_2_18(dvp):
     fb = dvp.curve.FixedBaseMsm(bases)
     xy, is_inf = fb.run(s)
     assert np_to_pt(xy, is_inf) == co.k233_mulgen(np_dot_mod(s, k))
+
+
+def test_points_add_like_curvepoint_add(dvp):
+    """CurvePoint::add (src/curve.rs:84-90): generic, doubling, P + (-P), neutral on either side -- vs the oracle group law"""
+    import pyref as o2
+    rnd = random.Random(44)
+    ks = [rnd.randrange(1, o.P) for _ in range(6)]
+    pts = [co.k233_mulgen(k) for k in ks]
+    neg = lambda p: (p[0], p[0] ^ p[1])
+    a = [pts[0], pts[1], pts[2], pts[3], pts[4], pts[5]]
+    b = [pts[1], pts[1], neg(pts[2]), pts[0], pts[4], pts[3]]
+    a_inf = np.array([0, 0, 0, 1, 0, 1], dtype=np.uint8)
+    b_inf = np.array([0, 0, 0, 0, 1, 1], dtype=np.uint8)
+    xy, inf = dvp.curve.add(pts_to_np(a), pts_to_np(b), a_inf, b_inf)
+    exp = [o2.k233_add(a[0], b[0]), o2.k233_add(a[1], a[1]), None, b[3], a[4], None]
+    for i, e in enumerate(exp):
+        assert np_to_pt(xy[i], bool(inf[i])) == e, i
