@@ -53,20 +53,23 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
     for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
   }
   // expansion: u = r0 & 1; r0 -= u; h = r0 >> 1 (arithmetic); (r0, r1) = (r1 - h, -h)
-  // windows 0 .. n_narrow-1 are c-1 digits wide, the rest c (fixed-base mode evens the windows out, see MsmFixedCtx)
-  uint32_t dig = 0;
-  int bitpos = 0, w = 0, width = n_narrow > 0 ? c - 1 : c;
-  for (int step = 0; step < W * c - n_narrow; ++step) {
-    dig |= tau_step(r0, r1) << bitpos;
-    if (++bitpos == width) {
-      digits[(size_t)w * n + i] = (DIGIT)dig;
-      dig = 0;
-      bitpos = 0;
+  // windows 0 .. n_narrow-1 are c-1 digits wide, the rest c (fixed-base mode evens the windows out, see MsmFixedCtx).
+  // Digits arrive sixteen at a time (tau_step16) into a 64-bit shift register; windows are cut from its low end.
+  const int total = W * c - n_narrow;
+  uint64_t buf = 0;
+  int nb = 0, w = 0, width = n_narrow > 0 ? c - 1 : c;
+  for (int done = 0; done < total; done += 16) {
+    buf |= (uint64_t)tau_step16(r0, r1) << nb;
+    nb += 16;
+    while (nb >= width && w < W) {
+      digits[(size_t)w * n + i] = (DIGIT)(buf & ((1ull << width) - 1));
+      buf >>= width;
+      nb -= width;
       ++w;
       width = w < n_narrow ? c - 1 : c;
     }
   }
-  uint32_t rest = 0;
+  uint32_t rest = (uint32_t)buf | (uint32_t)(buf >> 32);  // digits beyond the last window
 #pragma unroll
   for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
   if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than W*c digits

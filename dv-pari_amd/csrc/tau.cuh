@@ -144,4 +144,66 @@ __device__ __forceinline__ uint32_t tau_step(uint32_t* r0, uint32_t* r1) {
   return u;
 }
 
+// sixteen digits at once.  The digits depend only on the low bits of (r0, r1), so they come from a 32-bit copy of the
+// one-digit recurrence (after j steps the low 32-j bits are still exact); then rho <- (rho - D) / tau^16 in one
+// multi-limb pass: D = sum d_i tau^i = p + q tau by Horner, tau^16 = 178 - 93 tau, N(tau^16) = 2^16 and
+// conj(tau^16) = 271 + 93 tau, so with x = r0 - p, y = r1 - q:
+//     r0' = (271 x - 186 y) / 2^16,   r1' = (93 x + 178 y) / 2^16          (exact divisions).
+// ~3x fewer instructions than sixteen tau_step calls.  Returns the digits, digit i in bit i.
+__device__ __forceinline__ uint32_t tau_step16(uint32_t* r0, uint32_t* r1) {
+  uint32_t lo0 = r0[0], lo1 = r1[0], dw = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    uint32_t u = lo0 & 1u;
+    uint32_t h = (lo0 - u) >> 1;
+    lo0 = lo1 - h;
+    lo1 = 0u - h;
+    dw |= u << i;
+  }
+  int32_t p = 0, q = 0;
+#pragma unroll
+  for (int i = 15; i >= 0; --i) {
+    int32_t d = (int32_t)((dw >> i) & 1u);
+    int32_t np = d - 2 * q, nq = p - q;
+    p = np;
+    q = nq;
+  }
+  // x = r0 - p, y = r1 - q (5-limb two's complement), then the two linear combinations with carries in int64
+  uint32_t x[5], y[5];
+  {
+    int64_t bx = -(int64_t)p, by = -(int64_t)q;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      bx += (int64_t)(uint64_t)r0[k];
+      x[k] = (uint32_t)bx;
+      bx >>= 32;
+      by += (int64_t)(uint64_t)r1[k];
+      y[k] = (uint32_t)by;
+      by >>= 32;
+    }
+  }
+  uint32_t n0[5], n1[5];
+  int64_t c0 = 0, c1 = 0;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    // limbs 0..3 are unsigned digits, limb 4 carries the sign
+    int64_t xv = k < 4 ? (int64_t)(uint64_t)x[k] : (int64_t)(int32_t)x[k];
+    int64_t yv = k < 4 ? (int64_t)(uint64_t)y[k] : (int64_t)(int32_t)y[k];
+    c0 += 271 * xv - 186 * yv;
+    c1 += 93 * xv + 178 * yv;
+    n0[k] = (uint32_t)c0;
+    n1[k] = (uint32_t)c1;
+    c0 >>= 32;
+    c1 >>= 32;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    r0[k] = (n0[k] >> 16) | (n0[k + 1] << 16);
+    r1[k] = (n1[k] >> 16) | (n1[k + 1] << 16);
+  }
+  r0[4] = (uint32_t)((int32_t)n0[4] >> 16);
+  r1[4] = (uint32_t)((int32_t)n1[4] >> 16);
+  return dw;
+}
+
 }  // namespace dvp

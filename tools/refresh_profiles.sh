@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs ON THE MI355X BOX (gpurun -- 'bash tools/refresh_profiles.sh'): un-profiled bench line, the same command under
+# rocprofv3 --kernel-trace --stats, and the two separate PMC passes (FETCH_SIZE, WRITE_SIZE) for roofline.traffic.
+# Everything lands in gpurun_out/refresh/; tools/digest_profiles.py then writes the summaries into profiles/.
+set -e -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/refresh
+rm -rf $OUT && mkdir -p $OUT
+cd $ROOT
+timeout -k 10 600 python3 bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+echo "stats done"
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+echo "pmc fetch done"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+echo "pmc write done"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 20 > $OUT/msm_bench.log 2>&1
+echo "msm stats done"
+ls -R $OUT | head -40
