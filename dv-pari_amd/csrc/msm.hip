@@ -211,10 +211,14 @@ k_scatter_local(const uint16_t* __restrict__ digits, uint32_t n, int c, const ui
 }
 
 // ---- two-level counting sort for the fixed-base mode (keys of up to 20 bits) ----------------------------
-// Level 1 partitions the entries by the top c - 15 bits (up to 32 partitions, LDS cursors per block); level 2 is
-// the LDS counting sort above applied inside each partition on the low 15 bits.  An entry is the pair
-// (window w, scalar i); its id e = w * n_total + i0 + i indexes the pre-rotated base table directly.
-constexpr int FX_LO_MAX = 15, FX_C_MAX = 20, FX_NP_MAX = 1 << (FX_C_MAX - FX_LO_MAX);  // c = lo + hi bits, chosen per context
+// Level 1 partitions the entries by the top `hi` key bits (LDS cursors per block, up to 2^10 partitions); level 2 is the
+// LDS counting sort above applied inside each partition on the low `lo` <= 15 bits.  Both levels scatter single entries,
+// so the more bins a level has the fewer entries of a chunk share a 32-byte sector: with 2^15 level-2 bins each 4-byte
+// entry costs a whole sector (1.3 GB of HBM writes for 160 MB of entries), with 2^9 level-1 bins the two level-1
+// streams thrash the L2 instead.  The split is a per-context knob (MsmFixedCtx::hi_bits); staging each chunk in LDS
+// and writing whole runs would remove the trade-off and is the known next step for this stage.
+// An entry is the pair (window w, scalar i); its id e = w * n_total + i0 + i indexes the pre-rotated base table.
+constexpr int FX_C_MAX = 20, FX_NP_MAX = 1 << (FX_C_MAX / 2);  // c = lo + hi bits, chosen per context
 struct FxBits {
   int lo, hi;  // low bits sorted in LDS, high bits partitioned first
   __host__ __device__ uint32_t np() const { return 1u << hi; }
@@ -225,7 +229,7 @@ k_part_hist(const uint32_t* __restrict__ digits, size_t total, FxBits fb, uint32
   __shared__ uint32_t h[FX_NP_MAX];
   const uint32_t FX_NP = fb.np();
   const int FX_LO = fb.lo;
-  if (threadIdx.x < FX_NP) h[threadIdx.x] = 0;
+  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) h[k] = 0;
   __syncthreads();
   size_t lo = (size_t)blockIdx.x * SORT_CHUNK, hi = min(total, lo + SORT_CHUNK);
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
@@ -233,7 +237,7 @@ k_part_hist(const uint32_t* __restrict__ digits, size_t total, FxBits fb, uint32
     if (d) atomicAdd(&h[d >> FX_LO], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < FX_NP) phist[(size_t)blockIdx.x * FX_NP + threadIdx.x] = h[threadIdx.x];
+  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) phist[(size_t)blockIdx.x * FX_NP + k] = h[k];
 }
 // per partition (one block each): exclusive prefix over the level-1 blocks
 __global__ void __launch_bounds__(256)
@@ -259,19 +263,30 @@ k_part_scan(const uint32_t* __restrict__ phist, uint32_t nblk, FxBits fb, uint32
   }
   if (t == 255) pcount[part] = sh[255];
 }
-// partition starts and the global level-2 chunk index of each partition
-__global__ void k_part_starts(const uint32_t* __restrict__ pcount, FxBits fb, uint32_t* __restrict__ pstart, uint32_t* __restrict__ cstart) {
-  if (threadIdx.x || blockIdx.x) return;
-  const uint32_t FX_NP = fb.np();
-  uint32_t ps = 0, cs = 0;
-  for (uint32_t k = 0; k < FX_NP; ++k) {
-    pstart[k] = ps;
-    cstart[k] = cs;
-    ps += pcount[k];
-    cs += (pcount[k] + SORT_CHUNK - 1) / SORT_CHUNK;
+// partition starts and the global level-2 chunk index of each partition (one block of FX_NP_MAX threads)
+__global__ void __launch_bounds__(FX_NP_MAX)
+k_part_starts(const uint32_t* __restrict__ pcount, FxBits fb, uint32_t* __restrict__ pstart, uint32_t* __restrict__ cstart) {
+  __shared__ uint32_t sp[FX_NP_MAX], sc[FX_NP_MAX];
+  const uint32_t FX_NP = fb.np(), t = threadIdx.x;
+  uint32_t pc = t < FX_NP ? pcount[t] : 0, cc = (pc + SORT_CHUNK - 1) / SORT_CHUNK;
+  sp[t] = pc;
+  sc[t] = cc;
+  __syncthreads();
+  for (uint32_t o = 1; o < FX_NP_MAX; o <<= 1) {
+    uint32_t a = t >= o ? sp[t - o] : 0, b = t >= o ? sc[t - o] : 0;
+    __syncthreads();
+    sp[t] += a;
+    sc[t] += b;
+    __syncthreads();
   }
-  pstart[FX_NP] = ps;
-  cstart[FX_NP] = cs;
+  if (t < FX_NP) {
+    pstart[t] = sp[t] - pc;
+    cstart[t] = sc[t] - cc;
+  }
+  if (t == FX_NP - 1) {
+    pstart[FX_NP] = sp[t];
+    cstart[FX_NP] = sc[t];
+  }
 }
 __global__ void __launch_bounds__(SORT_TPB)
 k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, uint32_t n_total, uint32_t i0, FxBits fb,
@@ -280,7 +295,7 @@ k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, ui
   __shared__ uint32_t cur[FX_NP_MAX];
   const uint32_t FX_NP = fb.np();
   const int FX_LO = fb.lo;
-  if (threadIdx.x < FX_NP) cur[threadIdx.x] = pstart[threadIdx.x] + pbase[(size_t)blockIdx.x * FX_NP + threadIdx.x];
+  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + pbase[(size_t)blockIdx.x * FX_NP + k];
   __syncthreads();
   size_t lo = (size_t)blockIdx.x * SORT_CHUNK, hi = min(total, lo + SORT_CHUNK);
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
@@ -292,10 +307,15 @@ k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, ui
     pid[pos] = w * n_total + i0 + i;
   }
 }
+// the partition whose chunk range [cstart[k], cstart[k+1]) holds chunk g (empty partitions share their start with the
+// next one, so take the LAST k with cstart[k] <= g)
 __device__ __forceinline__ uint32_t fx_chunk_partition(const uint32_t* __restrict__ cstart, uint32_t FX_NP, uint32_t g) {
-  uint32_t hi = 0;
-  while (hi + 1 < FX_NP && cstart[hi + 1] <= g) ++hi;
-  return hi;
+  uint32_t lo = 0, hi = FX_NP;  // invariant: cstart[lo] <= g, and cstart[hi] > g or hi == FX_NP
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (cstart[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
 }
 // level 2, per global chunk g (partition hi, local chunk g - cstart[hi])
 __global__ void __launch_bounds__(SORT_TPB)
@@ -766,7 +786,8 @@ struct MsmFixedCtx {
     n_narrow = w_main * cc - 234;
     W = w_main + 1;
   }
-  FxBits bits() const { FxBits b; b.lo = c < FX_LO_MAX ? c : FX_LO_MAX; b.hi = c - b.lo; return b; }
+  int hi_bits = -1;  // level-1 partition bits of the sort (set at creation)
+  FxBits bits() const { FxBits b; b.hi = hi_bits; b.lo = c - b.hi; return b; }
 };
 static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   const bool fixed = fx != nullptr;
@@ -912,7 +933,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t gmax = fx_nblk + FX_NP;  // upper bound on the number of level-2 chunks
     hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
     hipLaunchKernelGGL(k_part_scan, dim3(FX_NP), dim3(256), 0, st, phist, fx_nblk, fb, pbase, pcount);
-    hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(64), 0, st, pcount, fb, pstart, cstart);
+    hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(FX_NP_MAX), 0, st, pcount, fb, pstart, cstart);
     hipLaunchKernelGGL(k_part_scatter, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, (uint32_t)n, fx->n_total, i0, fb, pbase,
                        pstart, plo, pid);
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
@@ -1053,6 +1074,8 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
   }
   if (const char* e = getenv("DVP_MSM_FIXED_C")) { int cc = atoi(e); if (cc >= 8 && cc <= FX_C_MAX) best_c = cc; }
   c->set_c(best_c);
+  c->hi_bits = c->c > 14 ? c->c - 14 : 0;  // measured on MI355X at c = 18: 4 partition bits beat 3 (the old 15-bit LDS sort) and 5..9
+  if (const char* e = getenv("DVP_FX_HI")) { int h = atoi(e); if (h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h; }
   DVP_HIP(hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff)));
   hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
   DVP_HIP(hipGetLastError());
