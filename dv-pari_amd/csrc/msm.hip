@@ -219,6 +219,7 @@ k_scatter_local(const uint16_t* __restrict__ digits, uint32_t n, int c, const ui
 // and writing whole runs would remove the trade-off and is the known next step for this stage.
 // An entry is the pair (window w, scalar i); its id e = w * n_total + i0 + i indexes the pre-rotated base table.
 constexpr int FX_C_MAX = 20, FX_NP_MAX = 1 << (FX_C_MAX / 2);  // c = lo + hi bits, chosen per context
+constexpr uint32_t FX_CHUNK = 16384;  // entries per block at both levels: the staged scatters keep a whole chunk in LDS
 struct FxBits {
   int lo, hi;  // low bits sorted in LDS, high bits partitioned first
   __host__ __device__ uint32_t np() const { return 1u << hi; }
@@ -231,7 +232,7 @@ k_part_hist(const uint32_t* __restrict__ digits, size_t total, FxBits fb, uint32
   const int FX_LO = fb.lo;
   for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) h[k] = 0;
   __syncthreads();
-  size_t lo = (size_t)blockIdx.x * SORT_CHUNK, hi = min(total, lo + SORT_CHUNK);
+  size_t lo = (size_t)blockIdx.x * FX_CHUNK, hi = min(total, lo + FX_CHUNK);
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
     uint32_t d = digits[e];
     if (d) atomicAdd(&h[d >> FX_LO], 1u);
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(FX_NP_MAX)
 k_part_starts(const uint32_t* __restrict__ pcount, FxBits fb, uint32_t* __restrict__ pstart, uint32_t* __restrict__ cstart) {
   __shared__ uint32_t sp[FX_NP_MAX], sc[FX_NP_MAX];
   const uint32_t FX_NP = fb.np(), t = threadIdx.x;
-  uint32_t pc = t < FX_NP ? pcount[t] : 0, cc = (pc + SORT_CHUNK - 1) / SORT_CHUNK;
+  uint32_t pc = t < FX_NP ? pcount[t] : 0, cc = (pc + FX_CHUNK - 1) / FX_CHUNK;
   sp[t] = pc;
   sc[t] = cc;
   __syncthreads();
@@ -297,7 +298,7 @@ k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, ui
   const int FX_LO = fb.lo;
   for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + pbase[(size_t)blockIdx.x * FX_NP + k];
   __syncthreads();
-  size_t lo = (size_t)blockIdx.x * SORT_CHUNK, hi = min(total, lo + SORT_CHUNK);
+  size_t lo = (size_t)blockIdx.x * FX_CHUNK, hi = min(total, lo + FX_CHUNK);
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
     uint32_t d = digits[e];
     if (!d) continue;
@@ -328,7 +329,7 @@ k_hist_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ pst
   for (uint32_t k = threadIdx.x; k < (nb >> 1); k += SORT_TPB) lds_cnt[k] = 0;
   __syncthreads();
   uint32_t hi = fx_chunk_partition(cstart, FX_NP, g);
-  uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * SORT_CHUNK, hi_e = min(pstart[hi + 1], lo_e + SORT_CHUNK);
+  uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * FX_CHUNK, hi_e = min(pstart[hi + 1], lo_e + FX_CHUNK);
   for (uint32_t j = lo_e + threadIdx.x; j < hi_e; j += SORT_TPB) {
     uint32_t d = plo[j];
     atomicAdd(&lds_cnt[d >> 1], 1u << (16 * (d & 1)));
@@ -367,8 +368,107 @@ k_scatter_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ 
   const uint32_t* of = off + ((size_t)hi << FX_LO);
   for (uint32_t k = threadIdx.x; k < nb; k += SORT_TPB) lds_cur[k] = of[k] + co[k];
   __syncthreads();
-  uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * SORT_CHUNK, hi_e = min(pstart[hi + 1], lo_e + SORT_CHUNK);
+  uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * FX_CHUNK, hi_e = min(pstart[hi + 1], lo_e + FX_CHUNK);
   for (uint32_t j = lo_e + threadIdx.x; j < hi_e; j += SORT_TPB) items[atomicAdd(&lds_cur[plo[j]], 1u)] = pid[j];
+}
+
+// ---- staged scatters (used when a level has <= SORT_TPB bins) ---------------------------------------------------------
+// A block first places its chunk into LDS grouped by bin (LDS cursors start at the exclusive scan of the chunk's own
+// histogram), then copies the staged chunk out in order: consecutive lanes hold consecutive entries of one bin, whose
+// destinations are consecutive, so every bin leaves as one coalesced run instead of as single-entry sector writes.
+__device__ __forceinline__ uint32_t block_scan_tpb(uint32_t v, uint32_t* sh, uint32_t* total) {
+  const int t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 1; o < SORT_TPB; o <<= 1) {
+    uint32_t x = t >= o ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  uint32_t incl = sh[t];
+  *total = sh[SORT_TPB - 1];
+  __syncthreads();
+  return incl - v;
+}
+constexpr unsigned FX_STAGE1_LDS = (2 * FX_NP_MAX + SORT_TPB + 2 * FX_CHUNK) * 4;
+constexpr unsigned FX_STAGE2_LDS = (2 * FX_NP_MAX + SORT_TPB + FX_CHUNK) * 4 + FX_CHUNK * 2;
+
+__global__ void __launch_bounds__(SORT_TPB)
+k_part_scatter_staged(const uint32_t* __restrict__ digits, size_t total, uint32_t n, uint32_t n_total, uint32_t i0, FxBits fb,
+                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pbase, const uint32_t* __restrict__ pstart,
+                      uint16_t* __restrict__ plo, uint32_t* __restrict__ pid) {
+  extern __shared__ uint32_t lds_st[];
+  uint32_t* cur = lds_st;             // [FX_NP_MAX]
+  uint32_t* gdst = cur + FX_NP_MAX;   // [FX_NP_MAX] destination of staged position 0 of the bin
+  uint32_t* sh = gdst + FX_NP_MAX;    // [SORT_TPB]
+  uint32_t* st_d = sh + SORT_TPB;     // [FX_CHUNK]
+  uint32_t* st_id = st_d + FX_CHUNK;  // [FX_CHUNK]
+  const uint32_t FX_NP = fb.np(), t = threadIdx.x;
+  const int FX_LO = fb.lo;
+  const size_t hb = (size_t)blockIdx.x * FX_NP;
+  uint32_t h = t < FX_NP ? phist[hb + t] : 0, tot;
+  uint32_t ex = block_scan_tpb(h, sh, &tot);
+  if (t < FX_NP) {
+    cur[t] = ex;
+    gdst[t] = pstart[t] + pbase[hb + t] - ex;
+  }
+  __syncthreads();
+  const size_t lo = (size_t)blockIdx.x * FX_CHUNK, hi = min(total, lo + FX_CHUNK);
+  const uint32_t w0 = (uint32_t)(lo / n);
+  for (size_t e = lo + t; e < hi; e += SORT_TPB) {
+    uint32_t d = digits[e];
+    if (!d) continue;
+    uint32_t w = w0;
+    size_t i = e - (size_t)w0 * n;
+    while (i >= n) {
+      i -= n;
+      ++w;
+    }
+    uint32_t pos = atomicAdd(&cur[d >> FX_LO], 1u);
+    st_d[pos] = d;
+    st_id[pos] = w * n_total + i0 + (uint32_t)i;
+  }
+  __syncthreads();
+  const uint32_t mask = (1u << FX_LO) - 1;
+  for (uint32_t pos = t; pos < tot; pos += SORT_TPB) {
+    uint32_t d = st_d[pos], dst = gdst[d >> FX_LO] + pos;
+    plo[dst] = (uint16_t)(d & mask);
+    pid[dst] = st_id[pos];
+  }
+}
+
+__global__ void __launch_bounds__(SORT_TPB)
+k_scatter_local2_staged(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ pid, const uint32_t* __restrict__ pstart,
+                        const uint32_t* __restrict__ cstart, FxBits fb, const uint32_t* __restrict__ off,
+                        const uint32_t* __restrict__ chunk_off, const uint16_t* __restrict__ hist, uint32_t* __restrict__ items) {
+  extern __shared__ uint32_t lds_st[];
+  uint32_t* cur = lds_st;
+  uint32_t* gdst = cur + FX_NP_MAX;
+  uint32_t* sh = gdst + FX_NP_MAX;
+  uint32_t* st_id = sh + SORT_TPB;                 // [FX_CHUNK]
+  uint16_t* st_b = (uint16_t*)(st_id + FX_CHUNK);  // [FX_CHUNK]
+  const uint32_t FX_NP = fb.np(), t = threadIdx.x;
+  const int FX_LO = fb.lo;
+  const uint32_t g = blockIdx.x, nb = 1u << FX_LO;  // nb <= SORT_TPB
+  if (g >= cstart[FX_NP]) return;
+  const uint32_t hi = fx_chunk_partition(cstart, FX_NP, g);
+  uint32_t h = t < nb ? hist[(size_t)g * nb + t] : 0, tot;
+  uint32_t ex = block_scan_tpb(h, sh, &tot);
+  if (t < nb) {
+    cur[t] = ex;
+    gdst[t] = off[((size_t)hi << FX_LO) + t] + chunk_off[(size_t)g * nb + t] - ex;
+  }
+  __syncthreads();
+  const uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * FX_CHUNK, hi_e = min(pstart[hi + 1], lo_e + FX_CHUNK);
+  for (uint32_t j = lo_e + t; j < hi_e; j += SORT_TPB) {
+    uint32_t b = plo[j];
+    uint32_t pos = atomicAdd(&cur[b], 1u);
+    st_id[pos] = pid[j];
+    st_b[pos] = (uint16_t)b;
+  }
+  __syncthreads();
+  for (uint32_t pos = t; pos < tot; pos += SORT_TPB) items[gdst[st_b[pos]] + pos] = st_id[pos];
 }
 
 // pre-rotated base table for the fixed-base mode: T[w][i] = tau^(o_w)(P_i), o_w = first digit of window w
@@ -846,6 +946,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_hist_local2, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE1_LDS);
+      if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
                           (const void*)k_affine_round<true>, (const void*)k_affine_round<false>};
       for (const void* f : ec)
@@ -862,7 +966,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
   size_t o_err = carve(16);
   size_t o_digits = carve(fx ? 16 : (size_t)p.W * n * 2);
-  const uint32_t fx_nblk = cdiv(p.e_max, SORT_CHUNK);
+  const uint32_t fx_nblk = cdiv(p.e_max, FX_CHUNK);
   size_t o_digits32 = carve(fx ? p.e_max * 4 : 16);
   size_t o_plo = carve(fx ? p.e_max * 2 : 16);
   size_t o_pid = carve(fx ? p.e_max * 4 : 16);
@@ -934,12 +1038,22 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
     hipLaunchKernelGGL(k_part_scan, dim3(FX_NP), dim3(256), 0, st, phist, fx_nblk, fb, pbase, pcount);
     hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(FX_NP_MAX), 0, st, pcount, fb, pstart, cstart);
-    hipLaunchKernelGGL(k_part_scatter, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, (uint32_t)n, fx->n_total, i0, fb, pbase,
-                       pstart, plo, pid);
+    const bool staged1 = FX_NP >= 64;           // few partitions: direct stores already coalesce
+    const bool staged2 = fb.lo <= 10;           // one bin per thread in the block scan
+    if (staged1)
+      hipLaunchKernelGGL(k_part_scatter_staged, dim3(fx_nblk), dim3(SORT_TPB), FX_STAGE1_LDS, st, digits32, p.e_max, (uint32_t)n,
+                         fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
+    else
+      hipLaunchKernelGGL(k_part_scatter, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, (uint32_t)n, fx->n_total, i0, fb, pbase,
+                         pstart, plo, pid);
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
     hipLaunchKernelGGL(k_hist_scan2, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, cstart, fb, chunk_off, cnt);
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
-    hipLaunchKernelGGL(k_scatter_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 4, st, plo, pid, pstart, cstart, fb, off, chunk_off, items);
+    if (staged2)
+      hipLaunchKernelGGL(k_scatter_local2_staged, dim3(gmax), dim3(SORT_TPB), FX_STAGE2_LDS, st, plo, pid, pstart, cstart, fb, off,
+                         chunk_off, hist16, items);
+    else
+      hipLaunchKernelGGL(k_scatter_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 4, st, plo, pid, pstart, cstart, fb, off, chunk_off, items);
   } else {
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
@@ -1074,7 +1188,7 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
   }
   if (const char* e = getenv("DVP_MSM_FIXED_C")) { int cc = atoi(e); if (cc >= 8 && cc <= FX_C_MAX) best_c = cc; }
   c->set_c(best_c);
-  c->hi_bits = c->c > 14 ? c->c - 14 : 0;  // measured on MI355X at c = 18: 4 partition bits beat 3 (the old 15-bit LDS sort) and 5..9
+  c->hi_bits = c->c / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
   if (const char* e = getenv("DVP_FX_HI")) { int h = atoi(e); if (h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h; }
   DVP_HIP(hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff)));
   hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
