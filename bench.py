@@ -154,13 +154,13 @@ def main():
     # work model of the dominant kernel (first batched-affine pair round): W windows per pair, half of the
     # entries are additions, each 5 products + 1 squaring + 1/16 of a table-driven inversion ~ 6.1 field-
     # multiplication equivalents; ceiling = the LDS-comb multiplier's own microbenchmark rate
-    # (tools/ubench/gfmul_lds.hip: 28.1 G products/s chip-wide)
+    # (tools/ubench/gfmul_occ.hip, 8 waves/CU as in the hot kernels: 31.6 G products/s chip-wide)
     plans = [pv.msm_plan(0), pv.msm_plan(1)]
     sizes = [pv.msm_size(0), pv.msm_size(1)]
     # effective windows: tau-adic expansions are ~234 digits long, the last allocated window is mostly empty
     w_eff = sum(-(-234 // max(c, 1)) * n for (c, _), n in zip(plans, sizes)) / max(sum(sizes), 1) if all(c for c, _ in plans) else 16
     mul_eq = pairs_per_launch * w_eff * 0.5 * 6.1
-    mul_ceiling = 28.1e9
+    mul_ceiling = 31.6e9
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_affine_round0.json")))
@@ -182,7 +182,7 @@ def main():
         "dtype": "u32",
         "data": "synthetic",
         "config": {
-            "workload": f"Proof::prove, synthetic dense R1CS, 2^{log_m} constraints (BASELINE config #4)",
+            "workload": f"Proof::prove, synthetic dense R1CS, 2^{log_m} constraints" + (" (BASELINE config #4)" if log_m == 20 else ""),
             "log2_constraints": log_m,
             "n_wires": inst.n_wires,
             "msm_pairs_per_proof": inst.n_wires + 5 * m,
