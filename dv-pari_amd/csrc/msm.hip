@@ -604,26 +604,30 @@ __device__ __forceinline__ const Aff* aff_ptr(const Aff* __restrict__ pts, const
 
 // Thread t of T = ceil(total / AFF_B) owns output slots s = k*T + t, k < AFF_B (lane-consecutive slots:
 // coalesced outputs, prefix products and -- after the first round -- inputs).
-template <bool FIRST>
+template <bool FIRST, int B>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */,
-               uint32_t nkeys, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
+               uint32_t nkeys, GfSqrTables T, Gf* __restrict__ prefix, uint32_t* __restrict__ gdesc, Aff* __restrict__ out) {
   extern __shared__ char lds_raw[];
   GfLds L = gf_lds_init(lds_raw);
-  uint32_t* desc = (uint32_t*)(lds_raw + EC_LDS) + threadIdx.x;  // stride EC_TPB
   const uint32_t total = ooff[nkeys];
-  const uint32_t nthr = (total + AFF_B - 1) / AFF_B;
+  const uint32_t nthr = (total + B - 1) / B;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nthr) return;
+  // slot descriptors: B = 16 keeps them in the 16 KB of LDS beside the tables; B = 32 (the big rounds, where halving the
+  // inversions per addition pays) parks them in HBM in [slot][thread] order
+  uint32_t* desc = B <= AFF_B ? (uint32_t*)(lds_raw + EC_LDS) + threadIdx.x : gdesc + tid;
+  const size_t dstr = B <= AFF_B ? (size_t)EC_TPB : (size_t)nthr;
   // pre-pass: slot -> (first input index, has-partner flag in bit 31); 0xffffffff = no slot.  The AFF_B binary
   // searches over the key offsets advance in lockstep, so each step has AFF_B independent loads in flight instead of
   // one (18 dependent L2 round trips per slot, one slot after the other, used to cost as much as the additions).
-  {
+#pragma unroll 1
+  for (int k0 = 0; k0 < B; k0 += AFF_B) {
     uint32_t lo[AFF_B], hi[AFF_B], sv[AFF_B];
 #pragma unroll
     for (int k = 0; k < AFF_B; ++k) {
-      sv[k] = min((uint32_t)k * nthr + tid, total - 1);
+      sv[k] = min((uint32_t)(k0 + k) * nthr + tid, total - 1);
       lo[k] = 0;
       hi[k] = nkeys;  // invariant: ooff[lo] <= s < ooff[hi]
     }
@@ -648,12 +652,12 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
     }
 #pragma unroll
     for (int k = 0; k < AFF_B; ++k) {
-      uint32_t sk = (uint32_t)k * nthr + tid, d = 0xffffffffu;
+      uint32_t sk = (uint32_t)(k0 + k) * nthr + tid, d = 0xffffffffu;
       if (sk < total) {
         uint32_t j = sk - o0[k];
         d = (o1[k] + 2 * j) | ((2 * j + 1 < cn[k]) ? 0x80000000u : 0u);
       }
-      desc[k * EC_TPB] = d;
+      desc[(size_t)(k0 + k) * dstr] = d;
     }
   }
   const Gf one = gf_one();
@@ -669,9 +673,9 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
       xa = pa->x; xb = pb->x;
     }
 #pragma unroll 1
-    for (int k = 0; k < AFF_B; ++k) {
+    for (int k = 0; k < B; ++k) {
       // prefetch the next slot while this one multiplies
-      uint32_t dn = (k + 1 < AFF_B) ? desc[(k + 1) * EC_TPB] : 0xffffffffu;
+      uint32_t dn = (k + 1 < B) ? desc[(size_t)(k + 1) * dstr] : 0xffffffffu;
       const Aff *na = nullptr, *nb = nullptr;
       Gf nxa = gf_zero(), nxb = gf_zero();
       if (dn != 0xffffffffu && (dn >> 31)) {
@@ -694,8 +698,8 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
   Gf inv = gf_inv_fast(run, T, L);
   // pass 2 (backwards): recover each inverse and finish the addition
 #pragma unroll 1
-  for (int k = AFF_B - 1; k >= 0; --k) {
-    uint32_t d = desc[k * EC_TPB];
+  for (int k = B - 1; k >= 0; --k) {
+    uint32_t d = desc[(size_t)k * dstr];
     if (d == 0xffffffffu) continue;
     uint32_t s = (uint32_t)k * nthr + tid;
     const Aff* pa = aff_ptr<FIRST>(pts, items, d & 0x7fffffffu);
@@ -951,7 +955,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
-                          (const void*)k_affine_round<true>, (const void*)k_affine_round<false>};
+                          (const void*)k_affine_round<true, 16>, (const void*)k_affine_round<false, 16>,
+                          (const void*)k_affine_round<true, 32>, (const void*)k_affine_round<false, 32>};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS);
     });
@@ -992,6 +997,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_affA = carve(affine_mode ? affA_n * sizeof(Aff) : 16);
   size_t o_affB = carve(affine_mode ? affB_n * sizeof(Aff) : 16);
   size_t o_prefix = carve(affine_mode ? aff_threads * AFF_B * sizeof(Gf) : 16);
+  size_t o_gdesc = carve(affine_mode ? (aff_threads * AFF_B + 64) * 4 : 16);
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_tail = carve((size_t)2 * p.W * p.c * sizeof(Ld));
   DVP_TRY(g_ws.ensure(o));
@@ -1022,6 +1028,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   Aff* affA = (Aff*)(base + o_affA);
   Aff* affB = (Aff*)(base + o_affB);
   Gf* prefix = (Gf*)(base + o_prefix);
+  uint32_t* gdesc = (uint32_t*)(base + o_gdesc);
   Ld* tail = (Ld*)(base + o_tail);
   const uint32_t nk = p.nkeys;
 
@@ -1091,13 +1098,21 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
       size_t out_max = cap / 2 + nk + 1;
       Aff* outp = (r & 1) ? affB : affA;
-      uint32_t grid = cdiv(cdiv(out_max, AFF_B), EC_TPB);
+      // big rounds share one inversion among 32 additions, small ones among 16 (they need the threads)
+      size_t b32_min = (size_t)8 << 20;
+      if (const char* e = getenv("DVP_MSM_B32_MIN")) b32_min = (size_t)atoll(e);
+      const bool big = out_max >= b32_min;
+      uint32_t grid = cdiv(cdiv(out_max, big ? 32 : AFF_B), EC_TPB);
+#define DVP_AFF_LAUNCH(FIRST, BB) \
+  hipLaunchKernelGGL((k_affine_round<FIRST, BB>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, gdesc, outp)
       if (r == 0) {
         ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // the dominant kernel: first pair round (gathers the bases)
-        hipLaunchKernelGGL((k_affine_round<true>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, outp);
+        if (big) DVP_AFF_LAUNCH(true, 32); else DVP_AFF_LAUNCH(true, 16);
         ps0.stop();
-      } else
-        hipLaunchKernelGGL((k_affine_round<false>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, outp);
+      } else {
+        if (big) DVP_AFF_LAUNCH(false, 32); else DVP_AFF_LAUNCH(false, 16);
+      }
+#undef DVP_AFF_LAUNCH
       pts_in = outp;
       cap = out_max;
       cur = nxt;
