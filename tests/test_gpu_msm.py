@@ -148,6 +148,16 @@ def test_fixed_base_msm_context(dvp, hint):
 
     xy, is_inf = fb.run(s)
     assert np_to_pt(xy, is_inf) == expect(0, n)
+    # the 32-additions-per-inversion flavour of the pair rounds (normally only rounds of >= 8M additions)
+    os.environ["DVP_MSM_B32_MIN"] = "1"
+    os.environ["DVP_MSM_AFF_MIN"] = "64"
+    try:
+        xy, is_inf = fb.run(s)
+        assert np_to_pt(xy, is_inf) == expect(0, n)
+        xy, is_inf = fb.run(s[7:4000], 7, 4000)
+        assert np_to_pt(xy, is_inf) == expect(7, 4000)
+    finally:
+        del os.environ["DVP_MSM_B32_MIN"], os.environ["DVP_MSM_AFF_MIN"]
     parts = []
     for lo, hi in ((0, 1500), (1500, 1501), (1501, 6000), (10, 10)):
         xy, is_inf = fb.run(s[lo:hi], lo, hi)
