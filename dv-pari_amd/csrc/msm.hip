@@ -1076,7 +1076,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t max_cnt = 0;
   DVP_HIP(hipMemcpyAsync(&max_cnt, d_max, 4, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
-  size_t aff_min = (size_t)1 << 20;
+  size_t aff_min = (size_t)1 << 19;
   if (const char* e = getenv("DVP_MSM_AFF_MIN")) aff_min = (size_t)atoll(e);
   const size_t e_est = fx ? (size_t)n * (size_t)(p.W - 1) : p.e_max;  // the overflow window of the fixed-base split is empty
   int ra = 0;
