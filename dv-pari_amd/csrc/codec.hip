@@ -117,8 +117,8 @@ k_decode(const uint8_t* __restrict__ enc, size_t n, Aff* __restrict__ out, uint8
 }
 
 // ---- fixed-base tables: tab[w][d] = sum_t d_t tau^(c w + t)(G), affine ------------------------------
-constexpr int GEN_C = 12;
-constexpr int GEN_W = TAU_DIGITS / GEN_C;  // 20
+constexpr int GEN_C = 16;  // 15 windows, 63 MB table (L2 / Infinity-Cache resident): 15 mixed additions per scalar
+constexpr int GEN_W = TAU_DIGITS / GEN_C;  // 15
 
 __global__ void __launch_bounds__(256) k_gen_table(Aff* __restrict__ tab) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,9 +140,11 @@ __global__ void __launch_bounds__(256) k_gen_table(Aff* __restrict__ tab) {
   tab[tid] = a;  // d == 0 -> zeros, never read
 }
 
-__global__ void __launch_bounds__(256)
-k_mulgen(const uint32_t* __restrict__ scalars, size_t n, const Aff* __restrict__ tab, Aff* __restrict__ out,
+__global__ void __launch_bounds__(256, 2)
+k_mulgen(const uint32_t* __restrict__ scalars, size_t n, const Aff* __restrict__ tab, GfSqrTables T, Aff* __restrict__ out,
          uint8_t* __restrict__ out_inf, unsigned long long* __restrict__ err) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -156,16 +158,32 @@ k_mulgen(const uint32_t* __restrict__ scalars, size_t n, const Aff* __restrict__
   } else {
     tau_partial_reduce(s, r0, r1);
   }
+  // digits sixteen per step (tau.cuh), windows of GEN_C cut from a 64-bit shift register; LDS-comb products
   Ld acc = ld_infinity();
+  uint64_t buf = 0;
+  int nb = 0, w = 0;
 #pragma unroll 1
-  for (int w = 0; w < GEN_W; ++w) {
-    uint32_t d = 0;
-#pragma unroll 1
-    for (int t = 0; t < GEN_C; ++t) d |= tau_step(r0, r1) << t;
-    if (d) acc = ld_madd(acc, tab[((size_t)w << GEN_C) + d]);
+  for (int done = 0; done < GEN_W * GEN_C; done += 16) {
+    buf |= (uint64_t)tau_step16(r0, r1) << nb;
+    nb += 16;
+    while (nb >= GEN_C && w < GEN_W) {
+      uint32_t d = (uint32_t)buf & ((1u << GEN_C) - 1);
+      buf >>= GEN_C;
+      nb -= GEN_C;
+      if (d) ld_madd_ip(acc, tab[((size_t)w << GEN_C) + d], L);
+      ++w;
+    }
   }
   Aff a;
-  bool fin = ld_to_aff(acc, &a);
+  a.x = gf_zero();
+  a.y = gf_zero();
+  bool fin = !ld_is_inf(acc);
+  if (fin) {
+    Gf zi = gf_inv_fast(acc.Z, T, L);
+    gf_tab_build(L, zi);
+    a.x = gf_mul_tab(acc.X, L);
+    a.y = gf_mul(acc.Y, gf_sqr(zi), L);
+  }
   out[i] = a;
   out_inf[i] = fin ? 0 : 1;
 }
@@ -208,8 +226,10 @@ int mulgen_dev(const void* d_scalars, size_t n, Aff* d_out, uint8_t* d_inf, hipS
   DevBuf err;
   DVP_TRY(err.alloc(8));
   DVP_HIP(hipMemsetAsync(err.p, 0xff, 8, st));
-  hipLaunchKernelGGL(k_mulgen, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, n, tab, d_out, d_inf,
-                     err.as<unsigned long long>());
+  GfSqrTables T;
+  DVP_TRY(gf_sqr_tables(&T, st));
+  hipLaunchKernelGGL(k_mulgen, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, (const uint32_t*)d_scalars, n, tab, T, d_out,
+                     d_inf, err.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   return read_err(err.as<unsigned long long>(), st, DVP_EINVAL);
 }
