@@ -32,11 +32,12 @@ __constant__ uint32_t K233_GY[8] = {0x56fae6a3u, 0x56e0c110u, 0xf18aeb9bu, 0x27a
                                     0x555a67c4u, 0x19b7f70fu, 0x537dece8u, 0x000001dbu};
 
 // P in E[r] (affine, x != 0)?  E[r] = 4E: Tr(x) = 0 and a half of P has Tr(x_half) = 0.
-__device__ __forceinline__ bool k233_in_subgroup(const Aff& p) {
+// half-trace through the byte table (30 lookups instead of 232 squarings)
+__device__ __forceinline__ bool k233_in_subgroup(const Aff& p, const GfSqrTables& T, const GfLds& L) {
   if (gf_is_zero(p.x)) return false;
   if (gf_trace(p.x)) return false;
-  Gf lam = gf_halftrace(p.x);                       // lam^2 + lam = x
-  Gf u2 = gf_add(p.y, gf_mul(gf_add(lam, gf_one()), p.x));  // x_half^2
+  Gf lam = gf_sqr_tab(p.x, T.th);                   // lam^2 + lam = x
+  Gf u2 = gf_add(p.y, gf_mul(gf_add(lam, gf_one()), p.x, L));  // x_half^2
   return gf_trace(u2) == 0;
 }
 
@@ -74,9 +75,11 @@ k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n,
   store30(out + i * 30, w);
 }
 
-__global__ void __launch_bounds__(256)
-k_decode(const uint8_t* __restrict__ enc, size_t n, Aff* __restrict__ out, uint8_t* __restrict__ inf,
+__global__ void __launch_bounds__(256, 2)
+k_decode(const uint8_t* __restrict__ enc, size_t n, GfSqrTables T, Aff* __restrict__ out, uint8_t* __restrict__ inf,
          unsigned long long* __restrict__ err) {
+  extern __shared__ char lds_raw[];
+  GfLds L = gf_lds_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t top;
@@ -92,18 +95,18 @@ k_decode(const uint8_t* __restrict__ enc, size_t n, Aff* __restrict__ out, uint8
     Gf e = gf_add(w2, w);
     ok = !gf_is_zero(e);
     if (ok) {
-      Gf einv = gf_inv(e);
+      Gf einv = gf_inv_fast(e, T, L);
       Gf cst = gf_sqr(einv);  // 1/e^2
       ok = gf_trace(cst) == 0;
       if (ok) {
-        Gf z = gf_halftrace(cst);
+        Gf z = gf_sqr_tab(cst, T.th);   // half-trace: z^2 + z = 1/e^2
         Gf lam = gf_add(w2, gf_one());  // x + y/x
         Aff c0, c1;
-        c0.x = gf_mul(e, z);
+        c0.x = gf_mul(e, z, L);
         c1.x = gf_add(c0.x, e);
-        c0.y = gf_mul(c0.x, gf_add(lam, c0.x));
-        c1.y = gf_mul(c1.x, gf_add(lam, c1.x));
-        bool s0 = k233_in_subgroup(c0), s1 = k233_in_subgroup(c1);
+        c0.y = gf_mul(c0.x, gf_add(lam, c0.x), L);
+        c1.y = gf_mul(c1.x, gf_add(lam, c1.x), L);
+        bool s0 = k233_in_subgroup(c0, T, L), s1 = k233_in_subgroup(c1, T, L);
         if (s0) r = c0; else if (s1) r = c1; else ok = false;
       }
     }
@@ -246,7 +249,10 @@ int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipSt
   DevBuf err;
   DVP_TRY(err.alloc(8));
   DVP_HIP(hipMemsetAsync(err.p, 0xff, 8, st));
-  hipLaunchKernelGGL(k_decode, dim3(cdiv(n, 256)), dim3(256), 0, st, d_enc, n, d_out, d_inf, err.as<unsigned long long>());
+  GfSqrTables T;
+  DVP_TRY(gf_sqr_tables(&T, st));
+  hipLaunchKernelGGL(k_decode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, d_enc, n, T, d_out, d_inf,
+                     err.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   return read_err(err.as<unsigned long long>(), st, DVP_EDECODE);
 }

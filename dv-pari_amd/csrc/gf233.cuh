@@ -329,6 +329,7 @@ struct GfSqrTables {
   const Gf* t29;
   const Gf* t58;
   const Gf* t116;
+  const Gf* th;  // the half-trace (also GF(2)-linear): th[pos][byte] = H(byte * z^(8 pos))
 };
 GF_DEV Gf gf_sqr_tab(const Gf& a, const Gf* __restrict__ T) {
   Gf r = gf_zero();

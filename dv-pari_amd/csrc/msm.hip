@@ -553,13 +553,18 @@ k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const 
 }
 
 // ---- multi-squaring tables for the fast inversion (gf233.cuh) ----------------------------------------
-__global__ void __launch_bounds__(256) k_build_sqr_tables(Gf* __restrict__ t29, Gf* __restrict__ t58, Gf* __restrict__ t116) {
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;  // 3 * 30 * 256 entries
-  if (tid >= 3 * 30 * 256) return;
+__global__ void __launch_bounds__(256)
+k_build_sqr_tables(Gf* __restrict__ t29, Gf* __restrict__ t58, Gf* __restrict__ t116, Gf* __restrict__ th) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;  // 4 * 30 * 256 entries
+  if (tid >= 4 * 30 * 256) return;
   uint32_t which = tid / (30 * 256), e = tid - which * 30 * 256, pos = e >> 8, byte = e & 255;
   Gf v = gf_zero();
   v.w[pos >> 2] = byte << (8 * (pos & 3));
   if (pos == 29) v.w[7] &= 0x1FFu;  // bits >= 233 never occur in a reduced element
+  if (which == 3) {
+    th[e] = gf_halftrace(v);
+    return;
+  }
   int k = which == 0 ? 29 : which == 1 ? 58 : 116;
   v = gf_sqr_n(v, k);
   (which == 0 ? t29 : which == 1 ? t58 : t116)[e] = v;
@@ -573,8 +578,8 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
   std::lock_guard<std::mutex> g(g_sqr_mu);
   if (!g_sqr_tab[dev]) {
     Gf* t;
-    DVP_HIP(hipMalloc((void**)&t, (size_t)3 * 30 * 256 * sizeof(Gf)));
-    hipLaunchKernelGGL(k_build_sqr_tables, dim3(cdiv(3 * 30 * 256, 256)), dim3(256), 0, st, t, t + 30 * 256, t + 2 * 30 * 256);
+    DVP_HIP(hipMalloc((void**)&t, (size_t)4 * 30 * 256 * sizeof(Gf)));
+    hipLaunchKernelGGL(k_build_sqr_tables, dim3(cdiv(4 * 30 * 256, 256)), dim3(256), 0, st, t, t + 30 * 256, t + 2 * 30 * 256, t + 3 * 30 * 256);
     DVP_HIP(hipGetLastError());
     DVP_HIP(hipStreamSynchronize(st));
     g_sqr_tab[dev] = t;
@@ -582,6 +587,7 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
   out->t29 = g_sqr_tab[dev];
   out->t58 = g_sqr_tab[dev] + 30 * 256;
   out->t116 = g_sqr_tab[dev] + 2 * 30 * 256;
+  out->th = g_sqr_tab[dev] + 3 * 30 * 256;
   return DVP_OK;
 }
 
