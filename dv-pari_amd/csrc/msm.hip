@@ -805,11 +805,13 @@ __global__ void __launch_bounds__(EC_TPB, 2) k_merge(Ld* __restrict__ A, int j, 
 }
 
 // E[w*c+t] = tau^(w*c+t)( A[w*2^c + 1 + t] )
-__global__ void __launch_bounds__(64) k_frob(const Ld* __restrict__ A, int c, int W, Ld* __restrict__ E) {
+// (window w starts at digit w*c - min(w, n_narrow): the first n_narrow windows are c-1 digits wide)
+__global__ void __launch_bounds__(64) k_frob(const Ld* __restrict__ A, int c, int W, int n_narrow, Ld* __restrict__ E) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (uint32_t)(W * c)) return;
   uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
-  E[tid] = ld_frob_n(A[((size_t)w << c) + 1 + t], (int)tid);
+  int first = (int)(w * (uint32_t)c) - min((int)w, n_narrow);
+  E[tid] = ld_frob_n(A[((size_t)w << c) + 1 + t], first + (int)t);
 }
 
 // out[i] = in[2i] + in[2i+1]   (in[count] treated as infinity when count is odd)
@@ -874,7 +876,7 @@ static MsmWorkspace g_ws;
 
 struct MsmPlan {
   uint32_t n;
-  int c, W;
+  int c, W, n_narrow;
   uint32_t K, nkeys;
   size_t e_max, t1_max, t2_max;
 };
@@ -903,20 +905,30 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   const bool fixed = fx != nullptr;
   MsmPlan p;
   p.n = (uint32_t)n;
-  // cost model: ceil(240/c) * (8.4 n + 28 * 2^c) field multiplications
+  // cost model: W(c) * (8.4 n + 28 * 2^c) field multiplications.  Windows are evened out as in the fixed-base mode
+  // (see MsmFixedCtx): the 234 real digits go into ceil(234/c) windows of c or c-1 digits (narrow ones first), the
+  // digits above them (never seen beyond 236) into overflow windows.  A uniform 240/c split left a short top window
+  // whose entries all fell into a few dozen buckets and serialised the reducer.
+  auto windows = [](int c, int* n_narrow) {
+    int w_main = (234 + c - 1) / c;
+    *n_narrow = w_main * c - 234;
+    return w_main + (TAU_DIGITS - 234 + c - 1) / c;
+  };
   double best = 1e300;
   p.c = 4;
+  int nn;
   for (int c = 4; c <= 15; ++c) {  // <= 15: the sort keeps 2^c u32 cursors in LDS
-    int W = (TAU_DIGITS + c - 1) / c;
+    int W = windows(c, &nn);
     double cost = W * (8.4 * (double)n + 28.0 * (double)(1u << c));
     if (cost < best) { best = cost; p.c = c; }
   }
   if (const char* e = getenv("DVP_MSM_C")) { int c = atoi(e); if (c >= 2 && c <= 15) p.c = c; }
-  p.W = (TAU_DIGITS + p.c - 1) / p.c;
+  p.W = windows(p.c, &p.n_narrow);
   p.nkeys = (uint32_t)p.W << p.c;
   if (fixed) {  // all windows share one bucket set (bases pre-rotated by tau^(c w))
     p.c = fx->c;
     p.W = fx->W;
+    p.n_narrow = fx->n_narrow;
     p.nkeys = 1u << fx->c;
   }
   p.e_max = n * (size_t)p.W;
@@ -1042,10 +1054,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
   if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
-                       (uint32_t)n, p.c, p.W, fx->n_narrow, digits32, err);
+                       (uint32_t)n, p.c, p.W, p.n_narrow, digits32, err);
   else
     hipLaunchKernelGGL((k_recode<uint16_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
-                       (uint32_t)n, p.c, p.W, 0, digits, err);
+                       (uint32_t)n, p.c, p.W, p.n_narrow, digits, err);
   if (fx) {
     const uint32_t gmax = fx_nblk + FX_NP;  // upper bound on the number of level-2 chunks
     hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
@@ -1084,7 +1096,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipStreamSynchronize(st));
   size_t aff_min = (size_t)1 << 19;
   if (const char* e = getenv("DVP_MSM_AFF_MIN")) aff_min = (size_t)atoll(e);
-  const size_t e_est = fx ? (size_t)n * (size_t)(p.W - 1) : p.e_max;  // the overflow window of the fixed-base split is empty
+  const size_t e_est = (size_t)n * (size_t)((234 + p.c - 1) / p.c);  // the overflow windows are empty in practice
   int ra = 0;
   if (affine_mode)
     while (((uint64_t)1 << ra) < max_cnt && (e_est >> (ra + 1)) >= aff_min) ++ra;
@@ -1168,7 +1180,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;
   Ld* tb = tail + cntT;
-  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, ta);
+  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, ta);
   while (cntT > 1) {
     uint32_t half = (cntT + 1) / 2;
     hipLaunchKernelGGL(k_pair_add, dim3(cdiv(4 * half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
