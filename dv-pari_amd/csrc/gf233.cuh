@@ -348,6 +348,13 @@ GF_DEV Gf gf_sqr_tab(const Gf& a, const Gf* __restrict__ T) {
   }
   return r;
 }
+// a^(2^k) for any k: table passes for the 116 / 58 / 29 parts, plain squarings for the rest (< 29)
+GF_DEV Gf gf_sqr_n_fast(Gf a, int k, const GfSqrTables& T) {
+  while (k >= 116) { a = gf_sqr_tab(a, T.t116); k -= 116; }
+  if (k >= 58) { a = gf_sqr_tab(a, T.t58); k -= 58; }
+  if (k >= 29) { a = gf_sqr_tab(a, T.t29); k -= 29; }
+  return gf_sqr_n(a, k);
+}
 // a^(2^233-2) with table-driven runs; products through the LDS multiplier.  a == 0 -> 0.
 template <class LT>
 GF_DEV Gf gf_inv_fast(const Gf& a, const GfSqrTables& T, const LT& L) {

@@ -806,12 +806,17 @@ __global__ void __launch_bounds__(EC_TPB, 2) k_merge(Ld* __restrict__ A, int j, 
 
 // E[w*c+t] = tau^(w*c+t)( A[w*2^c + 1 + t] )
 // (window w starts at digit w*c - min(w, n_narrow): the first n_narrow windows are c-1 digits wide)
-__global__ void __launch_bounds__(64) k_frob(const Ld* __restrict__ A, int c, int W, int n_narrow, Ld* __restrict__ E) {
+__global__ void __launch_bounds__(64)
+k_frob(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ E) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (uint32_t)(W * c)) return;
   uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
-  int first = (int)(w * (uint32_t)c) - min((int)w, n_narrow);
-  E[tid] = ld_frob_n(A[((size_t)w << c) + 1 + t], first + (int)t);
+  int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
+  Ld p = A[((size_t)w << c) + 1 + t];
+  p.X = gf_sqr_n_fast(p.X, k, T);  // up to 239 squarings per coordinate: table passes, not a serial chain
+  p.Y = gf_sqr_n_fast(p.Y, k, T);
+  p.Z = gf_sqr_n_fast(p.Z, k, T);
+  E[tid] = p;
 }
 
 // out[i] = in[2i] + in[2i+1]   (in[count] treated as infinity when count is odd)
@@ -1180,7 +1185,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;
   Ld* tb = tail + cntT;
-  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, ta);
+  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, Tsq, ta);
   while (cntT > 1) {
     uint32_t half = (cntT + 1) / 2;
     hipLaunchKernelGGL(k_pair_add, dim3(cdiv(4 * half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
