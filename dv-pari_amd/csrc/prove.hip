@@ -322,8 +322,8 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
   DVP_TRY(A((void**)&p->E2, 4 * m * sizeof(Fr)));
   DVP_TRY(A((void**)&p->r2, m * sizeof(Fr)));
   DVP_TRY(A((void**)&p->SA, (n_wires + m) * sizeof(Fr)));
-  DVP_TRY(A((void**)&p->den, m * sizeof(Fr)));
-  DVP_TRY(A((void**)&p->den2, m * sizeof(Fr)));
+  DVP_TRY(A((void**)&p->den, 2 * m * sizeof(Fr)));  // [den | den2]: one batch inversion covers both
+  p->den2 = p->den + m;
   DVP_TRY(A((void**)&p->SK, 4 * m * sizeof(Fr)));
   DVP_TRY(A((void**)&p->partial, 3 * 1024 * sizeof(Fr)));
   DVP_TRY(A((void**)&p->abir0, 4 * sizeof(Fr)));
@@ -349,7 +349,7 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
 extern "C" void dvp_prover_destroy(dvp_prover* p) {
   if (!p) return;
   void* ptrs[] = {p->dD, p->dD2, p->barw, p->z2inv, p->coeffs_m, p->bases_a, p->inf_a, p->bases_k, p->inf_k, p->w, p->E,
-                  p->E2, p->r2, p->SA, p->den, p->den2, p->SK, p->partial, p->abir0, p->flags, p->pts, p->pts_inf32,
+                  p->E2, p->r2, p->SA, p->den, p->SK, p->partial, p->abir0, p->flags, p->pts, p->pts_inf32,
                   p->pts_inf8, p->enc};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
@@ -598,8 +598,7 @@ extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const
   Fr alpha_m = fr_to_mont(alpha);
   Fr z_alpha_m = host_vanish(p, 0, alpha_m);
   hipLaunchKernelGGL(k_alpha_denoms, gm, bt, 0, st, p->dD, p->dD2, alpha_m, m, p->den, p->den2, p->flags + 1);
-  DVP_TRY(batch_inverse_dev(p->den, m, st));
-  DVP_TRY(batch_inverse_dev(p->den2, m, st));
+  DVP_TRY(batch_inverse_dev(p->den, 2 * (size_t)m, st));  // den2 = den + m
   uint32_t nb = cdiv(m, PT);
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(k_bary3_partial, dim3(nb), bt, 0, st, p->E, p->barw, p->den, m, p->partial);
