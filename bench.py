@@ -12,7 +12,7 @@ index range over the ranks and combined by all-gather + local add (strong scalin
 fixed).  Rank 0 prints ONE JSON line; the proof of the last step is checked with the designated-
 verifier equation (src/srs.rs:374-428) outside the timed region.
 
-roofline: dominant kernel = dvp::k_affine_round<true> (first batched-affine pair round of the MSM bucket
+roofline: dominant kernel = dvp::k_affine_round<true, B> (first batched-affine pair round of the MSM bucket
 accumulation: it gathers every base once per window); algorithmic bytes = 96 B per (scalar, base) pair
  x pairs per launch, divided by the launch time measured with HIP events on the launch
 stream (dvp_profile_*).  The kernel is bound by GF(2^233) products (integer VALU + LDS; no carry-less
@@ -159,7 +159,10 @@ def main():
     sizes = [pv.msm_size(0), pv.msm_size(1)]
     # effective windows: tau-adic expansions are ~234 digits long, the last allocated window is mostly empty
     w_eff = sum(-(-234 // max(c, 1)) * n for (c, _), n in zip(plans, sizes)) / max(sum(sizes), 1) if all(c for c, _ in plans) else 16
-    mul_eq = pairs_per_launch * w_eff * 0.5 * 6.1
+    # per addition: 5 products + 1 squaring (~0.13) + 1/B of a table-driven inversion (~15 product-equivalents); the first
+    # round of an MSM this size runs the B = 32 flavour
+    per_add = 5.13 + 15.0 / (32 if pairs_per_launch * w_eff * 0.5 >= (8 << 20) else 16)
+    mul_eq = pairs_per_launch * w_eff * 0.5 * per_add
     mul_ceiling = 31.6e9
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
@@ -191,7 +194,7 @@ def main():
             "witness": "resident in HBM",
         },
         "roofline": {
-            "kernel": "dvp::k_affine_round<true>",
+            "kernel": "dvp::k_affine_round<true, 32>",
             "bound": "hbm",
             "achieved": achieved,
             "peak": 8000.0,
@@ -203,8 +206,8 @@ def main():
             "algorithmic_bytes_per_launch": 96.0 * pairs_per_launch,
             "work_model": {
                 "note": "kernel is bound by GF(2^233) products (integer VALU + LDS table reads; gfx950 has no carry-less "
-                        "multiply): W/2 affine additions per pair at ~6.1 products each; ceiling = measured rate of the "
-                        "multiplier alone",
+                        "multiply): W/2 affine additions per pair at 5 products + 1 squaring + 1/B inversion each (~5.6 at B = 32); "
+                        "ceiling = measured rate of the multiplier alone",
                 "mul_equivalents_per_launch": mul_eq,
                 "achieved_mul_per_s": mul_eq / (acc_avg_ms * 1e-3) if acc_n else 0.0,
                 "multiplier_microbench_mul_per_s": mul_ceiling,

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "k_affine_round<true>"
+KERNEL = "k_affine_round<true"
 
 
 def one(pattern):
@@ -48,7 +48,7 @@ write, d2 = pmc("pmc_write", "WRITE_SIZE")
 assert fetch and write and len(fetch) == len(write), (len(fetch), len(write))
 avg_f, avg_w = sum(fetch) / len(fetch), sum(write) / len(write)
 out = {
-    "kernel": "dvp::k_affine_round<true>",
+    "kernel": "dvp::k_affine_round<true, B> (B = 32 additions per inversion in these launches, 16 in small rounds)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
     "launches": len(fetch),
     "avg_FETCH_SIZE_KB": avg_f,
