@@ -200,3 +200,20 @@ def test_points_add_like_curvepoint_add(dvp):
     exp = [o2.k233_add(a[0], b[0]), o2.k233_add(a[1], a[1]), None, b[3], a[4], None]
     for i, e in enumerate(exp):
         assert np_to_pt(xy[i], bool(inf[i])) == e, i
+
+
+def test_msm_2_20_linearity(dvp):
+    """full-size property (the reference's own MSM test is linearity, src/curve.rs:198-232): with one base vector of
+    2^20 points, MSM(s) + MSM(t) == MSM(s + t) and MSM(3 s) == 3 MSM(s), for both the one-shot and the fixed-base path"""
+    n = 1 << 20
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(rand_fr_np(n, 81))
+    s, t = rand_fr_np(n, 82), rand_fr_np(n, 83)
+    si, ti = from_limbs(s), from_limbs(t)
+    st_sum = to_limbs([(a + b) % o.P for a, b in zip(si, ti)])
+    s3 = to_limbs([3 * a % o.P for a in si])
+    fb = dvp.curve.FixedBaseMsm(bases)
+    for run in (lambda sc: gpu_msm(dvp, sc, bases), lambda sc: np_to_pt(*fb.run(sc))):
+        ps, pt, pst, p3 = run(s), run(t), run(st_sum), run(s3)
+        assert o.k233_add(ps, pt) == pst
+        assert o.k233_add(o.k233_add(ps, ps), ps) == p3
+    assert gpu_msm(dvp, s, bases) == np_to_pt(*fb.run(s))
