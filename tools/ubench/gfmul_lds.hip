@@ -44,7 +44,7 @@ template <int K, int NW> __device__ __forceinline__ void row_x(u32* acc, const G
     if (j + 7 < 15) acc[j + 7] ^= hi[j].w;
   }
 }
-__device__ __noinline__ Gf gf_mul_tab_x(const Gf& a, const GfLds& c) {
+__device__ __forceinline__ Gf gf_mul_tab_x(const Gf& a, const GfLds& c) {
   u32 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0;
