@@ -782,7 +782,7 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 // QUAD: the deep levels have far fewer additions than the chip has lanes and are pure latency; there the four lanes
 // of a quad share one addition (gf233.cuh, quad-cooperative product), 2.2x shorter per level.
 template <bool QUAD>
-__global__ void __launch_bounds__(EC_TPB, 2) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+__global__ void __launch_bounds__(EC_TPB, QUAD ? 1 : 2) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (QUAD) tid >>= 2;
