@@ -628,11 +628,12 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
   // pre-pass: slot -> (first input index, has-partner flag in bit 31); 0xffffffff = no slot.  The AFF_B binary
   // searches over the key offsets advance in lockstep, so each step has AFF_B independent loads in flight instead of
   // one (18 dependent L2 round trips per slot, one slot after the other, used to cost as much as the additions).
+  constexpr int PB = B < AFF_B ? B : AFF_B;  // searches advancing together
 #pragma unroll 1
-  for (int k0 = 0; k0 < B; k0 += AFF_B) {
-    uint32_t lo[AFF_B], hi[AFF_B], sv[AFF_B];
+  for (int k0 = 0; k0 < B; k0 += PB) {
+    uint32_t lo[PB], hi[PB], sv[PB];
 #pragma unroll
-    for (int k = 0; k < AFF_B; ++k) {
+    for (int k = 0; k < PB; ++k) {
       sv[k] = min((uint32_t)(k0 + k) * nthr + tid, total - 1);
       lo[k] = 0;
       hi[k] = nkeys;  // invariant: ooff[lo] <= s < ooff[hi]
@@ -640,24 +641,24 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
     const int steps = nkeys > 1 ? 32 - __builtin_clz(nkeys - 1) : 0;
 #pragma unroll 1
     for (int it = 0; it < steps; ++it) {
-      uint32_t v[AFF_B];
+      uint32_t v[PB];
 #pragma unroll
-      for (int k = 0; k < AFF_B; ++k) v[k] = ooff[(lo[k] + hi[k]) >> 1];
+      for (int k = 0; k < PB; ++k) v[k] = ooff[(lo[k] + hi[k]) >> 1];
 #pragma unroll
-      for (int k = 0; k < AFF_B; ++k) {
+      for (int k = 0; k < PB; ++k) {
         uint32_t mid = (lo[k] + hi[k]) >> 1;  // hi - lo == 1 gives mid == lo: a no-op step
         if (v[k] <= sv[k]) lo[k] = mid; else hi[k] = mid;
       }
     }
-    uint32_t o0[AFF_B], o1[AFF_B], cn[AFF_B];
+    uint32_t o0[PB], o1[PB], cn[PB];
 #pragma unroll
-    for (int k = 0; k < AFF_B; ++k) {
+    for (int k = 0; k < PB; ++k) {
       o0[k] = ooff[lo[k]];
       o1[k] = off[lo[k]];
       cn[k] = cnt[lo[k]];
     }
 #pragma unroll
-    for (int k = 0; k < AFF_B; ++k) {
+    for (int k = 0; k < PB; ++k) {
       uint32_t sk = (uint32_t)(k0 + k) * nthr + tid, d = 0xffffffffu;
       if (sk < total) {
         uint32_t j = sk - o0[k];
@@ -979,7 +980,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
                           (const void*)k_affine_round<true, 16>, (const void*)k_affine_round<false, 16>,
-                          (const void*)k_affine_round<true, 32>, (const void*)k_affine_round<false, 32>};
+                          (const void*)k_affine_round<true, 32>, (const void*)k_affine_round<false, 32>,
+                          (const void*)k_affine_round<true, 8>, (const void*)k_affine_round<false, 8>,
+                          (const void*)k_affine_round<true, 4>, (const void*)k_affine_round<false, 4>};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS);
     });
@@ -1121,20 +1124,26 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
       size_t out_max = cap / 2 + nk + 1;
       Aff* outp = (r & 1) ? affB : affA;
-      // big rounds share one inversion among 32 additions, small ones among 16 (they need the threads)
-      size_t b32_min = (size_t)8 << 20;
+      // slots per inversion: big rounds 32 (fewer inversions per addition), then 16; rounds too small to fill the chip
+      // with 16-slot threads get 8 or 4, whose threads are short (the round is pure latency by then)
+      size_t b32_min = (size_t)8 << 20, b16_min = (size_t)1 << 21, b8_min = (size_t)1 << 20;
       if (const char* e = getenv("DVP_MSM_B32_MIN")) b32_min = (size_t)atoll(e);
-      const bool big = out_max >= b32_min;
-      uint32_t grid = cdiv(cdiv(out_max, big ? 32 : AFF_B), EC_TPB);
+      if (const char* e = getenv("DVP_MSM_B16_MIN")) b16_min = (size_t)atoll(e);
+      if (const char* e = getenv("DVP_MSM_B8_MIN")) b8_min = (size_t)atoll(e);
+      const int bsel = out_max >= b32_min ? 32 : out_max >= b16_min ? 16 : out_max >= b8_min ? 8 : 4;
+      uint32_t grid = cdiv(cdiv(out_max, bsel), EC_TPB);
 #define DVP_AFF_LAUNCH(FIRST, BB) \
   hipLaunchKernelGGL((k_affine_round<FIRST, BB>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, gdesc, outp)
+#define DVP_AFF_PICK(FIRST) \
+  do { if (bsel == 32) DVP_AFF_LAUNCH(FIRST, 32); else if (bsel == 16) DVP_AFF_LAUNCH(FIRST, 16); else if (bsel == 8) DVP_AFF_LAUNCH(FIRST, 8); else DVP_AFF_LAUNCH(FIRST, 4); } while (0)
       if (r == 0) {
         ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // the dominant kernel: first pair round (gathers the bases)
-        if (big) DVP_AFF_LAUNCH(true, 32); else DVP_AFF_LAUNCH(true, 16);
+        DVP_AFF_PICK(true);
         ps0.stop();
       } else {
-        if (big) DVP_AFF_LAUNCH(false, 32); else DVP_AFF_LAUNCH(false, 16);
+        DVP_AFF_PICK(false);
       }
+#undef DVP_AFF_PICK
 #undef DVP_AFF_LAUNCH
       pts_in = outp;
       cap = out_max;
