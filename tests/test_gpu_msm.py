@@ -217,3 +217,31 @@ def test_msm_2_20_linearity(dvp):
         assert o.k233_add(ps, pt) == pst
         assert o.k233_add(o.k233_add(ps, ps), ps) == p3
     assert gpu_msm(dvp, s, bases) == np_to_pt(*fb.run(s))
+
+
+def test_fixed_base_vs_one_shot_randomised(dvp):
+    """differential sweep: every fixed-base window size 8..20 (evened windows, both sort flavours, 4/8/16-slot pair rounds)
+    against the one-shot path on random sub-ranges, plus scalars with long runs of zero / one digits"""
+    rnd = random.Random(2026)
+    n = 3000
+    k = rand_fr_np(n, 91)
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
+    s = rand_fr_np(n, 92)
+    special = [0, 1, 2, o.P - 1, o.P - 2, (1 << 231) - 1, 1 << 230, (1 << 116) + 1, 0xFFFFFFFFFFFFFFFF, (o.P - 1) // 2, 3 << 200]
+    s[: len(special)] = to_limbs(special)
+    ks, ss = from_limbs(k), from_limbs(s)
+    for c in range(8, 21):
+        os.environ["DVP_MSM_FIXED_C"] = str(c)
+        os.environ["DVP_MSM_AFF_MIN"] = str(rnd.choice([16, 256, 4096, 1 << 19]))
+        try:
+            fb = dvp.curve.FixedBaseMsm(bases)
+            for _ in range(3):
+                lo = rnd.randrange(0, n - 1)
+                hi = rnd.randrange(lo + 1, n + 1)
+                xy, is_inf = fb.run(s[lo:hi], lo, hi)
+                exp = co.k233_mulgen(sum(ss[i] * ks[i] for i in range(lo, hi)) % o.P)
+                assert np_to_pt(xy, is_inf) == exp, (c, lo, hi)
+                assert gpu_msm(dvp, s[lo:hi], bases[lo:hi]) == exp, (c, lo, hi)
+            fb.close()
+        finally:
+            del os.environ["DVP_MSM_FIXED_C"], os.environ["DVP_MSM_AFF_MIN"]
