@@ -75,6 +75,7 @@ _SIGS = {
     "dvp_prove": (C.c_int, [vp, u64p, u32, u64p, u32, u8p]),
     "dvp_prove_dev": (C.c_int, [vp, vp, u8p, vp]),
     "dvp_prove_begin": (C.c_int, [vp, vp, vp]),
+    "dvp_prove_begin_partial": (C.c_int, [vp, vp, C.c_int, vp]),
     "dvp_prover_msm_size": (C.c_size_t, [vp, C.c_int]),
     "dvp_prover_msm_plan": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dvp_prover_msm_partial": (C.c_int, [vp, C.c_int, sz, sz, vp, vp, vp]),

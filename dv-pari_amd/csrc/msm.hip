@@ -1222,7 +1222,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 
 // ---- fixed-base contexts (the prover's SRS vectors) -----------------------------------------------
 // range_hint = number of bases a typical call will cover (the per-GPU shard): the shared window size c
-// minimises W(c) * range * 6.1 (pair additions) + 28 * 2^c (bucket merge) in field multiplications
+// minimises an empirical cost in field multiplications (pair additions + a per-bucket term, see below)
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
@@ -1230,7 +1230,10 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
   int best_c = 8;
   for (int cc = 8; cc <= FX_C_MAX; ++cc) {
     int w_main = (234 + cc - 1) / cc;
-    double cost = (double)w_main * (double)range_hint * 6.1 + 40.0 * (double)(1u << cc);
+    // pair additions at ~5.6 product-equivalents + a per-bucket term for merge/reducer/sort; measured on MI355X at 2^20
+    // constraints: c = 18 beats 16, 17, 19 and 20 for every shard from 0.26 M to 4.2 M pairs, c = 20 wins from ~8 M pairs
+    double cost = (double)w_main * (double)range_hint * 5.6 + 10.0 * (double)(1u << cc) +
+                  (cc > 18 ? 25.0 * (double)((1u << cc) - (1u << 18)) : 0.0);
     if (cost < best) { best = cost; best_c = cc; }
   }
   if (const char* e = getenv("DVP_MSM_FIXED_C")) { int cc = atoi(e); if (cc >= 8 && cc <= FX_C_MAX) best_c = cc; }

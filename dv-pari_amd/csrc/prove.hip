@@ -506,6 +506,13 @@ static bool prover_ready(dvp_prover* p) {
 // phase 1 (src/proving.rs:434-508): assignment -> a,b,c',i -> extend -> q2; leaves SA = [w | q2].
 // d_assignment: n_wires canonical Fr = [1, public.., private..] already in HBM.
 extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream) {
+  return dvp_prove_begin_partial(p, d_assignment, 1, stream);
+}
+
+// need_extend == 0: the caller's MSM shards lie inside [w] and [k_a | k_b] only, which need neither q2 nor r2, so the
+// three extends and the quotient are skipped (multi-GPU load balancing, distributed.py::shard_plan).  q2 / r2 and the
+// k_r part of the second MSM's scalars are then NOT valid on this prover until the next full begin.
+extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream) {
   if (!p || !d_assignment || !prover_ready(p)) return DVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
@@ -519,6 +526,18 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
   Csr C{p->mat[2].row_ptr, p->mat[2].wire, p->mat[2].coeff, p->mat[2].n_rows};
   dim3 gm(cdiv(m, PT)), bt(PT);
   hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, p->n_pub, m, p->E, p->flags);
+  DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  if (!need_extend) {
+    DVP_HIP(hipGetLastError());
+    unsigned long long f0[2];
+    DVP_HIP(hipMemcpyAsync(f0, p->flags, 16, hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+    if (f0[0] != ~0ull) {
+      g_last_error_index = (int64_t)f0[0];
+      return DVP_EUNSAT;
+    }
+    return DVP_OK;
+  }
   // extend_evals (src/proving.rs:410-422): a, b, c' always; i only when its degree makes Horner the dearer route
   uint32_t hmax = HORNER_MAX_PUB;
   if (const char* e = getenv("DVP_HORNER_MAX_PUB")) hmax = (uint32_t)atoi(e);  // tests force either route
@@ -530,7 +549,6 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
     DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2, n_ext, st));
     pe.stop();
   }
-  DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   if (horner)
     hipLaunchKernelGGL(k_quotient<true>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
   else

@@ -3,7 +3,9 @@
 Only the two MSMs shard (they are sums over disjoint index ranges): every rank runs the
 cheap Fr stages redundantly on its own copy of the data, computes the partial sum of its contiguous
 slice of (scalars, bases), and the partial points are combined with ONE all-gather of 80 bytes per
-rank followed by a local N-term addition.  RCCL has no reduction operator for elliptic-curve points,
+rank followed by a local N-term addition.  The slices are not uniform (shard_plan): the scalars [w] of the first
+MSM and [k_a | k_b] of the second need no extended evaluations, so the ranks that own only those skip the three
+ECFFT extends and take a larger share of the MSM work in exchange.  RCCL has no reduction operator for elliptic-curve points,
 so "all-reduce of partial bucket sums" is realised as all-gather + local add; the message is
 latency-bound (<= 640 B on 8 GPUs), xGMI bandwidth is irrelevant here.
 
@@ -19,6 +21,43 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_plan(world: int, n_wires: int, m: int, extend_pairs: float = None):
+    """Per-rank (range of MSM 0, range of MSM 1, need_extend).  MSM 0 runs over [w (n_wires) | q2 (m)], MSM 1 over
+    [k_a (m) | k_b (m) | k_r (2m)]; q2 and k_r need the extends (q2 itself, r2 inside k_r), the rest does not.  With s
+    "extender" ranks (the last s) and cost E of the extends expressed in (scalar, base) pairs, the non-extenders take X
+    pairs of the extend-free part and the extenders everything else; X equalises the two loads where the caps allow, and
+    s minimises the larger load.  s == world (uniform slices, every rank extends) is what small worlds get."""
+    ta, tb = n_wires + m, 4 * m
+    cap_a, cap_b = n_wires, 2 * m
+    e = 0.3 * m if extend_pairs is None else extend_pairs  # measured on MI355X: three extends of 2^20 ~ 0.3 M pairs of sharded MSM
+    best = None
+    for s in range(world, 0, -1):
+        if s == world:
+            x, load = 0.0, e + (ta + tb) / world
+        else:
+            x = min(float(cap_a + cap_b), (world - s) * (ta + tb + s * e) / world)
+            load = max(x / (world - s), e + (ta + tb - x) / s)
+        if best is None or load < best[0] * 0.98:  # prefer more extenders (simpler) unless the gain is real
+            best = (load, s, x)
+    _, s, x = best
+    plan = []
+    if s == world:
+        for r in range(world):
+            plan.append((shard_range(ta, r, world), shard_range(tb, r, world), True))
+        return plan
+    x_a = min(cap_a, int(round(x * cap_a / (cap_a + cap_b))))
+    x_b = min(cap_b, int(round(x)) - x_a)
+    n0 = world - s
+    for r in range(world):
+        if r < n0:
+            plan.append((shard_range(x_a, r, n0), shard_range(x_b, r, n0), False))
+        else:
+            lo_a, hi_a = shard_range(ta - x_a, r - n0, s)
+            lo_b, hi_b = shard_range(tb - x_b, r - n0, s)
+            plan.append(((x_a + lo_a, x_a + hi_a), (x_b + lo_b, x_b + hi_b), True))
+    return plan
+
+
 @dataclass
 class GpuBackend:
     """Default backend: dv-pari_amd.proving.Prover phases + torch CUDA tensors."""
@@ -32,8 +71,12 @@ class GpuBackend:
         self.part = torch.zeros(10, dtype=torch.int64, device=self.device)  # x||y (8 words) + inf flag (u32) + pad
         self.ones = None
 
-    def begin(self, assignment):
-        self.prover.begin(assignment.data_ptr(), self.torch.cuda.current_stream().cuda_stream)
+    def begin(self, assignment, need_extend=True):
+        self.prover.begin(assignment.data_ptr(), self.torch.cuda.current_stream().cuda_stream, need_extend)
+
+    def dims(self):
+        """(n_wires, m) of the instance: what shard_plan needs"""
+        return self.prover.inst.n_wires, self.prover.m
 
     def msm_size(self, which):
         return self.prover.msm_size(which)
@@ -74,10 +117,13 @@ def prove_sharded(backend, assignment, group=None):
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    backend.begin(assignment)
+    n_wires, m = backend.dims()
+    range_a, range_b, need_extend = shard_plan(world, n_wires, m)[rank]
+    backend.begin(assignment, need_extend)
+    assert backend.msm_size(0) == n_wires + m and backend.msm_size(1) == 4 * m
     proof = None
     for which in (0, 1):
-        lo, hi = shard_range(backend.msm_size(which), rank, world)
+        lo, hi = range_a if which == 0 else range_b
         part = backend.msm_partial(which, lo, hi)
         if world > 1:
             gathered = [torch.empty_like(part) for _ in range(world)]

@@ -198,8 +198,8 @@ class Prover:
         check(lib.dvp_prove_dev(self._h, d_assignment, ptr(out), stream), "dvp_prove_dev")
         return Proof.from_bytes(out.tobytes())
 
-    def begin(self, d_assignment: int, stream: int = 0):
-        check(lib.dvp_prove_begin(self._h, d_assignment, stream), "dvp_prove_begin")
+    def begin(self, d_assignment: int, stream: int = 0, need_extend: bool = True):
+        check(lib.dvp_prove_begin_partial(self._h, d_assignment, int(need_extend), stream), "dvp_prove_begin")
 
     def msm_size(self, which: int) -> int:
         return int(lib.dvp_prover_msm_size(self._h, which))

@@ -174,6 +174,9 @@ int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t proof[118], v
  * index range and their partial sums combined by the caller (all-gather + local add):
  *   begin -> msm_partial(0, lo, hi) -> challenge(commit point) -> msm_partial(1, lo, hi) -> finish */
 int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream);
+/* begin for a rank whose MSM shards need neither q2 nor r2 (they lie inside [w] and [k_a | k_b]): need_extend = 0
+ * skips the extends and the quotient; need_extend != 0 is dvp_prove_begin */
+int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream);
 size_t dvp_prover_msm_size(const dvp_prover* p, int which);
 /* window bits / window count chosen for MSM `which` (0,0 until its fixed-base tables exist) */
 int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows);

@@ -60,12 +60,18 @@ def _worker(rank, world, port, q):
     class OracleBackend:
         """same protocol as distributed.GpuBackend, arithmetic by the C oracle"""
 
-        def begin(self, assignment):
+        def dims(self):
+            return 8, 8  # n_wires, m of the toy instance
+
+        def begin(self, assignment, need_extend=True):
             self.state = {}
             self.w = assignment
             self.pr = o.prove_scalars(tree, st, assignment[1:3], assignment[3:], self._alpha)
             gk = st["g_k"][0] + st["g_k"][1] + st["g_k"][2]
             self.sc = [self.pr["w"] + self.pr["q2"], self.pr["s_k"]]
+            if not need_extend:  # a rank that skips the extends has no q2 and no k_r: poison them
+                self.sc[0] = self.sc[0][:8] + [12345] * 8
+                self.sc[1] = self.sc[1][:16] + [54321] * 16
             self.bases = [[co.k233_mulgen(k) for k in st["g_m"] + st["g_q"]], [co.k233_mulgen(k) for k in gk]]
 
         def _alpha(self, dl):
@@ -104,7 +110,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_prove_sharded_world2_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_prove_sharded_gloo(world):
+    """world 2: uniform slices; world 3: one rank skips the extends (distributed.shard_plan) and owns only [w], [k_a|k_b]"""
     import torch.multiprocessing as mp
 
     s = socket.socket()
@@ -113,7 +121,7 @@ def test_prove_sharded_world2_gloo():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -121,4 +129,4 @@ def test_prove_sharded_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
-    assert res[0][2] == res[1][2]  # every rank holds the same commitment
+    assert len({h for _, _, h in res}) == 1  # every rank holds the same commitment

@@ -189,18 +189,31 @@ def test_sharded_prove_simulated_ranks(dvp, world):
     dev = torch.device("cuda", 0)
     be = dvp.distributed.GpuBackend(pv, dev)
     assignment = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
-    be.begin(assignment)
-    proof = None
-    for which in (0, 1):
-        parts = []
-        for r in range(world):
-            lo, hi = dvp.distributed.shard_range(be.msm_size(which), r, world)
-            parts.append(be.msm_partial(which, lo, hi).clone())
-        point = be.combine(torch.stack(parts))
-        if which == 0:
-            be.challenge(point)
-        else:
-            proof = be.finish(point)
+    # every simulated rank re-runs its own begin (with or without the extends, as shard_plan says) and, for the second
+    # MSM, its own challenge.  Ranks that skip the extends run on a SECOND prover that never computed q2 / r2 / k_r, so
+    # reading any of them would change the result.
+    plan = dvp.distributed.shard_plan(world, *be.dims())
+    pv2 = dvp.proving.Prover(inst)
+    pv2.set_srs(dvp.srs.verifier_runs_setup(pv2, inst, td))
+    be2 = dvp.distributed.GpuBackend(pv2, dev)
+    parts = []
+    for r in range(world):
+        (lo, hi), _, need = plan[r]
+        b = be if need else be2
+        b.begin(assignment, need)
+        parts.append(b.msm_partial(0, lo, hi).clone())
+    commit = be.combine(torch.stack(parts))
+    parts = []
+    for r in range(world):
+        _, (lo, hi), need = plan[r]
+        b = be if need else be2
+        b.begin(assignment, need)
+        b.challenge(commit)
+        parts.append(b.msm_partial(1, lo, hi).clone())
+    be.begin(assignment, True)
+    be.challenge(commit)
+    proof = be.finish(be.combine(torch.stack(parts)))
+    pv2.close()
     assert proof == ref and dvp.srs.verify(td, pub, proof)
 
 

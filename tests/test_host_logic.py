@@ -67,3 +67,28 @@ def test_fr_limb_helpers(dvp):
     arr = dvp.fr.vec(vals)
     assert arr.shape == (4, 4) and dvp.fr.to_ints(arr) == vals
     assert dvp.fr.to_int(dvp.fr.limbs(o.P + 5)) == 5
+
+
+def test_shard_plan_roles_and_coverage(dvp):
+    """distributed.shard_plan: contiguous cover of both MSM index spaces, ranks that skip the extends stay inside the
+    extend-free parts, and the modelled loads are balanced within a few percent"""
+    d = dvp.distributed
+    for n_wires, m in ((1 << 20, 1 << 20), (3_000_000, 1 << 22), (8, 8), (100, 1 << 10)):
+        for world in (1, 2, 3, 4, 5, 6, 7, 8):
+            plan = d.shard_plan(world, n_wires, m)
+            assert len(plan) == world
+            for idx, total in ((0, n_wires + m), (1, 4 * m)):
+                rs = [p[idx] for p in plan]
+                assert rs[0][0] == 0 and rs[-1][1] == total
+                assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
+                assert all(lo <= hi for lo, hi in rs)
+            ext = [p[2] for p in plan]
+            assert ext[-1] and ext == sorted(ext)  # extenders are the last ranks, at least one
+            for (a, b, need) in plan:
+                if not need:
+                    assert a[1] <= n_wires and b[1] <= 2 * m
+            if m >= 1 << 20:
+                loads = [(a[1] - a[0]) + (b[1] - b[0]) + (0.3 * m if need else 0) for a, b, need in plan]
+                assert max(loads) <= 1.03 * (sum(loads) / world) or all(ext)
+    assert all(need for _, _, need in d.shard_plan(2, 1 << 20, 1 << 20))       # small worlds: uniform
+    assert not d.shard_plan(8, 1 << 20, 1 << 20)[0][2]                           # 8 ranks: some skip the extends

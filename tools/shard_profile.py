@@ -31,19 +31,29 @@ def timed(f):
 
 
 for world in [int(x) for x in os.environ.get("SHARD_WORLDS", "1,2,4,8").split(",")]:
-    acc = None
-    for rep in range(4):
-        ph = {}
-        _, ph["begin"] = timed(lambda: be.begin(assignment))
-        lo, hi = dvp.distributed.shard_range(be.msm_size(0), 0, world)
-        _, ph["msmA_part"] = timed(lambda: be.msm_partial(0, lo, hi))
-        full, _ = timed(lambda: be.msm_partial(0, 0, be.msm_size(0)).clone())
-        _, ph["challenge"] = timed(lambda: be.challenge(full))
-        lo, hi = dvp.distributed.shard_range(be.msm_size(1), 0, world)
-        _, ph["msmB_part"] = timed(lambda: be.msm_partial(1, lo, hi))
-        full, _ = timed(lambda: be.msm_partial(1, 0, be.msm_size(1)).clone())
-        _, ph["finish"] = timed(lambda: be.finish(full))
-        if rep:
-            acc = ph if acc is None else {k: min(acc[k], v) for k, v in ph.items()}
-    tot = sum(acc.values())
-    print(f"world {world}: " + "  ".join(f"{k} {v:6.2f}" for k, v in acc.items()) + f"   sum {tot:6.2f} ms  ({(1 << log_m) / tot / 1e3:.1f} M constraints/s projected)", flush=True)
+    plan = dvp.distributed.shard_plan(world, *be.dims())
+    roles = sorted({0, world - 1})  # rank 0 skips the extends when the plan has such ranks; the last rank never does
+    worst = None
+    for rank in roles:
+        range_a, range_b, need = plan[rank]
+        acc = None
+        for rep in range(4):
+            ph = {}
+            _, ph["begin"] = timed(lambda: be.begin(assignment, need))
+            _, ph["msmA_part"] = timed(lambda: be.msm_partial(0, *range_a))
+            be.begin(assignment, True)
+            full, _ = timed(lambda: be.msm_partial(0, 0, be.msm_size(0)).clone())
+            be.begin(assignment, need)
+            _, ph["challenge"] = timed(lambda: be.challenge(full))
+            _, ph["msmB_part"] = timed(lambda: be.msm_partial(1, *range_b))
+            be.begin(assignment, True)
+            be.challenge(full)
+            full, _ = timed(lambda: be.msm_partial(1, 0, be.msm_size(1)).clone())
+            _, ph["finish"] = timed(lambda: be.finish(full))
+            if rep:
+                acc = ph if acc is None else {k: min(acc[k], v) for k, v in ph.items()}
+        tot = sum(acc.values())
+        tag = "extends" if need else "no extends"
+        print(f"world {world} rank {rank} ({tag}): " + "  ".join(f"{k} {v:6.2f}" for k, v in acc.items()) + f"   sum {tot:6.2f} ms", flush=True)
+        worst = tot if worst is None else max(worst, tot)
+    print(f"world {world}: slowest rank {worst:6.2f} ms  ({(1 << log_m) / worst / 1e3:.1f} M constraints/s projected)", flush=True)
