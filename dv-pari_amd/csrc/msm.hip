@@ -1185,7 +1185,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   for (int j = 0; j < p.c; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
-    if (total <= MERGE_QUAD_MAX)
+    static const uint32_t quad_max = getenv("DVP_MSM_QUAD_MAX") ? (uint32_t)atoll(getenv("DVP_MSM_QUAD_MAX")) : MERGE_QUAD_MAX;
+    if (total <= quad_max)
       hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
     else
       hipLaunchKernelGGL(k_merge<false>, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
