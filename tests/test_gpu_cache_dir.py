@@ -180,3 +180,42 @@ def test_sparse_cache_dir_with_witness_file(dvp, tmp_path):
     assert e.value.status == -1
     dvp.proving.release_cache_dir()
     pv.close()
+
+
+def test_cpp_host_over_the_c_abi(dvp, tmp_path):
+    """examples/dvp_prove_cli.cpp -- a compiled host that sees only include/dvpari.h -- proves from a cache_dir written
+    by the Python setup and prints the same 118 bytes as the Python host"""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++ on this box")
+    exe = tmp_path / "dvp_prove_cli"
+    libdir = os.path.join(root, "dv-pari_amd")
+    subprocess.check_call([gxx, "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "dvp_prove_cli.cpp"),
+                           "-L" + libdir, "-ldvpari_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    A, g = dvp.artifacts, dvp.gnark_r1cs
+    inst0, pub, prv = g.synthetic_sparse(10)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    inst0.write_dump_file(cache / A.R1CS_CONSTRAINTS_FILE)
+    g.write_witness_to_file(cache / A.R1CS_WITNESS_FILE, [1] + pub + prv)
+    rnd = random.Random(31)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    _, pv = dvp.srs.verifier_runs_setup_cache_dir(td, cache, len(pub), write_precomputes=False)
+    ref = pv.prove(pub, prv)
+    pv.close()
+    env = dict(os.environ, DVP_NO_TORCH_PRELOAD="1")
+    out = subprocess.run([str(exe), str(cache), str(len(pub)), str(tmp_path / "proof.bin")], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert bytes.fromhex(out.stdout.strip()) == ref.to_bytes()
+    assert (tmp_path / "proof.bin").read_bytes() == ref.to_bytes()
+    assert dvp.srs.verify(td, pub, dvp.proving.Proof.from_bytes((tmp_path / "proof.bin").read_bytes()))
+    # a different public-input count is a different statement (Vandermonde fold, transcript): other bytes
+    out = subprocess.run([str(exe), str(cache), "0"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and bytes.fromhex(out.stdout.strip()) != ref.to_bytes()
+    # missing files are reported with a status, not a crash
+    out = subprocess.run([str(exe), str(tmp_path / "nowhere"), "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 1 and "i/o" in out.stderr.lower() or "io" in out.stderr.lower()
