@@ -37,3 +37,20 @@ def test_no_cpu_fallback_in_product_path():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import pyref" not in src and "c_oracle" not in src and "dvp_oracle" not in src, f
+
+
+def test_cpp_example_builds_against_the_header(tmp_path):
+    """examples/dvp_prove_cli.cpp sees only include/dvpari.h: it must compile with plain g++ and link against the
+    library; without a GPU it reports that (exit 3), with one it reports the missing cache_dir (exit 1)"""
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    libdir = os.path.join(ROOT, "dv-pari_amd")
+    exe = tmp_path / "dvp_prove_cli"
+    subprocess.check_call([gxx, "-O1", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "dvp_prove_cli.cpp"), "-L" + libdir, "-ldvpari_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    out = subprocess.run([str(exe), str(tmp_path / "nowhere"), "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode in (1, 3), (out.returncode, out.stderr)
