@@ -133,3 +133,57 @@ def test_open_cache_dir_errors_without_gpu_work(dvp, tmp_path):
     (tmp_path / "r1cs_to_dvsnark").write_bytes(py_dump(dvp.gnark_r1cs.TOY_ROWS, dvp.gnark_r1cs.TOY_COEFFS))
     assert dvp.lib.dvp_prover_open_cache_dir(os.fspath(tmp_path).encode(), 2, C.byref(h)) == -6  # SRS files missing
     assert not h.value
+
+
+def test_r1cs_dump_parser_survives_corruption(dvp):
+    """random truncations and byte flips of a valid dump: the native parser either accepts (and then agrees with a plain
+    python walk of the same bytes) or reports a status -- it never reads out of bounds"""
+    rnd = random.Random(99)
+    coeffs = [rnd.randrange(o.P) for _ in range(5)]
+    rows = rand_rows(rnd, 40, 30, len(coeffs))
+    good = py_dump(rows, coeffs)
+
+    def py_walk(buf):
+        """None if malformed, else (n_coeffs, n_rows, nnz)"""
+        try:
+            (nc,) = struct.unpack_from("<I", buf, 0)
+            off = 4 + 32 * nc
+            if off + 4 > len(buf):
+                return None
+            (nr,) = struct.unpack_from("<I", buf, off)
+            off += 4
+            nnz = [0, 0, 0]
+            for _ in range(nr):
+                cnt = struct.unpack_from("<III", buf, off)
+                off += 12
+                for k in range(3):
+                    if off + 8 * cnt[k] > len(buf):
+                        return None
+                    for t in range(cnt[k]):
+                        _, c = struct.unpack_from("<II", buf, off + 8 * t)
+                        if c >= nc:
+                            return "badcoeff"
+                    nnz[k] += cnt[k]
+                    off += 8 * cnt[k]
+            return nc, nr, nnz
+        except struct.error:
+            return None
+
+    for it in range(300):
+        b = bytearray(good)
+        if it % 3 == 0:
+            b = b[: rnd.randrange(0, len(b))]
+        else:
+            for _ in range(rnd.randrange(1, 4)):
+                if b:
+                    b[rnd.randrange(len(b))] = rnd.randrange(256)
+        b = bytes(b)
+        exp = py_walk(b)
+        try:
+            inst = dvp.gnark_r1cs.R1CSInstance.from_dump_bytes(b, 2)
+            got = (inst.coeffs.shape[0], inst.n_rows, [int(mt.row_ptr[-1]) for mt in (inst.l, inst.r, inst.o)])
+        except dvp.DvpError as e:
+            got = None if e.status == -6 else "badcoeff" if e.status == -1 else e.status
+        if isinstance(exp, tuple) and exp[1] == 0:
+            continue  # zero rows: accepted by the walk, padded to one row by the host mirror
+        assert got == (exp if not isinstance(exp, tuple) else (exp[0], exp[1], exp[2])), (it, exp, got)
