@@ -33,7 +33,7 @@ __constant__ uint32_t K233_GY[8] = {0x56fae6a3u, 0x56e0c110u, 0xf18aeb9bu, 0x27a
 
 // P in E[r] (affine, x != 0)?  E[r] = 4E: Tr(x) = 0 and a half of P has Tr(x_half) = 0.
 // half-trace through the byte table (30 lookups instead of 232 squarings)
-__device__ __forceinline__ bool k233_in_subgroup(const Aff& p, const GfSqrTables& T, const GfLds& L) {
+__device__ __forceinline__ bool k233_in_subgroup(const Aff& p, const GfSqrTables& T, const GfLdsK& L) {
   if (gf_is_zero(p.x)) return false;
   if (gf_trace(p.x)) return false;
   Gf lam = gf_sqr_tab(p.x, T.th);                   // lam^2 + lam = x
@@ -63,7 +63,7 @@ __device__ __forceinline__ Gf load30(const uint8_t* src, uint32_t* top_bits) {
 __global__ void __launch_bounds__(256)
 k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n, GfSqrTables T, uint8_t* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
+  GfLdsK L = gf_ldsk_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Gf w = gf_zero();
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256, 2)
 k_decode(const uint8_t* __restrict__ enc, size_t n, GfSqrTables T, Aff* __restrict__ out, uint8_t* __restrict__ inf,
          unsigned long long* __restrict__ err) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
+  GfLdsK L = gf_ldsk_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t top;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256, 2)
 k_mulgen(const uint32_t* __restrict__ scalars, size_t n, const Aff* __restrict__ tab, GfSqrTables T, Aff* __restrict__ out,
          uint8_t* __restrict__ out_inf, unsigned long long* __restrict__ err) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
+  GfLdsK L = gf_ldsk_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -183,8 +183,7 @@ k_mulgen(const uint32_t* __restrict__ scalars, size_t n, const Aff* __restrict__
   bool fin = !ld_is_inf(acc);
   if (fin) {
     Gf zi = gf_inv_fast(acc.Z, T, L);
-    gf_tab_build(L, zi);
-    a.x = gf_mul_tab(acc.X, L);
+    a.x = gf_mul(acc.X, zi, L);
     a.y = gf_mul(acc.Y, gf_sqr(zi), L);
   }
   out[i] = a;
@@ -231,7 +230,7 @@ int mulgen_dev(const void* d_scalars, size_t n, Aff* d_out, uint8_t* d_inf, hipS
   DVP_HIP(hipMemsetAsync(err.p, 0xff, 8, st));
   GfSqrTables T;
   DVP_TRY(gf_sqr_tables(&T, st));
-  hipLaunchKernelGGL(k_mulgen, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, (const uint32_t*)d_scalars, n, tab, T, d_out,
+  hipLaunchKernelGGL(k_mulgen, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDSK_BYTES_PER_WAVE, st, (const uint32_t*)d_scalars, n, tab, T, d_out,
                      d_inf, err.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   return read_err(err.as<unsigned long long>(), st, DVP_EINVAL);
@@ -240,7 +239,7 @@ int mulgen_dev(const void* d_scalars, size_t n, Aff* d_out, uint8_t* d_inf, hipS
 int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st) {
   GfSqrTables T;
   DVP_TRY(gf_sqr_tables(&T, st));
-  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, d_pts, d_inf, n, T, d_out);
+  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDSK_BYTES_PER_WAVE, st, d_pts, d_inf, n, T, d_out);
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
@@ -251,7 +250,7 @@ int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipSt
   DVP_HIP(hipMemsetAsync(err.p, 0xff, 8, st));
   GfSqrTables T;
   DVP_TRY(gf_sqr_tables(&T, st));
-  hipLaunchKernelGGL(k_decode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDS_BYTES_PER_WAVE, st, d_enc, n, T, d_out, d_inf,
+  hipLaunchKernelGGL(k_decode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDSK_BYTES_PER_WAVE, st, d_enc, n, T, d_out, d_inf,
                      err.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   return read_err(err.as<unsigned long long>(), st, DVP_EDECODE);

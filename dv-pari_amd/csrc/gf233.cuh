@@ -292,6 +292,198 @@ GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLdsQ& c) {
   return gf_mul_tab(a, c);
 }
 
+// two products against the same operand b: the table of b is built once
+GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLds& c, Gf& r1, Gf& r2) {
+  gf_tab_build(c, b);
+  r1 = gf_mul_tab(a1, c);
+  r2 = gf_mul_tab(a2, c);
+}
+GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLdsQ& c, Gf& r1, Gf& r2) {
+  gf_tab_build(c.l, b);
+  r1 = gf_mul_tab(a1, c);
+  r2 = gf_mul_tab(a2, c);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Karatsuba over the LDS comb (the throughput kernels' multiplier).  a = a0 + a1 z^117, b = b0 + b1 z^117:
+//     a b = L + (M + L + H) z^117 + H z^234,   L = a0 b0,  H = a1 b1,  M = (a0 + a1)(b0 + b1).
+// The three half-products run against 3-bit window tables of 117-bit operands, whose entries u(z) * bh(z) have 119
+// bits = FOUR words: one ds_read_b128 per lookup instead of two, 120 lookups per product instead of 176, and 8 KB of
+// LDS per wave instead of 16 KB -- which is what lets the EC kernels run 3-4 waves per SIMD instead of 2 (the comb is
+// LDS-pipe-bound at 2 waves: 176 x 4 + 14 x 13 LDS cycles per wave-product against 120 x 4 + 21 x 13 here).
+// Measured on MI355X (tools/ubench/gfmul_kara.hip): 31.0 G products/s for the 16 KB comb, 38.0 / 39.7 G/s for this
+// form at 3 / 4 waves per SIMD.  Details that matter on gfx950: lookups of a row are combined with 3-input xors
+// (v_bitop3 0x96: 8 ops for 16 loaded words), and LDS addresses are kept as 32-bit integers so that a lookup address
+// is one shift + one bitop3 ((x & 0x1C00) | lane_base) with no pointer add.
+// Layout: byte address = wave region + u * 1024 + lane * 16, u = 0..7 (row 0 stays zero).
+constexpr unsigned GF_LDSK_BYTES_PER_WAVE = 8192;
+typedef __attribute__((address_space(3))) gf_u32x4 gf_lds_u32x4;
+GF_DEV gf_u32x4 gf_lds_ld(uint32_t addr) { return *(const gf_lds_u32x4*)addr; }
+GF_DEV void gf_lds_st(uint32_t addr, gf_u32x4 v) { *(gf_lds_u32x4*)addr = v; }
+GF_DEV uint32_t gf_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
+struct GfLdsK {
+  uint32_t lane_base;  // LDS byte address of this lane's row-0 entry (wave regions are 8 KB aligned)
+};
+GF_DEV GfLdsK gf_ldsk_init(char* lds_base) {
+  GfLdsK c;
+  uint32_t b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_base;
+  c.lane_base = b + (threadIdx.x >> 6) * GF_LDSK_BYTES_PER_WAVE + (threadIdx.x & 63) * 16;
+  gf_lds_st(c.lane_base, (gf_u32x4){0, 0, 0, 0});
+  return c;
+}
+GF_DEV void gf_k_shl1(const uint32_t* in, uint32_t* out) {
+#pragma unroll
+  for (int i = 3; i > 0; --i) out[i] = __builtin_amdgcn_alignbit(in[i], in[i - 1], 31);
+  out[0] = in[0] << 1;
+}
+GF_DEV void gf_k_store(const GfLdsK& c, int u, const uint32_t* w) {
+  gf_lds_st(c.lane_base + (uint32_t)u * 1024, (gf_u32x4){w[0], w[1], w[2], w[3]});
+}
+// table of a half operand (<= 117 bits in 4 words)
+GF_DEV void gf_k_tab_build(const GfLdsK& c, const uint32_t* b) {
+  uint32_t t2[4], t3[4], t4[4], t6[4];
+  gf_k_store(c, 1, b);
+  gf_k_shl1(b, t2);
+  gf_k_store(c, 2, t2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t3[i] = t2[i] ^ b[i];
+  gf_k_store(c, 3, t3);
+  gf_k_shl1(t2, t4);
+  gf_k_store(c, 4, t4);
+  gf_k_shl1(t3, t6);
+  gf_k_store(c, 6, t6);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t4[i] ^= b[i];
+    t6[i] ^= b[i];
+  }
+  gf_k_store(c, 5, t4);
+  gf_k_store(c, 7, t6);
+}
+// one digit position of a half operand: NW lookups (all issued before the first xor), 4 NW words into NW + 3
+template <int NW>
+GF_DEV void gf_k_row(uint32_t* acc, const uint32_t* a, const GfLdsK& c, int rsh, int lsh) {
+  gf_u32x4 v[NW];
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    uint32_t sh = (a[j] >> rsh) << lsh;
+    v[j] = gf_lds_ld(__builtin_amdgcn_bitop3_b32(sh, 0x1C00u, c.lane_base, 0xEA));  // (sh & 0x1C00) | lane_base
+  }
+  asm volatile("" ::: "memory");
+  acc[0] ^= v[0].x;
+  acc[1] = gf_xor3(acc[1], v[0].y, v[1].x);
+  if (NW == 4) {
+    acc[2] = gf_xor3(acc[2], v[0].z, v[1].y) ^ v[2].x;
+    acc[3] = gf_xor3(gf_xor3(acc[3], v[0].w, v[1].z), v[2].y, v[3].x);
+    acc[4] = gf_xor3(acc[4], v[1].w, v[2].z) ^ v[3].y;
+    acc[5] = gf_xor3(acc[5], v[2].w, v[3].z);
+    acc[6] ^= v[3].w;
+  } else {
+    acc[2] = gf_xor3(acc[2], v[0].z, v[1].y) ^ v[2].x;
+    acc[3] = gf_xor3(acc[3], v[0].w, v[1].z) ^ v[2].y;
+    acc[4] = gf_xor3(acc[4], v[1].w, v[2].z);
+    acc[5] ^= v[2].w;
+  }
+}
+GF_DEV void gf_k_shl3(uint32_t* acc) {
+#pragma unroll
+  for (int i = 7; i > 0; --i) acc[i] = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], 29);
+  acc[0] <<= 3;
+}
+// acc[0..7] = a (4 words, a[3] < 2^21) * (half operand whose table is in LDS); digit k of a word = bits [3k, 3k+3),
+// k = 10 is the 2-bit top digit, a[3] has digits 0..6 only
+GF_DEV void gf_k_mul_tab(uint32_t* acc, const uint32_t* a, const GfLdsK& c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0;
+  gf_k_row<3>(acc, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
+#pragma unroll 1
+  for (int k = 9; k >= 7; --k) {
+    gf_k_shl3(acc);
+    gf_k_row<3>(acc, a, c, 3 * k - 10, 0);
+  }
+#pragma unroll 1
+  for (int k = 6; k >= 4; --k) {
+    gf_k_shl3(acc);
+    gf_k_row<4>(acc, a, c, 3 * k - 10, 0);
+  }
+  gf_k_shl3(acc);
+  gf_k_row<4>(acc, a, c, 0, 1);  // k = 3: bits 9..11 -> << 1
+#pragma unroll 1
+  for (int k = 2; k >= 0; --k) {
+    gf_k_shl3(acc);
+    gf_k_row<4>(acc, a, c, 0, 10 - 3 * k);
+  }
+}
+// x = lo + hi z^117
+GF_DEV void gf_k_split(const Gf& x, uint32_t* lo, uint32_t* hi) {
+  lo[0] = x.w[0]; lo[1] = x.w[1]; lo[2] = x.w[2]; lo[3] = x.w[3] & 0x1FFFFFu;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) hi[i] = __builtin_amdgcn_alignbit(i + 4 < 8 ? x.w[i + 4] : 0u, x.w[i + 3], 21);
+}
+// L + (M + L + H) z^117 + H z^234, reduced
+GF_DEV Gf gf_k_combine(const uint32_t* L, const uint32_t* H, uint32_t* M) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) M[i] ^= L[i] ^ H[i];
+  uint32_t r[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r[i] = L[i];
+#pragma unroll
+  for (int i = 8; i < 16; ++i) r[i] = 0;
+  r[3] ^= M[0] << 21;  // << 117 = 3 words + 21 bits
+#pragma unroll
+  for (int i = 1; i < 8; ++i) r[3 + i] ^= __builtin_amdgcn_alignbit(M[i], M[i - 1], 11);
+  r[11] ^= M[7] >> 11;
+  r[7] ^= H[0] << 10;  // << 234 = 7 words + 10 bits
+#pragma unroll
+  for (int i = 1; i < 8; ++i) r[7 + i] ^= __builtin_amdgcn_alignbit(H[i], H[i - 1], 22);
+  r[15] ^= H[7] >> 22;
+  return gf_reduce16(r);
+}
+GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLdsK& c) {
+  uint32_t a0[4], a1[4], b0[4], b1[4];
+  gf_k_split(a, a0, a1);
+  gf_k_split(b, b0, b1);
+  uint32_t L[8], H[8], M[8];
+  gf_k_tab_build(c, b0);
+  gf_k_mul_tab(L, a0, c);
+  gf_k_tab_build(c, b1);
+  gf_k_mul_tab(H, a1, c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a0[i] ^= a1[i];
+    b0[i] ^= b1[i];
+  }
+  gf_k_tab_build(c, b0);
+  gf_k_mul_tab(M, a0, c);
+  return gf_k_combine(L, H, M);
+}
+// a1 * b and a2 * b: each half table of b is built once and serves both products
+GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLdsK& c, Gf& r1, Gf& r2) {
+  uint32_t p0[4], p1[4], q0[4], q1[4], b0[4], b1[4];
+  gf_k_split(a1, p0, p1);
+  gf_k_split(a2, q0, q1);
+  gf_k_split(b, b0, b1);
+  uint32_t L1[8], H1[8], M1[8], L2[8], H2[8], M2[8];
+  gf_k_tab_build(c, b0);
+  gf_k_mul_tab(L1, p0, c);
+  gf_k_mul_tab(L2, q0, c);
+  gf_k_tab_build(c, b1);
+  gf_k_mul_tab(H1, p1, c);
+  gf_k_mul_tab(H2, q1, c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p0[i] ^= p1[i];
+    q0[i] ^= q1[i];
+    b0[i] ^= b1[i];
+  }
+  gf_k_tab_build(c, b0);
+  gf_k_mul_tab(M1, p0, c);
+  gf_k_mul_tab(M2, q0, c);
+  r1 = gf_k_combine(L1, H1, M1);
+  r2 = gf_k_combine(L2, H2, M2);
+}
+
 // 16 bits -> 32 bits with zeros interleaved
 GF_DEV uint32_t gf_spread16(uint32_t x) {
   x = (x | (x << 8)) & 0x00FF00FFu;
@@ -359,9 +551,8 @@ GF_DEV Gf gf_sqr_n_fast(Gf a, int k, const GfSqrTables& T) {
 template <class LT>
 GF_DEV Gf gf_inv_fast(const Gf& a, const GfSqrTables& T, const LT& L) {
   Gf b1 = a;
-  gf_tab_build(L, b1);
-  Gf b2 = gf_mul_tab(gf_sqr(b1), L);
-  Gf b3 = gf_mul_tab(gf_sqr(b2), L);
+  Gf b2 = gf_mul(gf_sqr(b1), b1, L);
+  Gf b3 = gf_mul(gf_sqr(b2), b1, L);
   Gf b6 = gf_mul(gf_sqr_n(b3, 3), b3, L);
   Gf b7 = gf_mul(gf_sqr(b6), b1, L);
   Gf b14 = gf_mul(gf_sqr_n(b7, 7), b7, L);

@@ -104,9 +104,11 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q) {
 }
 
 
-// ---- LDS-comb flavours (hot kernels): same formulas, products through the LDS table multiplier
-// (gf233.cuh), with the table of a repeated operand built once: 6 builds for the 8 products of the mixed
-// addition (Z1 and C are used twice), 9 builds for the 13 products of the full addition. ----------------
+// ---- LDS-multiplier flavours (hot kernels): same formulas, products through one of the LDS multipliers of
+// gf233.cuh.  LT = GfLdsK (Karatsuba half tables, the throughput kernels), GfLds (16 KB comb) or GfLdsQ (the four
+// lanes of a quad compute one addition together: latency-bound stages).  Products that share an operand go through
+// gf_mul2, which builds the shared operand's table(s) once: 6 table sets for the 8 products of the mixed addition,
+// 9 for the 13 of the full addition. ----------------
 template <class LT>
 GF_DEV Ld ld_dbl(const Ld& p, const LT& L) {
   Gf z1s = gf_sqr(p.Z), x1s = gf_sqr(p.X);
@@ -121,7 +123,8 @@ GF_DEV Ld ld_dbl(const Ld& p, const LT& L) {
 
 // in-place forms (no aggregate returns through divergent paths: those made hipcc keep the accumulator
 // in scratch, 68 B/lane of write+read traffic per addition)
-GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const GfLds& L) {
+template <class LT>
+GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const LT& L) {
   if (ld_is_inf(p)) {
     p.X = q.x;
     p.Y = q.y;
@@ -129,8 +132,7 @@ GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const GfLds& L) {
     return;
   }
   Gf A = gf_add(p.Y, gf_mul(q.y, gf_sqr(p.Z), L));
-  gf_tab_build(L, p.Z);
-  Gf B = gf_add(p.X, gf_mul_tab(q.x, L));
+  Gf B = gf_add(p.X, gf_mul(q.x, p.Z, L));
   if (gf_is_zero(B)) {
     if (gf_is_zero(A)) {  // p == q: double the affine point
       Ld t;
@@ -142,10 +144,9 @@ GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const GfLds& L) {
     }
     return;
   }
-  Gf C = gf_mul_tab(B, L);  // Z1 * B
-  gf_tab_build(L, C);
-  Gf D = gf_mul_tab(gf_sqr(B), L);
-  Gf E = gf_mul_tab(A, L);
+  Gf C = gf_mul(B, p.Z, L);  // Z1 * B
+  Gf D, E;
+  gf_mul2(gf_sqr(B), A, C, L, D, E);
   Gf Z3 = gf_sqr(C);
   Gf X3 = gf_add(gf_add(gf_sqr(A), D), E);
   Gf F = gf_add(X3, gf_mul(q.x, Z3, L));
@@ -154,13 +155,13 @@ GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const GfLds& L) {
   p.X = X3;
   p.Z = Z3;
 }
-GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const GfLds& L) {
+template <class LT>
+GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const LT& L) {
   Ld r = p;
   ld_madd_ip(r, q, L);
   return r;
 }
 
-// LT = GfLds (one lane per addition) or GfLdsQ (the four lanes of a quad compute one addition together)
 template <class LT>
 GF_DEV void ld_add_ip(Ld& p, const Ld& q, const LT& L) {
   if (ld_is_inf(q)) return;
@@ -170,9 +171,8 @@ GF_DEV void ld_add_ip(Ld& p, const Ld& q, const LT& L) {
   }
   Gf A1 = gf_mul(q.Y, gf_sqr(p.Z), L);
   Gf A2 = gf_mul(p.Y, gf_sqr(q.Z), L);
-  gf_tab_build(L, p.Z);
-  Gf B1 = gf_mul_tab(q.X, L);
-  Gf E = gf_mul_tab(q.Z, L);
+  Gf B1, E;
+  gf_mul2(q.X, q.Z, p.Z, L, B1, E);
   Gf B2 = gf_mul(p.X, q.Z, L);
   Gf C = gf_add(A1, A2);
   Gf D = gf_add(B1, B2);
@@ -186,15 +186,12 @@ GF_DEV void ld_add_ip(Ld& p, const Ld& q, const LT& L) {
     return;
   }
   Gf Ds = gf_sqr(D);
-  gf_tab_build(L, Ds);
-  Gf DB = gf_mul_tab(B1, L);
-  Gf DA = gf_mul_tab(A1, L);
-  gf_tab_build(L, E);
-  Gf F = gf_mul_tab(D, L);
-  Gf I = gf_mul_tab(DB, L);
-  gf_tab_build(L, F);
-  Gf G = gf_mul_tab(Ds, L);
-  Gf H = gf_mul_tab(C, L);
+  Gf DB, DA;
+  gf_mul2(B1, A1, Ds, L, DB, DA);
+  Gf F, I;
+  gf_mul2(D, DB, E, L, F, I);
+  Gf G, H;
+  gf_mul2(Ds, C, F, L, G, H);
   Gf Z3 = gf_sqr(F);
   Gf X3 = gf_add(gf_add(gf_sqr(C), H), G);
   I = gf_add(I, X3);

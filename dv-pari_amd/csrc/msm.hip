@@ -488,9 +488,11 @@ k_frob_table(const Aff* __restrict__ bases, uint32_t n, int FX_C, int FX_W, int 
   }
 }
 
-// EC kernels on the LDS multiplier: 256-thread blocks, 4 x 16 KB of tables (512-thread blocks measured 5% slower end to end)
+// EC kernels on the Karatsuba LDS multiplier: 256-thread blocks, 4 x 8 KB of half tables; the quad-cooperative
+// flavours (latency-bound stages) keep the 16 KB comb tables
 constexpr int EC_TPB = 256;
-constexpr unsigned EC_LDS = (EC_TPB / 64) * GF_LDS_BYTES_PER_WAVE;
+constexpr unsigned EC_LDS = (EC_TPB / 64) * GF_LDSK_BYTES_PER_WAVE;
+constexpr unsigned EC_LDS_Q = (EC_TPB / 64) * GF_LDS_BYTES_PER_WAVE;
 constexpr uint32_t MERGE_QUAD_MAX = 16384;  // additions per level up to which 4 lanes per addition win (measured: 35 us vs 41 us at 16384)
 
 // ---- segmented reduction by fan-in K ----------------------------------------------------------------
@@ -510,12 +512,12 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, 
 }
 
 template <bool INDIRECT>
-__global__ void __launch_bounds__(EC_TPB, 2)
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
                Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
+  GfLdsK L = gf_ldsk_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
@@ -535,11 +537,11 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   out[tid] = acc;
 }
 
-__global__ void __launch_bounds__(EC_TPB, 2)
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
              const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K, Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
+  GfLdsK L = gf_ldsk_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
@@ -611,12 +613,12 @@ __device__ __forceinline__ const Aff* aff_ptr(const Aff* __restrict__ pts, const
 // Thread t of T = ceil(total / AFF_B) owns output slots s = k*T + t, k < AFF_B (lane-consecutive slots:
 // coalesced outputs, prefix products and -- after the first round -- inputs).
 template <bool FIRST, int B>
-__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */,
                uint32_t nkeys, GfSqrTables T, Gf* __restrict__ prefix, uint32_t* __restrict__ gdesc, Aff* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLds L = gf_lds_init(lds_raw);
+  GfLdsK L = gf_ldsk_init(lds_raw);
   const uint32_t total = ooff[nkeys];
   const uint32_t nthr = (total + B - 1) / B;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,9 +730,9 @@ k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, 
     }
     Gf den = dbl ? px : dd;
     Gf pre = prefix[(size_t)k * nthr + tid];
-    gf_tab_build(L, inv);
-    Gf dinv = gf_mul_tab(pre, L);  // 1/den
-    inv = gf_mul_tab(den, L);      // strip this slot's factor
+    Gf dinv, inv_next;
+    gf_mul2(pre, den, inv, L, dinv, inv_next);  // 1/den, and the running inverse stripped of this slot's factor
+    inv = inv_next;
     Gf num = dbl ? py : gf_add(py, qy);
     Gf lam = gf_mul(num, dinv, L);
     if (dbl) lam = gf_add(lam, px);
@@ -783,7 +785,7 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 // QUAD: the deep levels have far fewer additions than the chip has lanes and are pure latency; there the four lanes
 // of a quad share one addition (gf233.cuh, quad-cooperative product), 2.2x shorter per level.
 template <bool QUAD>
-__global__ void __launch_bounds__(EC_TPB, QUAD ? 1 : 2) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+__global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (QUAD) tid >>= 2;
@@ -799,9 +801,10 @@ __global__ void __launch_bounds__(EC_TPB, QUAD ? 1 : 2) k_merge(Ld* __restrict__
       A[base + s] = l;
     }
   } else {
-    GfLds L = gf_lds_init(lds_raw);
+    GfLdsK L = gf_ldsk_init(lds_raw);
     if (s == 0 && j >= 2) A[base + 1 + j] = r;
-    A[base + s] = ld_add(l, r, L);
+    ld_add_ip(l, r, L);
+    A[base + s] = l;
   }
 }
 
@@ -843,8 +846,7 @@ __global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSq
   a.y = gf_zero();
   if (fin) {
     Gf zi = gf_inv_fast(p.Z, T, L);
-    gf_tab_build(L, zi);
-    a.x = gf_mul_tab(p.X, L);
+    a.x = gf_mul(p.X, zi, L);
     a.y = gf_mul(p.Y, gf_sqr(zi), L);
   }
   if (threadIdx.x != 0) return;
@@ -984,7 +986,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                           (const void*)k_affine_round<true, 8>, (const void*)k_affine_round<false, 8>,
                           (const void*)k_affine_round<true, 4>, (const void*)k_affine_round<false, 4>};
       for (const void* f : ec)
-        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, AFF_LDS);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q + AFF_B * EC_TPB * 4);
     });
     DVP_HIP(attr_err);
   }
@@ -1187,7 +1189,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     static const uint32_t quad_max = getenv("DVP_MSM_QUAD_MAX") ? (uint32_t)atoll(getenv("DVP_MSM_QUAD_MAX")) : MERGE_QUAD_MAX;
     if (total <= quad_max)
-      hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
+      hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
     else
       hipLaunchKernelGGL(k_merge<false>, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
   }
