@@ -15,7 +15,7 @@ static double g_prof_ms[PROF_NSLOTS] = {0};
 static uint64_t g_prof_n[PROF_NSLOTS] = {0};
 struct Pending { int slot; hipEvent_t e0, e1; };
 static std::vector<Pending> g_prof_pending;
-static const char* kProfNames[PROF_NSLOTS] = {"msm_affine_round0", "msm_total", "extend_total", "prove_total"};
+static const char* kProfNames[PROF_NSLOTS] = {"msm_affine_round0", "msm_total", "extend_total", "prove_total", "msm_affine_rest", "msm_sort", "msm_tail"};
 
 ProfScope::ProfScope(int slot_, hipStream_t st_) : slot(slot_), st(st_) {
   if (!g_prof_enabled) return;

@@ -64,7 +64,7 @@ inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 // ---- per-kernel HIP-event timers (bench.py's roofline leg; off by default) ------------------------
 // A timed launch records two events on the launch stream; prof_collect() (called where the host
 // already synchronises) folds the elapsed times into named slots readable through dvp_profile_read.
-enum ProfSlot { PROF_MSM_ACCUM_AFFINE = 0, PROF_MSM_TOTAL, PROF_EXTEND_TOTAL, PROF_PROVE_TOTAL, PROF_NSLOTS };
+enum ProfSlot { PROF_MSM_ACCUM_AFFINE = 0, PROF_MSM_TOTAL, PROF_EXTEND_TOTAL, PROF_PROVE_TOTAL, PROF_MSM_AFFINE_REST, PROF_MSM_SORT, PROF_MSM_TAIL, PROF_NSLOTS };
 extern bool g_prof_enabled;
 struct ProfScope {
   int slot;

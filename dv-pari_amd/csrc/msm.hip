@@ -596,150 +596,136 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
 // ---- batched-affine pair rounds --------------------------------------------------------------------
 // One round halves every bucket: output slot (key, j) = in[2j] + in[2j+1] (or in[2j] alone when the
 // count is odd), all in AFFINE coordinates.  An affine addition needs one field inversion; a thread owns
-// AFF_B consecutive output slots and shares ONE inversion among them (Montgomery's trick): per addition
-// 3 products for the trick + 2 products + 1 squaring for the chord/tangent formulas, against 8M + 5S for
-// a mixed projective addition.  Prefix products are parked in HBM ([slot-in-thread][thread] layout, so
-// the traffic is coalesced).  (0,0) -- not a curve point -- marks infinity.
-constexpr int AFF_B = 16;
+// B output slots and shares ONE inversion among them (Montgomery's trick): per addition 3 products for
+// the trick + 2 products + 1 squaring for the chord/tangent formulas, against 8M + 5S for a mixed
+// projective addition.  Prefix products are parked in HBM ([slot-in-thread][thread] layout, so the
+// traffic is coalesced).  (0,0) -- not a curve point -- marks infinity.
+//
+// A round is two launches.  k_round_desc resolves every output slot to its two input points once -- (a, b) =
+// indices into `pts`, b = NONE for the odd leftover of a bucket -- with a group of lanes per bucket, so the hot
+// kernel neither searches the bucket offsets (18 dependent L2 round trips per slot in the first version) nor chases
+// the sorted item list; k_affine_round then runs two software-pipelined passes over its slots: the descriptor of
+// slot k+2 and the operands of slot k+1 are in flight while slot k multiplies, so the random 64-byte gathers of the
+// bases (HBM misses in the first round: the pre-rotated table is 5 GB) are off the critical path.
+constexpr uint32_t AFF_NONE = 0xffffffffu;
 
-// slot descriptors live in the 16 KB of LDS left beside the multiplier tables: desc[k][thread]
-constexpr unsigned AFF_LDS = EC_LDS + AFF_B * EC_TPB * 4;
-
-template <bool FIRST>
-__device__ __forceinline__ const Aff* aff_ptr(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, uint32_t i) {
-  return FIRST ? pts + items[i] : pts + i;
+template <bool FIRST, int LPK>
+__global__ void __launch_bounds__(256)
+k_round_desc(const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+             const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */, uint32_t nkeys, uint2* __restrict__ desc) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t key = gid / LPK, lane = gid % LPK;
+  if (key >= nkeys) return;
+  const uint32_t c = cnt[key], o = off[key], oo = ooff[key], nout = (c + 1) >> 1;
+  for (uint32_t j = lane; j < nout; j += LPK) {
+    const uint32_t i0 = o + 2 * j;
+    uint2 d;
+    d.x = FIRST ? items[i0] : i0;
+    d.y = (2 * j + 1 < c) ? (FIRST ? items[i0 + 1] : i0 + 1) : AFF_NONE;
+    desc[oo + j] = d;
+  }
 }
 
-// Thread t of T = ceil(total / AFF_B) owns output slots s = k*T + t, k < AFF_B (lane-consecutive slots:
-// coalesced outputs, prefix products and -- after the first round -- inputs).
-template <bool FIRST, int B>
+// Thread t of T = ceil(total / B) owns output slots s = k*T + t, k < B (lane-consecutive slots: coalesced
+// descriptors, outputs, prefix products and -- after the first round -- inputs).
+// B (slots per thread = additions per shared inversion) is chosen ON THE DEVICE from the round's size so that the
+// grid is a whole number of chip-fulls: all threads of a round take the same time, so with a fixed B the last
+// partial wave of blocks ran on a mostly idle chip (2.2 chip-fulls cost 3: the first version averaged 64 % of its
+// 12 waves per CU).  With `cap` = resident threads of the chip, R = ceil(total / (cap * AFF_BMAX)) chip-fulls of
+// B = ceil(total / (cap * R)) slots each: B is 25..48 in the big rounds and shrinks to 1..8 in the last ones, where a
+// round is pure latency and short threads are what is wanted.
+constexpr int AFF_BMAX = 48;
+__device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_t cap) {
+  const uint32_t units = (total + cap - 1) / cap;  // slots per resident thread if the round were one chip-full
+  const uint32_t R = (units + AFF_BMAX - 1) / AFF_BMAX;
+  return R ? (units + R - 1) / R : 1;
+}
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_affine_round(const Aff* __restrict__ pts, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
-               const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */,
-               uint32_t nkeys, GfSqrTables T, Gf* __restrict__ prefix, uint32_t* __restrict__ gdesc, Aff* __restrict__ out) {
+k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, const uint32_t* __restrict__ total_ptr /* ooff[nkeys] */,
+               uint32_t cap, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
-  const uint32_t total = ooff[nkeys];
+  const uint32_t total = *total_ptr;
+  const int B = (int)aff_slots_per_thread(total, cap);
   const uint32_t nthr = (total + B - 1) / B;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nthr) return;
-  // slot descriptors: B = 16 keeps them in the 16 KB of LDS beside the tables; B = 32 (the big rounds, where halving the
-  // inversions per addition pays) parks them in HBM in [slot][thread] order
-  uint32_t* desc = B <= AFF_B ? (uint32_t*)(lds_raw + EC_LDS) + threadIdx.x : gdesc + tid;
-  const size_t dstr = B <= AFF_B ? (size_t)EC_TPB : (size_t)nthr;
-  // pre-pass: slot -> (first input index, has-partner flag in bit 31); 0xffffffff = no slot.  The AFF_B binary
-  // searches over the key offsets advance in lockstep, so each step has AFF_B independent loads in flight instead of
-  // one (18 dependent L2 round trips per slot, one slot after the other, used to cost as much as the additions).
-  constexpr int PB = B < AFF_B ? B : AFF_B;  // searches advancing together
-#pragma unroll 1
-  for (int k0 = 0; k0 < B; k0 += PB) {
-    uint32_t lo[PB], hi[PB], sv[PB];
-#pragma unroll
-    for (int k = 0; k < PB; ++k) {
-      sv[k] = min((uint32_t)(k0 + k) * nthr + tid, total - 1);
-      lo[k] = 0;
-      hi[k] = nkeys;  // invariant: ooff[lo] <= s < ooff[hi]
-    }
-    const int steps = nkeys > 1 ? 32 - __builtin_clz(nkeys - 1) : 0;
-#pragma unroll 1
-    for (int it = 0; it < steps; ++it) {
-      uint32_t v[PB];
-#pragma unroll
-      for (int k = 0; k < PB; ++k) v[k] = ooff[(lo[k] + hi[k]) >> 1];
-#pragma unroll
-      for (int k = 0; k < PB; ++k) {
-        uint32_t mid = (lo[k] + hi[k]) >> 1;  // hi - lo == 1 gives mid == lo: a no-op step
-        if (v[k] <= sv[k]) lo[k] = mid; else hi[k] = mid;
-      }
-    }
-    uint32_t o0[PB], o1[PB], cn[PB];
-#pragma unroll
-    for (int k = 0; k < PB; ++k) {
-      o0[k] = ooff[lo[k]];
-      o1[k] = off[lo[k]];
-      cn[k] = cnt[lo[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < PB; ++k) {
-      uint32_t sk = (uint32_t)(k0 + k) * nthr + tid, d = 0xffffffffu;
-      if (sk < total) {
-        uint32_t j = sk - o0[k];
-        d = (o1[k] + 2 * j) | ((2 * j + 1 < cn[k]) ? 0x80000000u : 0u);
-      }
-      desc[(size_t)(k0 + k) * dstr] = d;
-    }
-  }
+  const uint2 none = make_uint2(AFF_NONE, AFF_NONE);
+  auto ld_desc = [&](int k) -> uint2 {
+    if (k < 0 || k >= B) return none;
+    const uint32_t sk = (uint32_t)k * nthr + tid;
+    return sk < total ? desc[sk] : none;
+  };
   const Gf one = gf_one();
   // pass 1: denominators and running product (x-coordinates only; y is touched when x1 == x2)
   Gf run = one;
   {
-    uint32_t d = desc[0];
-    const Aff *pa = nullptr, *pb = nullptr;
+    uint2 d0 = ld_desc(0), d1 = ld_desc(1);
     Gf xa = gf_zero(), xb = gf_zero();
-    if (d != 0xffffffffu && (d >> 31)) {
-      pa = aff_ptr<FIRST>(pts, items, d & 0x7fffffffu);
-      pb = aff_ptr<FIRST>(pts, items, (d & 0x7fffffffu) + 1);
-      xa = pa->x; xb = pb->x;
-    }
+    if (d0.y != AFF_NONE) { xa = pts[d0.x].x; xb = pts[d0.y].x; }
 #pragma unroll 1
     for (int k = 0; k < B; ++k) {
-      // prefetch the next slot while this one multiplies
-      uint32_t dn = (k + 1 < B) ? desc[(size_t)(k + 1) * dstr] : 0xffffffffu;
-      const Aff *na = nullptr, *nb = nullptr;
+      const uint2 d2 = ld_desc(k + 2);
       Gf nxa = gf_zero(), nxb = gf_zero();
-      if (dn != 0xffffffffu && (dn >> 31)) {
-        na = aff_ptr<FIRST>(pts, items, dn & 0x7fffffffu);
-        nb = aff_ptr<FIRST>(pts, items, (dn & 0x7fffffffu) + 1);
-        nxa = na->x; nxb = nb->x;
-      }
+      if (d1.y != AFF_NONE) { nxa = pts[d1.x].x; nxb = pts[d1.y].x; }
       Gf den = one;
-      bool live = d != 0xffffffffu && (d >> 31) && !gf_is_zero(xa) && !gf_is_zero(xb);
-      if (live) {
+      if (d0.y != AFF_NONE && !gf_is_zero(xa) && !gf_is_zero(xb)) {
         Gf dd = gf_add(xa, xb);
         if (!gf_is_zero(dd)) den = dd;
-        else if (gf_eq(pa->y, pb->y)) den = xa;  // doubling: lambda = x + y/x
+        else if (gf_eq(pts[d0.x].y, pts[d0.y].y)) den = xa;  // doubling: lambda = x + y/x
       }
       prefix[(size_t)k * nthr + tid] = run;
       run = gf_mul(run, den, L);
-      d = dn; pa = na; pb = nb; xa = nxa; xb = nxb;
+      d0 = d1; d1 = d2; xa = nxa; xb = nxb;
     }
   }
   Gf inv = gf_inv_fast(run, T, L);
   // pass 2 (backwards): recover each inverse and finish the addition
+  {
+    uint2 e0 = ld_desc(B - 1), e1 = ld_desc(B - 2);
+    Gf px = gf_zero(), qx = gf_zero(), pre = one;
+    if (e0.x != AFF_NONE) px = pts[e0.x].x;
+    if (e0.y != AFF_NONE) { qx = pts[e0.y].x; pre = prefix[(size_t)(B - 1) * nthr + tid]; }
 #pragma unroll 1
-  for (int k = B - 1; k >= 0; --k) {
-    uint32_t d = desc[(size_t)k * dstr];
-    if (d == 0xffffffffu) continue;
-    uint32_t s = (uint32_t)k * nthr + tid;
-    const Aff* pa = aff_ptr<FIRST>(pts, items, d & 0x7fffffffu);
-    Gf px = pa->x, py = pa->y;
-    if (!(d >> 31)) {  // odd leftover: pass through
-      out[s].x = px; out[s].y = py;
-      continue;
+    for (int k = B - 1; k >= 0; --k) {
+      const uint2 e2 = ld_desc(k - 2);
+      // this slot's y-coordinates (needed after the two products of the inverse recovery) ...
+      Gf py = gf_zero(), qy = gf_zero();
+      if (e0.x != AFF_NONE) py = pts[e0.x].y;
+      if (e0.y != AFF_NONE) qy = pts[e0.y].y;
+      // ... and the next slot's x-coordinates and prefix product
+      Gf npx = gf_zero(), nqx = gf_zero(), npre = one;
+      if (e1.x != AFF_NONE) npx = pts[e1.x].x;
+      if (e1.y != AFF_NONE) { nqx = pts[e1.y].x; npre = prefix[(size_t)(k - 1) * nthr + tid]; }
+      if (e0.x != AFF_NONE) {
+        const uint32_t sidx = (uint32_t)k * nthr + tid;
+        Gf ox = px, oy = py;  // odd leftover, or q == infinity: pass p through
+        if (e0.y != AFF_NONE) {
+          if (gf_is_zero(px)) { ox = qx; oy = qy; }
+          else if (!gf_is_zero(qx)) {
+            Gf dd = gf_add(px, qx);
+            const bool same_x = gf_is_zero(dd);
+            const bool dbl = same_x && gf_eq(py, qy);
+            if (same_x && !dbl) {  // p == -q
+              ox = gf_zero(); oy = gf_zero();
+            } else {
+              Gf den = dbl ? px : dd;
+              Gf dinv, inv_next;
+              gf_mul2(pre, den, inv, L, dinv, inv_next);  // 1/den, and the running inverse stripped of this slot's factor
+              inv = inv_next;
+              Gf num = dbl ? py : gf_add(py, qy);
+              Gf lam = gf_mul(num, dinv, L);
+              if (dbl) lam = gf_add(lam, px);
+              ox = gf_add(gf_add(gf_sqr(lam), lam), dd);  // dd == 0 when doubling (curve a = 0)
+              // y3 = lam (x1 + x3) + x3 + y1   (the same expression covers the doubling)
+              oy = gf_add(gf_add(gf_mul(gf_add(px, ox), lam, L), ox), py);
+            }
+          }
+        }
+        out[sidx].x = ox; out[sidx].y = oy;
+      }
+      e0 = e1; e1 = e2; px = npx; qx = nqx; pre = npre;
     }
-    const Aff* pb = aff_ptr<FIRST>(pts, items, (d & 0x7fffffffu) + 1);
-    Gf qx = pb->x, qy = pb->y;
-    if (gf_is_zero(px)) { out[s].x = qx; out[s].y = qy; continue; }
-    if (gf_is_zero(qx)) { out[s].x = px; out[s].y = py; continue; }
-    Gf dd = gf_add(px, qx);
-    bool same_x = gf_is_zero(dd);
-    bool dbl = same_x && gf_eq(py, qy);
-    if (same_x && !dbl) {  // p == -q
-      out[s].x = gf_zero(); out[s].y = gf_zero();
-      continue;
-    }
-    Gf den = dbl ? px : dd;
-    Gf pre = prefix[(size_t)k * nthr + tid];
-    Gf dinv, inv_next;
-    gf_mul2(pre, den, inv, L, dinv, inv_next);  // 1/den, and the running inverse stripped of this slot's factor
-    inv = inv_next;
-    Gf num = dbl ? py : gf_add(py, qy);
-    Gf lam = gf_mul(num, dinv, L);
-    if (dbl) lam = gf_add(lam, px);
-    Gf x3 = gf_add(gf_add(gf_sqr(lam), lam), dd);  // dd == 0 when doubling (curve a = 0)
-    // y3 = lam (x1 + x3) + x3 + y1   (the same expression covers the doubling)
-    Gf y3 = gf_add(gf_add(gf_mul(gf_add(px, x3), lam, L), x3), py);
-    out[s].x = x3; out[s].y = y3;
   }
 }
 
@@ -889,6 +875,30 @@ struct MsmPlan {
   size_t e_max, t1_max, t2_max;
 };
 
+// Tuning knobs (tools/README.md): read from the environment ONCE per process, for sweeps and A/B runs; the defaults
+// are the measured optima.
+struct MsmTune {
+  int c = 0, k = 0, fixed_c = 0, fx_hi = -1;
+  bool proj_mode = false;
+  size_t aff_min = (size_t)1 << 19;
+  uint32_t quad_max = 0;
+  MsmTune() {
+    auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+    c = (int)geti("DVP_MSM_C", 0);
+    k = (int)geti("DVP_MSM_K", 0);
+    fixed_c = (int)geti("DVP_MSM_FIXED_C", 0);
+    fx_hi = (int)geti("DVP_FX_HI", -1);
+    const char* m = getenv("DVP_MSM_MODE");
+    proj_mode = m && !strcmp(m, "proj");
+    aff_min = (size_t)geti("DVP_MSM_AFF_MIN", (long long)aff_min);
+    quad_max = (uint32_t)geti("DVP_MSM_QUAD_MAX", 0);
+  }
+};
+static const MsmTune& msm_tune() {
+  static const MsmTune t;
+  return t;
+}
+
 static MsmPlan msm_plan(size_t n, const struct MsmFixedCtx* fx);
 // Windows of the fixed-base mode.  tau-adic expansions of reduced scalars are at most 234 digits long (measured: 229-233
 // typical) and their top 3-4 digits are mostly zero.  A uniform split leaves a short top window (234 mod c digits) whose
@@ -930,7 +940,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
     double cost = W * (8.4 * (double)n + 28.0 * (double)(1u << c));
     if (cost < best) { best = cost; p.c = c; }
   }
-  if (const char* e = getenv("DVP_MSM_C")) { int c = atoi(e); if (c >= 2 && c <= 15) p.c = c; }
+  if (msm_tune().c >= 2 && msm_tune().c <= 15) p.c = msm_tune().c;
   p.W = windows(p.c, &p.n_narrow);
   p.nkeys = (uint32_t)p.W << p.c;
   if (fixed) {  // all windows share one bucket set (bases pre-rotated by tau^(c w))
@@ -944,7 +954,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   uint32_t K = (uint32_t)(p.e_max / 262144);
   if (K < 8) K = 8;
   if (K > 16) K = 16;
-  if (const char* e = getenv("DVP_MSM_K")) { int k = atoi(e); if (k >= 2 && k <= 64) K = (uint32_t)k; }
+  if (msm_tune().k >= 2 && msm_tune().k <= 64) K = (uint32_t)msm_tune().k;
   p.K = K;
   p.t1_max = p.e_max / K + p.nkeys + 1;
   p.t2_max = p.t1_max / K + p.nkeys + 1;
@@ -981,12 +991,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
-                          (const void*)k_affine_round<true, 16>, (const void*)k_affine_round<false, 16>,
-                          (const void*)k_affine_round<true, 32>, (const void*)k_affine_round<false, 32>,
-                          (const void*)k_affine_round<true, 8>, (const void*)k_affine_round<false, 8>,
-                          (const void*)k_affine_round<true, 4>, (const void*)k_affine_round<false, 4>};
+                          (const void*)k_affine_round};
       for (const void* f : ec)
-        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q + AFF_B * EC_TPB * 4);
+        if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
     });
     DVP_HIP(attr_err);
   }
@@ -1019,13 +1026,13 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_choff = carve(sort_cells * 4);
   size_t o_bufA = carve(p.t1_max * sizeof(Ld));
   size_t o_bufB = carve(p.t2_max * sizeof(Ld));
-  const bool affine_mode = !(getenv("DVP_MSM_MODE") && !strcmp(getenv("DVP_MSM_MODE"), "proj"));
+  const MsmTune& tune = msm_tune();
+  const bool affine_mode = !tune.proj_mode;
   const size_t affA_n = p.e_max / 2 + p.nkeys + 1, affB_n = p.e_max / 4 + p.nkeys + 1;
-  const size_t aff_threads = (size_t)cdiv(cdiv(affA_n, AFF_B), EC_TPB) * EC_TPB;
   size_t o_affA = carve(affine_mode ? affA_n * sizeof(Aff) : 16);
   size_t o_affB = carve(affine_mode ? affB_n * sizeof(Aff) : 16);
-  size_t o_prefix = carve(affine_mode ? aff_threads * AFF_B * sizeof(Gf) : 16);
-  size_t o_gdesc = carve(affine_mode ? (aff_threads * AFF_B + 64) * 4 : 16);
+  size_t o_prefix = carve(affine_mode ? (affA_n + 64) * sizeof(Gf) : 16);  // one prefix product per output slot
+  size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_tail = carve((size_t)2 * p.W * p.c * sizeof(Ld));
   DVP_TRY(g_ws.ensure(o));
@@ -1056,11 +1063,12 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   Aff* affA = (Aff*)(base + o_affA);
   Aff* affB = (Aff*)(base + o_affB);
   Gf* prefix = (Gf*)(base + o_prefix);
-  uint32_t* gdesc = (uint32_t*)(base + o_gdesc);
+  uint2* gdesc = (uint2*)(base + o_gdesc);
   Ld* tail = (Ld*)(base + o_tail);
   const uint32_t nk = p.nkeys;
 
   ProfScope ps_total(PROF_MSM_TOTAL, st);
+  ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
   if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
@@ -1096,6 +1104,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
   }
+  ps_sort.stop();
   // ---- bucket accumulation: batched-affine pair rounds while a round still carries >= aff_min additions,
   // then the projective fan-in-K reducer on what is left (it has a short critical path and balances skew)
   uint32_t* d_max = (uint32_t*)(err + 1);
@@ -1104,8 +1113,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t max_cnt = 0;
   DVP_HIP(hipMemcpyAsync(&max_cnt, d_max, 4, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
-  size_t aff_min = (size_t)1 << 19;
-  if (const char* e = getenv("DVP_MSM_AFF_MIN")) aff_min = (size_t)atoll(e);
+  const size_t aff_min = tune.aff_min;
   const size_t e_est = (size_t)n * (size_t)((234 + p.c - 1) / p.c);  // the overflow windows are empty in practice
   int ra = 0;
   if (affine_mode)
@@ -1119,34 +1127,37 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
   if (ra > 0) {
-    const GfSqrTables& T = Tsq;
+    // resident threads of k_affine_round on this device (3 blocks of 256 per CU on MI355X: 196 608)
+    int dev = 0, n_cu = 256, blk_per_cu = 3;
+    DVP_HIP(hipGetDevice(&dev));
+    DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round, EC_TPB, EC_LDS));
+    if (blk_per_cu < 1) blk_per_cu = 1;
+    const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
     for (int r = 0; r < ra; ++r) {
       int nxt = (cur + 1) % 3;
       hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, 2u);
       DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
       size_t out_max = cap / 2 + nk + 1;
       Aff* outp = (r & 1) ? affB : affA;
-      // slots per inversion: big rounds 32 (fewer inversions per addition), then 16; rounds too small to fill the chip
-      // with 16-slot threads get 8 or 4, whose threads are short (the round is pure latency by then)
-      size_t b32_min = (size_t)8 << 20, b16_min = (size_t)1 << 21, b8_min = (size_t)1 << 20;
-      if (const char* e = getenv("DVP_MSM_B32_MIN")) b32_min = (size_t)atoll(e);
-      if (const char* e = getenv("DVP_MSM_B16_MIN")) b16_min = (size_t)atoll(e);
-      if (const char* e = getenv("DVP_MSM_B8_MIN")) b8_min = (size_t)atoll(e);
-      const int bsel = out_max >= b32_min ? 32 : out_max >= b16_min ? 16 : out_max >= b8_min ? 8 : 4;
-      uint32_t grid = cdiv(cdiv(out_max, bsel), EC_TPB);
-#define DVP_AFF_LAUNCH(FIRST, BB) \
-  hipLaunchKernelGGL((k_affine_round<FIRST, BB>), dim3(grid), dim3(EC_TPB), AFF_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, T, prefix, gdesc, outp)
-#define DVP_AFF_PICK(FIRST) \
-  do { if (bsel == 32) DVP_AFF_LAUNCH(FIRST, 32); else if (bsel == 16) DVP_AFF_LAUNCH(FIRST, 16); else if (bsel == 8) DVP_AFF_LAUNCH(FIRST, 8); else DVP_AFF_LAUNCH(FIRST, 4); } while (0)
-      if (r == 0) {
-        ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // the dominant kernel: first pair round (gathers the bases)
-        DVP_AFF_PICK(true);
+      // descriptors: lanes per bucket by the average bucket size of this round
+      const size_t per_key = (e_est >> (r + 1)) / nk;
+#define DVP_DESC_LAUNCH(FIRST, LPK) \
+  hipLaunchKernelGGL((k_round_desc<FIRST, LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, items, pc[cur], po[cur], po[nxt], nk, gdesc)
+#define DVP_DESC_PICK(FIRST) \
+  do { if (per_key >= 48) DVP_DESC_LAUNCH(FIRST, 64); else if (per_key >= 8) DVP_DESC_LAUNCH(FIRST, 16); else DVP_DESC_LAUNCH(FIRST, 4); } while (0)
+      if (r == 0) DVP_DESC_PICK(true); else DVP_DESC_PICK(false);
+#undef DVP_DESC_PICK
+#undef DVP_DESC_LAUNCH
+      // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
+      const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), AFF_BMAX);
+      const uint32_t grid = r_max * (aff_cap / EC_TPB) + 1;
+      const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
+      {
+        ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
+        hipLaunchKernelGGL(k_affine_round, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, Tsq, prefix, outp);
         ps0.stop();
-      } else {
-        DVP_AFF_PICK(false);
       }
-#undef DVP_AFF_PICK
-#undef DVP_AFF_LAUNCH
       pts_in = outp;
       cap = out_max;
       cur = nxt;
@@ -1185,9 +1196,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     }
     hipLaunchKernelGGL(k_bucket_gather, dim3(cdiv(nk, 256)), dim3(256), 0, st, in, pc[cur], po[cur], nk, bkt);
   }
+  ProfScope ps_tail(PROF_MSM_TAIL, st);  // merge tree, Frobenius tail, final add tree
   for (int j = 0; j < p.c; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
-    static const uint32_t quad_max = getenv("DVP_MSM_QUAD_MAX") ? (uint32_t)atoll(getenv("DVP_MSM_QUAD_MAX")) : MERGE_QUAD_MAX;
+    const uint32_t quad_max = tune.quad_max ? tune.quad_max : MERGE_QUAD_MAX;
     if (total <= quad_max)
       hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
     else
@@ -1205,6 +1217,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     cntT = half;
   }
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, Tsq, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
   // the scalar-range flag is the only thing that needs the host
@@ -1239,10 +1252,10 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
                   (cc > 18 ? 25.0 * (double)((1u << cc) - (1u << 18)) : 0.0);
     if (cost < best) { best = cost; best_c = cc; }
   }
-  if (const char* e = getenv("DVP_MSM_FIXED_C")) { int cc = atoi(e); if (cc >= 8 && cc <= FX_C_MAX) best_c = cc; }
+  if (msm_tune().fixed_c >= 8 && msm_tune().fixed_c <= FX_C_MAX) best_c = msm_tune().fixed_c;
   c->set_c(best_c);
   c->hi_bits = c->c / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
-  if (const char* e = getenv("DVP_FX_HI")) { int h = atoi(e); if (h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h; }
+  if (int h = msm_tune().fx_hi; h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h;
   DVP_HIP(hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff)));
   hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
   DVP_HIP(hipGetLastError());
