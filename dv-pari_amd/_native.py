@@ -31,6 +31,8 @@ _SIGS = {
     "dvp_device_count": (C.c_int, []),
     "dvp_set_device": (C.c_int, [C.c_int]),
     "dvp_last_error_index": (C.c_int64, []),
+    "dvp_tune_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "dvp_tune_reset": (None, []),
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),
     "dvp_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -57,6 +59,7 @@ _SIGS = {
     "dvp_msm_affine_dev": (C.c_int, [vp, vp, vp, sz, vp, vp, vp]),
     "dvp_msm_ctx_create": (C.c_int, [u64p, u8p, sz, sz, C.POINTER(vp)]),
     "dvp_msm_ctx_destroy": (None, [vp]),
+    "dvp_msm_ctx_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run": (C.c_int, [vp, u64p, sz, sz, u64p, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run_dev": (C.c_int, [vp, vp, sz, sz, vp, vp, vp]),
     "dvp_msm_xsk233": (C.c_int, [u8p, u8p, sz, u8p]),
@@ -119,6 +122,22 @@ class DvpError(RuntimeError):
 def check(status, where=""):
     if status != 0:
         raise DvpError(status, where)
+
+
+class tune:
+    """with tune(DVP_MSM_FIXED_C=20, DVP_MSM_AFF_MIN=64): ...  -- run-time tuning knobs (dvp_tune_set), restored on exit"""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            check(lib.dvp_tune_set(k.encode(), int(v)), f"dvp_tune_set({k})")
+        return self
+
+    def __exit__(self, *exc):
+        lib.dvp_tune_reset()
+        return False
 
 
 # ---- int <-> limb helpers (canonical little-endian 4 x u64) ----------------------------------------

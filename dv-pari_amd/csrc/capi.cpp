@@ -4,6 +4,7 @@
 #include <mutex>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 namespace dvp {
 thread_local int64_t g_last_error_index = -1;
@@ -42,7 +43,40 @@ void prof_collect() {
   }
   g_prof_pending.clear();
 }
+
+static void tune_from_env(Tune& t) {
+  t = Tune();
+  auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
+  t.msm_c = geti("DVP_MSM_C", t.msm_c);
+  t.msm_k = geti("DVP_MSM_K", t.msm_k);
+  t.msm_fixed_c = geti("DVP_MSM_FIXED_C", t.msm_fixed_c);
+  t.fx_hi = geti("DVP_FX_HI", t.fx_hi);
+  const char* m = getenv("DVP_MSM_MODE");
+  t.msm_proj = (m && !strcmp(m, "proj")) ? 1 : 0;
+  t.msm_aff_min = geti("DVP_MSM_AFF_MIN", t.msm_aff_min);
+  t.msm_aff_bmax = geti("DVP_MSM_AFF_BMAX", t.msm_aff_bmax);
+  t.msm_quad_max = geti("DVP_MSM_QUAD_MAX", t.msm_quad_max);
+  t.msm_fixed_min = geti("DVP_MSM_FIXED_MIN", t.msm_fixed_min);
+  t.horner_max_pub = geti("DVP_HORNER_MAX_PUB", t.horner_max_pub);
+}
+Tune& tune() {
+  static Tune t = [] { Tune x; tune_from_env(x); return x; }();
+  return t;
+}
 }  // namespace dvp
+
+extern "C" int dvp_tune_set(const char* name, long long value) {
+  if (!name) return DVP_EINVAL;
+  dvp::Tune& t = dvp::tune();
+  struct { const char* n; long long* v; } tab[] = {
+      {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi},
+      {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax},
+      {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub}};
+  for (auto& e : tab)
+    if (!strcmp(name, e.n)) { *e.v = value; return DVP_OK; }
+  return DVP_EINVAL;
+}
+extern "C" void dvp_tune_reset(void) { dvp::tune_from_env(dvp::tune()); }
 
 extern "C" void dvp_profile_enable(int on) { dvp::g_prof_enabled = on != 0; }
 extern "C" void dvp_profile_reset(void) {

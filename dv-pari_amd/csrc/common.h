@@ -59,6 +59,23 @@ struct DevBuf {
   }
 };
 
+// Tuning knobs (tools/README.md).  Defaults are the measured optima; the environment (DVP_MSM_C, ...) is read ONCE, at
+// the first use, and dvp_tune_set / dvp_tune_reset (include/dvpari.h) change a knob at run time -- that is how the tests
+// force every window size / sort flavour / round shape, and how tools/ sweep.  Never read on a hot path.
+struct Tune {
+  long long msm_c = 0;          // DVP_MSM_C: one-shot window bits (0 = cost model)
+  long long msm_k = 0;          // DVP_MSM_K: fan-in of the projective reducer (0 = default)
+  long long msm_fixed_c = 0;    // DVP_MSM_FIXED_C: fixed-base window bits (0 = cost model)
+  long long fx_hi = -1;         // DVP_FX_HI: level-1 partition bits of the fixed-base sort (-1 = c/2)
+  long long msm_proj = 0;       // DVP_MSM_MODE=proj: skip the batched-affine rounds
+  long long msm_aff_min = 1ll << 19;   // DVP_MSM_AFF_MIN: pair rounds run while a round has this many additions
+  long long msm_aff_bmax = 48;  // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns
+  long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
+  long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables
+  long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)
+};
+Tune& tune();
+
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ---- per-kernel HIP-event timers (bench.py's roofline leg; off by default) ------------------------

@@ -634,19 +634,19 @@ k_round_desc(const uint32_t* __restrict__ items, const uint32_t* __restrict__ cn
 // 12 waves per CU).  With `cap` = resident threads of the chip, R = ceil(total / (cap * AFF_BMAX)) chip-fulls of
 // B = ceil(total / (cap * R)) slots each: B is 25..48 in the big rounds and shrinks to 1..8 in the last ones, where a
 // round is pure latency and short threads are what is wanted.
-constexpr int AFF_BMAX = 48;
-__device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_t cap) {
+constexpr uint32_t AFF_BMAX = 48;  // default (Tune::msm_aff_bmax)
+__device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_t cap, uint32_t bmax) {
   const uint32_t units = (total + cap - 1) / cap;  // slots per resident thread if the round were one chip-full
-  const uint32_t R = (units + AFF_BMAX - 1) / AFF_BMAX;
+  const uint32_t R = (units + bmax - 1) / bmax;
   return R ? (units + R - 1) / R : 1;
 }
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, const uint32_t* __restrict__ total_ptr /* ooff[nkeys] */,
-               uint32_t cap, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
+               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
   const uint32_t total = *total_ptr;
-  const int B = (int)aff_slots_per_thread(total, cap);
+  const int B = (int)aff_slots_per_thread(total, cap, bmax);
   const uint32_t nthr = (total + B - 1) / B;
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nthr) return;
@@ -875,30 +875,6 @@ struct MsmPlan {
   size_t e_max, t1_max, t2_max;
 };
 
-// Tuning knobs (tools/README.md): read from the environment ONCE per process, for sweeps and A/B runs; the defaults
-// are the measured optima.
-struct MsmTune {
-  int c = 0, k = 0, fixed_c = 0, fx_hi = -1;
-  bool proj_mode = false;
-  size_t aff_min = (size_t)1 << 19;
-  uint32_t quad_max = 0;
-  MsmTune() {
-    auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
-    c = (int)geti("DVP_MSM_C", 0);
-    k = (int)geti("DVP_MSM_K", 0);
-    fixed_c = (int)geti("DVP_MSM_FIXED_C", 0);
-    fx_hi = (int)geti("DVP_FX_HI", -1);
-    const char* m = getenv("DVP_MSM_MODE");
-    proj_mode = m && !strcmp(m, "proj");
-    aff_min = (size_t)geti("DVP_MSM_AFF_MIN", (long long)aff_min);
-    quad_max = (uint32_t)geti("DVP_MSM_QUAD_MAX", 0);
-  }
-};
-static const MsmTune& msm_tune() {
-  static const MsmTune t;
-  return t;
-}
-
 static MsmPlan msm_plan(size_t n, const struct MsmFixedCtx* fx);
 // Windows of the fixed-base mode.  tau-adic expansions of reduced scalars are at most 234 digits long (measured: 229-233
 // typical) and their top 3-4 digits are mostly zero.  A uniform split leaves a short top window (234 mod c digits) whose
@@ -940,7 +916,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
     double cost = W * (8.4 * (double)n + 28.0 * (double)(1u << c));
     if (cost < best) { best = cost; p.c = c; }
   }
-  if (msm_tune().c >= 2 && msm_tune().c <= 15) p.c = msm_tune().c;
+  if (tune().msm_c >= 2 && tune().msm_c <= 15) p.c = (int)tune().msm_c;
   p.W = windows(p.c, &p.n_narrow);
   p.nkeys = (uint32_t)p.W << p.c;
   if (fixed) {  // all windows share one bucket set (bases pre-rotated by tau^(c w))
@@ -954,7 +930,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   uint32_t K = (uint32_t)(p.e_max / 262144);
   if (K < 8) K = 8;
   if (K > 16) K = 16;
-  if (msm_tune().k >= 2 && msm_tune().k <= 64) K = (uint32_t)msm_tune().k;
+  if (tune().msm_k >= 2 && tune().msm_k <= 64) K = (uint32_t)tune().msm_k;
   p.K = K;
   p.t1_max = p.e_max / K + p.nkeys + 1;
   p.t2_max = p.t1_max / K + p.nkeys + 1;
@@ -1026,12 +1002,12 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_choff = carve(sort_cells * 4);
   size_t o_bufA = carve(p.t1_max * sizeof(Ld));
   size_t o_bufB = carve(p.t2_max * sizeof(Ld));
-  const MsmTune& tune = msm_tune();
-  const bool affine_mode = !tune.proj_mode;
+  const Tune tn = tune();
+  const bool affine_mode = !tn.msm_proj;
   const size_t affA_n = p.e_max / 2 + p.nkeys + 1, affB_n = p.e_max / 4 + p.nkeys + 1;
   size_t o_affA = carve(affine_mode ? affA_n * sizeof(Aff) : 16);
   size_t o_affB = carve(affine_mode ? affB_n * sizeof(Aff) : 16);
-  size_t o_prefix = carve(affine_mode ? (affA_n + 64) * sizeof(Gf) : 16);  // one prefix product per output slot
+  size_t o_prefix = carve(affine_mode ? (affA_n + 128) * sizeof(Gf) : 16);  // one prefix product per output slot
   size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_tail = carve((size_t)2 * p.W * p.c * sizeof(Ld));
@@ -1113,7 +1089,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t max_cnt = 0;
   DVP_HIP(hipMemcpyAsync(&max_cnt, d_max, 4, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
-  const size_t aff_min = tune.aff_min;
+  const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
   const size_t e_est = (size_t)n * (size_t)((234 + p.c - 1) / p.c);  // the overflow windows are empty in practice
   int ra = 0;
   if (affine_mode)
@@ -1134,6 +1110,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round, EC_TPB, EC_LDS));
     if (blk_per_cu < 1) blk_per_cu = 1;
     const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
+    const uint32_t aff_bmax = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
     for (int r = 0; r < ra; ++r) {
       int nxt = (cur + 1) % 3;
       hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, 2u);
@@ -1150,12 +1127,12 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
 #undef DVP_DESC_PICK
 #undef DVP_DESC_LAUNCH
       // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
-      const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), AFF_BMAX);
+      const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax);
       const uint32_t grid = r_max * (aff_cap / EC_TPB) + 1;
       const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
       {
         ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
-        hipLaunchKernelGGL(k_affine_round, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, Tsq, prefix, outp);
+        hipLaunchKernelGGL(k_affine_round, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
         ps0.stop();
       }
       pts_in = outp;
@@ -1199,7 +1176,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   ProfScope ps_tail(PROF_MSM_TAIL, st);  // merge tree, Frobenius tail, final add tree
   for (int j = 0; j < p.c; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
-    const uint32_t quad_max = tune.quad_max ? tune.quad_max : MERGE_QUAD_MAX;
+    const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
     if (total <= quad_max)
       hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
     else
@@ -1239,6 +1216,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 // ---- fixed-base contexts (the prover's SRS vectors) -----------------------------------------------
 // range_hint = number of bases a typical call will cover (the per-GPU shard): the shared window size c
 // minimises an empirical cost in field multiplications (pair additions + a per-bucket term, see below)
+void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
@@ -1252,14 +1230,20 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
                   (cc > 18 ? 25.0 * (double)((1u << cc) - (1u << 18)) : 0.0);
     if (cost < best) { best = cost; best_c = cc; }
   }
-  if (msm_tune().fixed_c >= 8 && msm_tune().fixed_c <= FX_C_MAX) best_c = msm_tune().fixed_c;
+  if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= FX_C_MAX) best_c = (int)tune().msm_fixed_c;
   c->set_c(best_c);
   c->hi_bits = c->c / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
-  if (int h = msm_tune().fx_hi; h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h;
-  DVP_HIP(hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff)));
-  hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
-  DVP_HIP(hipGetLastError());
-  DVP_HIP(hipDeviceSynchronize());
+  if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h;
+  hipError_t e = hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    msm_fixed_destroy(c);
+    return hip_fail(e, "msm_fixed_create", __FILE__, __LINE__);
+  }
   *out = c;
   return DVP_OK;
 }
@@ -1321,6 +1305,7 @@ struct dvp_msm_ctx {
   size_t n = 0;
 };
 
+extern "C" void dvp_msm_ctx_destroy(dvp_msm_ctx* c);
 extern "C" int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out) {
   if (!bases_xy || !out || !n || n >= ((size_t)1 << 27)) return DVP_EINVAL;
   if (!range_hint || range_hint > n) range_hint = n;
@@ -1329,11 +1314,12 @@ extern "C" int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases
   DVP_HIP(hipMemcpy(db.p, bases_xy, n * sizeof(Aff), hipMemcpyHostToDevice));
   dvp_msm_ctx* c = new dvp_msm_ctx();
   c->n = n;
-  DVP_HIP(hipMalloc((void**)&c->d_inf, n));
-  if (bases_inf) DVP_HIP(hipMemcpy(c->d_inf, bases_inf, n, hipMemcpyHostToDevice));
-  else DVP_HIP(hipMemset(c->d_inf, 0, n));
+  auto fail = [&](int rc) { dvp_msm_ctx_destroy(c); return rc; };
+  hipError_t e = hipMalloc((void**)&c->d_inf, n);
+  if (e == hipSuccess) e = bases_inf ? hipMemcpy(c->d_inf, bases_inf, n, hipMemcpyHostToDevice) : hipMemset(c->d_inf, 0, n);
+  if (e != hipSuccess) return fail(hip_fail(e, "dvp_msm_ctx_create", __FILE__, __LINE__));
   int rc = msm_fixed_create(db.as<Aff>(), (uint32_t)n, range_hint, &c->fx);
-  if (rc != DVP_OK) { (void)hipFree(c->d_inf); delete c; return rc; }
+  if (rc != DVP_OK) return fail(rc);
   *out = c;
   return DVP_OK;
 }
@@ -1342,6 +1328,10 @@ extern "C" void dvp_msm_ctx_destroy(dvp_msm_ctx* c) {
   msm_fixed_destroy(c->fx);
   if (c->d_inf) (void)hipFree(c->d_inf);
   delete c;
+}
+extern "C" int dvp_msm_ctx_plan(const dvp_msm_ctx* c, int* c_bits, int* windows) {
+  if (!c || !c_bits || !windows) return DVP_EINVAL;
+  return msm_fixed_info(c->fx, c_bits, windows);
 }
 // sum_{i in [lo,hi)} scalars[i - lo] * base[i]; d_scalars holds hi - lo canonical scalars (device)
 extern "C" int dvp_msm_ctx_run_dev(dvp_msm_ctx* c, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {

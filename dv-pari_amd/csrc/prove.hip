@@ -540,7 +540,7 @@ extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, 
   }
   // extend_evals (src/proving.rs:410-422): a, b, c' always; i only when its degree makes Horner the dearer route
   uint32_t hmax = HORNER_MAX_PUB;
-  if (const char* e = getenv("DVP_HORNER_MAX_PUB")) hmax = (uint32_t)atoi(e);  // tests force either route
+  if (tune().horner_max_pub >= 0) hmax = (uint32_t)tune().horner_max_pub;  // tests force either route
   const bool horner = p->n_pub <= hmax;
   const uint32_t n_ext = horner ? 3 : 4;
   DVP_HIP(hipMemcpyAsync(p->E2, p->E, n_ext * (size_t)m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
@@ -575,8 +575,7 @@ extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_
   const Aff* bs = which ? p->bases_k : p->bases_a;
   const uint8_t* inf = which ? p->inf_k : p->inf_a;
   // fixed-base mode pays off once the shared 2^20-bucket set is well filled
-  size_t fixed_min = (size_t)1 << 16;
-  if (const char* e = getenv("DVP_MSM_FIXED_MIN")) fixed_min = (size_t)atoll(e);
+  const size_t fixed_min = (size_t)(tune().msm_fixed_min > 0 ? tune().msm_fixed_min : 1);
   if (hi - lo >= fixed_min && total < ((size_t)1 << 27)) {
     if (!p->fx[which]) DVP_TRY(msm_fixed_create(bs, (uint32_t)total, hi - lo, &p->fx[which]));
     return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)lo, (uint32_t)hi, d_out_xy, d_out_inf, (hipStream_t)stream);

@@ -121,6 +121,12 @@ class FixedBaseMsm:
 
     __del__ = close
 
+    def plan(self):
+        """(window bits, windows) the context settled on"""
+        c, w = C.c_int(0), C.c_int(0)
+        check(lib.dvp_msm_ctx_plan(self._h, C.byref(c), C.byref(w)), "dvp_msm_ctx_plan")
+        return c.value, w.value
+
     def run(self, scalars: np.ndarray, lo: int = 0, hi: int = None):
         hi = self.n if hi is None else hi
         s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)

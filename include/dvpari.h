@@ -52,9 +52,16 @@ int dvp_set_device(int device_id);
 /* last failing index for DVP_EDECODE / DVP_EUNSAT / DVP_EINVAL (thread-local), or -1 */
 int64_t dvp_last_error_index(void);
 
+/* Tuning knobs for tests, sweeps and A/B runs (tools/README.md lists them; the defaults are the measured optima and
+ * the environment variables of the same names are read once, at first use).  dvp_tune_set returns DVP_EINVAL for an
+ * unknown name; dvp_tune_reset goes back to defaults + environment.  Not thread-safe against running calls. */
+int dvp_tune_set(const char* name, long long value);
+void dvp_tune_reset(void);
+
 /* Per-kernel HIP-event timers for the measurement harness (bench.py): off by default.  Names:
- * "msm_affine_round0" (k_affine_round<true>, the dominant MSM kernel), "msm_total", "extend_total",
- * "prove_total". */
+ * "msm_affine_round0" (first k_affine_round of an MSM, the dominant kernel: it gathers the bases), "msm_affine_rest"
+ * (the later pair rounds), "msm_sort" (recode + counting sort), "msm_tail" (merge tree, Frobenius tail), "msm_total",
+ * "extend_total", "prove_total". */
 void dvp_profile_enable(int on);
 void dvp_profile_reset(void);
 int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
@@ -123,6 +130,8 @@ int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void
 typedef struct dvp_msm_ctx dvp_msm_ctx;
 int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out);
 void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
+/* window bits c (all windows share one set of 2^c buckets) and window count the context settled on */
+int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 /* same seam with the reference's own wire formats: scalars n x 32 B canonical LE, bases n x 30 B

@@ -168,12 +168,9 @@ def test_sparse_cache_dir_with_witness_file(dvp, tmp_path):
     proof = dvp.proving.Proof.prove(cache, wpub, wprv)
     assert dvp.srs.verify(td, pub, proof)
     dvp.proving.release_cache_dir(cache)
-    os.environ["DVP_HORNER_MAX_PUB"] = "0"
-    try:
+    with dvp.tune(DVP_HORNER_MAX_PUB=0):  # i(X) on D' through a fourth extend instead of Horner
         assert dvp.proving.Proof.prove(cache, wpub, wprv) == proof
-    finally:
-        del os.environ["DVP_HORNER_MAX_PUB"]
-        dvp.proving.release_cache_dir()
+    dvp.proving.release_cache_dir()
     # wrong witness length: |assignment| != |g_m| (assert_eq!, src/curve.rs:142)
     with pytest.raises(dvp.DvpError) as e:
         dvp.proving.Proof.prove(cache, wpub, wprv[:-1])

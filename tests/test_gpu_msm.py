@@ -11,7 +11,7 @@ import pytest
 
 import pyref as o
 import c_oracle as co
-from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod
+from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast
 
 pytestmark = pytest.mark.gpu
 OSSL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k233_openssl.json")))["vectors"]
@@ -136,11 +136,8 @@ def test_fixed_base_msm_context(dvp, hint):
     inf[5] = 1
     fb = dvp.curve.FixedBaseMsm(bases, inf, hint if hint <= n else 0) if hint <= n else None
     if fb is None:
-        os.environ["DVP_MSM_FIXED_C"] = "20"
-        try:
+        with dvp.tune(DVP_MSM_FIXED_C=20):
             fb = dvp.curve.FixedBaseMsm(bases, inf, 0)
-        finally:
-            del os.environ["DVP_MSM_FIXED_C"]
     ks, ss = from_limbs(k), from_limbs(s)
 
     def expect(lo, hi):
@@ -148,16 +145,14 @@ def test_fixed_base_msm_context(dvp, hint):
 
     xy, is_inf = fb.run(s)
     assert np_to_pt(xy, is_inf) == expect(0, n)
-    # the 32-additions-per-inversion flavour of the pair rounds (normally only rounds of >= 8M additions)
-    os.environ["DVP_MSM_B32_MIN"] = "1"
-    os.environ["DVP_MSM_AFF_MIN"] = "64"
-    try:
-        xy, is_inf = fb.run(s)
-        assert np_to_pt(xy, is_inf) == expect(0, n)
-        xy, is_inf = fb.run(s[7:4000], 7, 4000)
-        assert np_to_pt(xy, is_inf) == expect(7, 4000)
-    finally:
-        del os.environ["DVP_MSM_B32_MIN"], os.environ["DVP_MSM_AFF_MIN"]
+    # pair rounds all the way down (normally only while a round has >= 2^19 additions), with 1, 3 and 64 additions per
+    # shared inversion at most (the device picks the count per round; one chip-full holds this whole input)
+    for bmax in (1, 3, 64):
+        with dvp.tune(DVP_MSM_AFF_MIN=64, DVP_MSM_AFF_BMAX=bmax):
+            xy, is_inf = fb.run(s)
+            assert np_to_pt(xy, is_inf) == expect(0, n)
+            xy, is_inf = fb.run(s[7:4000], 7, 4000)
+            assert np_to_pt(xy, is_inf) == expect(7, 4000)
     parts = []
     for lo, hi in ((0, 1500), (1500, 1501), (1501, 6000), (10, 10)):
         xy, is_inf = fb.run(s[lo:hi], lo, hi)
@@ -202,21 +197,26 @@ def test_points_add_like_curvepoint_add(dvp):
         assert np_to_pt(xy[i], bool(inf[i])) == e, i
 
 
-def test_msm_2_20_linearity(dvp):
-    """full-size property (the reference's own MSM test is linearity, src/curve.rs:198-232): with one base vector of
-    2^20 points, MSM(s) + MSM(t) == MSM(s + t) and MSM(3 s) == 3 MSM(s), for both the one-shot and the fixed-base path"""
-    n = 1 << 20
-    bases, _ = dvp.curve.point_scalar_mul_gen_batch(rand_fr_np(n, 81))
+@pytest.mark.parametrize("log_n", [20, 22])
+def test_msm_full_size_dlog_and_linearity(dvp, log_n):
+    """full size, oracle-backed: bases k_i*G, so MSM(s) must equal (sum s_i k_i)*G computed by the OpenSSL-pinned C
+    oracle -- for the one-shot and the fixed-base path (the shape of the reference's test_msm, src/curve.rs:218-232);
+    plus the reference's linearity property MSM(s) + MSM(t) == MSM(s + t) (src/curve.rs:198-215)"""
+    n = 1 << log_n
+    k = rand_fr_np(n, 81)
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
     s, t = rand_fr_np(n, 82), rand_fr_np(n, 83)
-    si, ti = from_limbs(s), from_limbs(t)
-    st_sum = to_limbs([(a + b) % o.P for a, b in zip(si, ti)])
-    s3 = to_limbs([3 * a % o.P for a in si])
     fb = dvp.curve.FixedBaseMsm(bases)
-    for run in (lambda sc: gpu_msm(dvp, sc, bases), lambda sc: np_to_pt(*fb.run(sc))):
-        ps, pt, pst, p3 = run(s), run(t), run(st_sum), run(s3)
-        assert o.k233_add(ps, pt) == pst
-        assert o.k233_add(o.k233_add(ps, ps), ps) == p3
-    assert gpu_msm(dvp, s, bases) == np_to_pt(*fb.run(s))
+    exp_s = co.k233_mulgen(np_dot_mod_fast(s, k))
+    ps_one, ps_fix = gpu_msm(dvp, s, bases), np_to_pt(*fb.run(s))
+    assert ps_one == exp_s and ps_fix == exp_s
+    if log_n == 20:
+        exp_t = co.k233_mulgen(np_dot_mod_fast(t, k))
+        assert np_to_pt(*fb.run(t)) == exp_t
+        st_sum = to_limbs([(a + b) % o.P for a, b in zip(from_limbs(s), from_limbs(t))])
+        pst = np_to_pt(*fb.run(st_sum))
+        assert o.k233_add(exp_s, exp_t) == pst == gpu_msm(dvp, st_sum, bases)
+    fb.close()
 
 
 def test_fixed_base_vs_one_shot_randomised(dvp):
@@ -231,10 +231,9 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     s[: len(special)] = to_limbs(special)
     ks, ss = from_limbs(k), from_limbs(s)
     for c in range(8, 21):
-        os.environ["DVP_MSM_FIXED_C"] = str(c)
-        os.environ["DVP_MSM_AFF_MIN"] = str(rnd.choice([16, 256, 4096, 1 << 19]))
-        try:
+        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]), DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
             fb = dvp.curve.FixedBaseMsm(bases)
+            assert fb.plan()[0] == c
             for _ in range(3):
                 lo = rnd.randrange(0, n - 1)
                 hi = rnd.randrange(lo + 1, n + 1)
@@ -243,5 +242,3 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
                 assert np_to_pt(xy, is_inf) == exp, (c, lo, hi)
                 assert gpu_msm(dvp, s[lo:hi], bases[lo:hi]) == exp, (c, lo, hi)
             fb.close()
-        finally:
-            del os.environ["DVP_MSM_FIXED_C"], os.environ["DVP_MSM_AFF_MIN"]

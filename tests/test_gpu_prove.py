@@ -121,18 +121,13 @@ def test_synthetic_2_14_verifies(dvp):
     assert not dvp.srs.verify(td, [pub[0], (pub[1] + 1) % o.P], proof)
     # fixed-base MSM mode (bases pre-rotated by tau^(c w), one shared 2^c-bucket set): same bytes for the
     # model-chosen window (single-level sort) and for forced c = 17 / 20 (two-level sort)
-    os.environ["DVP_MSM_FIXED_MIN"] = "1"
-    try:
-        for forced in (None, "17", "20"):
-            if forced:
-                os.environ["DVP_MSM_FIXED_C"] = forced
+    for forced in (0, 17, 20):
+        with dvp.tune(DVP_MSM_FIXED_MIN=1, DVP_MSM_FIXED_C=forced):
             pv3 = dvp.proving.Prover(inst)
             pv3.set_srs(dvp.srs.verifier_runs_setup(pv3, inst, td))
             assert pv3.prove(pub, prv) == proof, forced
+            assert forced == 0 or pv3.msm_plan(1)[0] == forced
             pv3.close()
-    finally:
-        del os.environ["DVP_MSM_FIXED_MIN"]
-        os.environ.pop("DVP_MSM_FIXED_C", None)
     # SRS handed over in the reference's file format (30-byte encodings) gives the same proof
     pv2 = dvp.proving.Prover(inst)
     srs = dvp.srs.verifier_runs_setup(pv2, inst, td)
@@ -218,15 +213,28 @@ def test_sharded_prove_simulated_ranks(dvp, world):
 
 
 def test_prove_2_20_full_size(dvp):
-    """BASELINE config #4 at full size (2^20 constraints): the proof verifies, is reproducible, and a tampered a0 or
-    public input is rejected; the cache-less Prover and the sharded path (3 simulated ranks) give identical bytes."""
+    """BASELINE config #4 at full size (2^20 constraints), oracle-backed (tests/fullsize.py): the domain and the SRS
+    scalars are pinned on sampled indices by their definitions, commit_p / kzg_k by the discrete-log identity against
+    the OpenSSL-pinned oracle (src/proving.rs:463,512,680), alpha by the oracle transcript, a0 / b0 by the barycentric
+    formula in python big ints (src/ec_fft.rs:455-491), and the whole by the designated-verifier equation on discrete
+    logs (src/srs.rs:374-428).  Then: reproducible bytes, tampering rejected, the sharded path (3 simulated ranks)
+    gives identical bytes."""
     import torch
+    import fullsize as fs
 
+    rnd = random.Random(2020)
     inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(20)
-    td = dvp.srs.Trapdoor(0x1234567 + (1 << 200), 0x7654321 + (1 << 190), 0xABCDEF + (1 << 180))
+    trap = (0x1234567 + (1 << 200), 0x7654321 + (1 << 190), 0xABCDEF + (1 << 180))
+    td = dvp.srs.Trapdoor(*trap)
     pv = dvp.proving.Prover(inst)
-    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    scalars = dvp.srs.srs_scalars(pv, inst, td)
+    g_m, g_q, g_k = scalars
+    D, D2 = fs.check_domains(pv, 20, rnd)
+    fs.check_srs_scalars(inst, trap, D, D2, g_m, g_q, g_k, rnd)
+    mg = dvp.curve.point_scalar_mul_gen_batch
+    pv.set_srs(dvp.srs.SRS(mg(g_m), mg(g_q), tuple(mg(v) for v in g_k)))
     proof = pv.prove(pub, prv)
+    fs.check_proof(dvp, pv, inst, trap, pub, prv, proof, scalars, D=D, check_bary=True, rnd=rnd)
     assert dvp.srs.verify(td, pub, proof)
     assert pv.prove(pub, prv) == proof
     bad = dvp.proving.Proof(proof.commit_p, proof.kzg_k, proof.a0, (int.from_bytes(proof.b0, "little") ^ 2).to_bytes(29, "little"))

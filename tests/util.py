@@ -40,3 +40,22 @@ def rand_fr_np(n, seed):
 def np_dot_mod(a, b):
     """sum a_i*b_i mod p for two [n,4] limb arrays (python ints)"""
     return sum(x * y for x, y in zip(from_limbs(a), from_limbs(b))) % o.P
+
+
+def np_dot_mod_fast(a, b):
+    """sum a_i*b_i mod p for two [n,4] limb arrays, EXACT, in numpy only (no product code): the operands are cut
+    into 16-bit limbs and the 16 x 16 limb-pair sums come from float64 matrix products over chunks of 2^18 rows
+    (every partial sum < 2^32 * 2^18 = 2^50 is exact in a double); the chunks are recombined with python ints.
+    ~1 s per 10 M terms, against ~1 us per term for a python loop -- this is what lets the full-size tests apply the
+    discrete-log identity sum s_i (k_i G) = (sum s_i k_i) G."""
+    A = np.ascontiguousarray(a, dtype="<u8").reshape(-1, 4).view("<u2").reshape(-1, 16)
+    B = np.ascontiguousarray(b, dtype="<u8").reshape(-1, 4).view("<u2").reshape(-1, 16)
+    assert A.shape == B.shape
+    total = 0
+    step = 1 << 18
+    for lo in range(0, A.shape[0], step):
+        M = A[lo:lo + step].astype(np.float64).T @ B[lo:lo + step].astype(np.float64)
+        for i in range(16):
+            for j in range(16):
+                total += int(M[i, j]) << (16 * (i + j))
+    return total % o.P

@@ -16,7 +16,7 @@ st=torch.cuda.current_stream().cuda_stream
 ref=None
 for cfg in sys.argv[2:]:
     c,K=cfg.split(',')
-    os.environ['DVP_MSM_C']=c; os.environ['DVP_MSM_K']=K
+    dvp.lib.dvp_tune_set(b'DVP_MSM_C',int(c)); dvp.lib.dvp_tune_set(b'DVP_MSM_K',int(K))
     for it in range(2):
         dvp.curve.multi_scalar_mul_dev(d_s.data_ptr(),d_b.data_ptr(),0,n,d_out.data_ptr(),d_inf.data_ptr(),st)
     torch.cuda.synchronize()
