@@ -52,6 +52,7 @@ _SIGS = {
     "dvp_fr_vec_mul": (C.c_int, [u64p, u64p, sz, u64p]),
     "dvp_fr_vec_scale": (C.c_int, [u64p, u64p, sz, u64p]),
     "dvp_fr_vec_scalar_sub": (C.c_int, [u64p, u64p, sz, u64p]),
+    "dvp_fr_vec_axpy": (C.c_int, [u64p, u64p, u64p, sz, u64p]),
     "dvp_fr_vec_dot": (C.c_int, [u64p, u64p, sz, u64p]),
     "dvp_fr_spmv": (C.c_int, [vp, vp, vp, u32, u64p, u32, u64p, u32, u64p]),
     "dvp_barycentric_eval": (C.c_int, [u64p, u64p, u64p, u64p, sz, u64p, u64p]),
@@ -99,6 +100,7 @@ _SIGS = {
     "dvp_prover_open_cache_dir": (C.c_int, [C.c_char_p, u32, C.POINTER(vp)]),
     "dvp_prove_cache_dir": (C.c_int, [C.c_char_p, u64p, u32, u64p, u32, u8p]),
     "dvp_cache_dir_release": (None, [C.c_char_p]),
+    "dvp_cache_dir_prover": (C.c_int, [C.c_char_p, u32, C.POINTER(vp)]),
     "dvp_transcript_challenge": (C.c_int, [u8p, u64p, u32, u64p]),
     "dvp_blake3": (C.c_int, [u8p, sz, u8p]),
 }

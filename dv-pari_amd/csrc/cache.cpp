@@ -19,9 +19,13 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
 
 #include "../../include/dvpari.h"
 
@@ -200,8 +204,39 @@ std::string join(const char* dir, const char* name) {
   return s + name;
 }
 
+// Provers opened by dvp_prove_cache_dir, keyed by (cache_dir, n_public, HIP device).  An entry is shared: a caller holds
+// a reference for the whole of its prove, which runs under the entry's own mutex (a dvp_prover is one set of device
+// buffers: two proofs on it must not overlap), and dvp_cache_dir_release only drops the table's reference, so the
+// prover is destroyed when the last prove in flight returns.
+struct OpenEntry {
+  dvp_prover* p = nullptr;
+  std::mutex mu;
+  ~OpenEntry() { if (p) dvp_prover_destroy(p); }
+};
+typedef std::tuple<std::string, uint32_t, int> OpenKey;
 std::mutex g_open_mu;
-std::map<std::pair<std::string, uint32_t>, dvp_prover*> g_open;
+std::map<OpenKey, std::shared_ptr<OpenEntry>> g_open;
+
+int current_device() {
+  int d = -1;
+  (void)hipGetDevice(&d);
+  return d;
+}
+int open_entry(const char* cache_dir, uint32_t n_public, std::shared_ptr<OpenEntry>* out) {
+  std::lock_guard<std::mutex> g(g_open_mu);
+  OpenKey key(std::string(cache_dir), n_public, current_device());
+  auto it = g_open.find(key);
+  if (it == g_open.end()) {
+    dvp_prover* p = nullptr;
+    int rc = dvp_prover_open_cache_dir(cache_dir, n_public, &p);
+    if (rc) return rc;
+    auto e = std::make_shared<OpenEntry>();
+    e->p = p;
+    it = g_open.emplace(key, e).first;
+  }
+  *out = it->second;
+  return DVP_OK;
+}
 
 }  // namespace
 
@@ -370,30 +405,30 @@ extern "C" int dvp_prover_open_cache_dir(const char* cache_dir, uint32_t n_publi
 extern "C" int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public_inputs, uint32_t n_public,
                                    const uint64_t* private_inputs, uint32_t n_private, uint8_t proof[118]) {
   if (!cache_dir || !proof) return DVP_EINVAL;
-  dvp_prover* p = nullptr;
-  {
-    std::lock_guard<std::mutex> g(g_open_mu);
-    auto key = std::make_pair(std::string(cache_dir), n_public);
-    auto it = g_open.find(key);
-    if (it == g_open.end()) {
-      int rc = dvp_prover_open_cache_dir(cache_dir, n_public, &p);
-      if (rc) return rc;
-      g_open.emplace(key, p);
-    } else {
-      p = it->second;
-    }
-  }
-  return dvp_prove(p, public_inputs, n_public, private_inputs, n_private, proof);
+  std::shared_ptr<OpenEntry> e;
+  int rc = open_entry(cache_dir, n_public, &e);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(e->mu);
+  return dvp_prove(e->p, public_inputs, n_public, private_inputs, n_private, proof);
+}
+
+// the prover dvp_prove_cache_dir uses for (cache_dir, n_public) on the current device, opened if need be: BORROWED --
+// valid until dvp_cache_dir_release; for inspection (dvp_prover_debug_read, dvp_prover_msm_plan), not for concurrent proving
+extern "C" int dvp_cache_dir_prover(const char* cache_dir, uint32_t n_public, dvp_prover** out) {
+  if (!cache_dir || !out) return DVP_EINVAL;
+  std::shared_ptr<OpenEntry> e;
+  int rc = open_entry(cache_dir, n_public, &e);
+  if (rc) return rc;
+  *out = e->p;
+  return DVP_OK;
 }
 
 extern "C" void dvp_cache_dir_release(const char* cache_dir) {
   std::lock_guard<std::mutex> g(g_open_mu);
   for (auto it = g_open.begin(); it != g_open.end();) {
-    if (!cache_dir || it->first.first == cache_dir) {
-      dvp_prover_destroy(it->second);
-      it = g_open.erase(it);
-    } else {
+    if (!cache_dir || std::get<0>(it->first) == cache_dir)
+      it = g_open.erase(it);  // the prover goes when the last prove holding the entry returns
+    else
       ++it;
-    }
   }
 }

@@ -167,6 +167,11 @@ __global__ void __launch_bounds__(256) k_vec_scale(const Fr* __restrict__ a, Fr 
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = fr_mul(s_m, a[i]);
 }
+// o = a + s * b (canonical in, canonical out; s in Montgomery form)
+__global__ void __launch_bounds__(256) k_vec_axpy(const Fr* __restrict__ a, Fr s_m, const Fr* __restrict__ b, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_add(a[i], fr_mul(s_m, b[i]));
+}
 __global__ void __launch_bounds__(256) k_vec_scalar_sub(Fr s, const Fr* __restrict__ a, Fr* __restrict__ o, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = fr_sub(s, a[i]);
@@ -234,6 +239,20 @@ extern "C" int dvp_fr_vec_scale(const uint64_t* a, const uint64_t s[4], size_t n
   DevBuf da;
   DVP_TRY(up(da, a, n * 32));
   hipLaunchKernelGGL(k_vec_scale, dim3(cdiv(n, 256)), dim3(256), 0, 0, da.as<Fr>(), fr_to_mont(sc), da.as<Fr>(), n);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, da.p, n * 32, hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+extern "C" int dvp_fr_vec_axpy(const uint64_t* a, const uint64_t s[4], const uint64_t* b, size_t n, uint64_t* out) {
+  if (!n) return DVP_OK;
+  if (!a || !b || !s || !out) return DVP_EINVAL;
+  Fr sc;
+  memcpy(sc.v, s, 32);
+  if (!fr_is_canonical(sc)) return DVP_EINVAL;
+  DevBuf da, db;
+  DVP_TRY(up(da, a, n * 32));
+  DVP_TRY(up(db, b, n * 32));
+  hipLaunchKernelGGL(k_vec_axpy, dim3(cdiv(n, 256)), dim3(256), 0, 0, da.as<Fr>(), fr_to_mont(sc), db.as<Fr>(), da.as<Fr>(), n);
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(out, da.p, n * 32, hipMemcpyDeviceToHost));
   return DVP_OK;

@@ -47,6 +47,14 @@ def scale(a, s: int):
     return out
 
 
+def axpy(a, s: int, b):
+    """a + s * b"""
+    a, b = _c(a), _c(b)
+    out = np.empty_like(a)
+    check(lib.dvp_fr_vec_axpy(ptr(a), ptr(limbs(s)), ptr(b), a.shape[0], ptr(out)), "dvp_fr_vec_axpy")
+    return out
+
+
 def scalar_sub(s: int, a):
     a = _c(a)
     out = np.empty_like(a)

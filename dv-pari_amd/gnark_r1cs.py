@@ -240,3 +240,48 @@ def synthetic_sparse(log_m: int, n_wires: int = None, max_terms: int = 8, seed: 
         rows.append((sides[0], sides[1], [(o, 0)]))
     inst = R1CSInstance.from_rows(rows, coeffs, n_public, n_wires=n_wires)
     return inst, w[1:1 + n_public], w[1 + n_public:]
+
+
+def synthetic_sparse_fast(log_m: int, max_terms: int = 8, levels: int = 32, seed: int = 0x5EED0005, n_coeffs: int = 64,
+                          n_public: int = 2):
+    """BASELINE config #5 at its stated size: the same circuit family as synthetic_sparse -- every row is
+    (sum_k c_k w[a_k]) * (sum_k c'_k w[b_k]) = w[o], 1..max_terms terms per side, fresh output wire per row,
+    rows = 7/8 * 2^log_m - 3 (so the instance is padded), SP1-like sparsity (src/gnark_r1cs.rs:84-91 is the format
+    it is written in) -- but built without a python loop over rows: the structure is drawn with numpy and the witness
+    is evaluated level by level (rows of a level only read wires of earlier levels) with the library's own Fr vector
+    ops.  Returns (R1CSInstance, public [n,4], private [n,4]) with the witness as limb arrays."""
+    m = 1 << log_m
+    n_rows = m - m // 8 - 3
+    n_free = 1 + n_public + 4
+    n_wires = n_free + n_rows
+    rng = np.random.default_rng(seed)
+    coeffs = fr.vec([1] + [int.from_bytes(rng.bytes(28), "little") for _ in range(n_coeffs - 1)])
+    bounds = np.linspace(0, n_rows, levels + 1).astype(np.int64)
+    level_of = np.searchsorted(bounds, np.arange(n_rows), side="right") - 1
+    # wires a row may read: everything produced before its level started (and the free wires)
+    avail = (n_free + bounds[level_of]).astype(np.int64)
+    sides = []
+    for _ in range(2):
+        cnt = rng.integers(1, max_terms + 1, size=n_rows).astype(np.int64)
+        rp = np.zeros(n_rows + 1, dtype=np.int64)
+        rp[1:] = np.cumsum(cnt)
+        row_of = np.repeat(np.arange(n_rows, dtype=np.int64), cnt)
+        wire = (rng.integers(0, 1 << 62, size=int(rp[-1])) % avail[row_of]).astype(np.uint32)
+        cid = rng.integers(0, n_coeffs, size=int(rp[-1])).astype(np.uint32)
+        sides.append(Csr(rp.astype(np.uint32), wire, cid))
+    out = Csr(np.arange(n_rows + 1, dtype=np.uint32), (n_free + np.arange(n_rows)).astype(np.uint32), np.zeros(n_rows, dtype=np.uint32))
+    w = np.zeros((n_wires, 4), dtype=np.uint64)
+    w[0, 0] = 1
+    w[1:n_free] = fr.vec([int.from_bytes(rng.bytes(28), "little") for _ in range(n_free - 1)])
+    for lv in range(levels):
+        lo, hi = int(bounds[lv]), int(bounds[lv + 1])
+        if hi == lo:
+            continue
+        vals = []
+        for sd in sides:
+            a, b = int(sd.row_ptr[lo]), int(sd.row_ptr[hi])
+            rp = (sd.row_ptr[lo:hi + 1].astype(np.int64) - a).astype(np.uint32)
+            vals.append(fr.spmv(rp, sd.wire[a:b], sd.coeff[a:b], coeffs, w[: n_free + lo]))
+        w[n_free + lo:n_free + hi] = fr.mul(vals[0], vals[1])
+    inst = R1CSInstance(m, n_public, n_rows, n_wires, sides[0], sides[1], out, coeffs)
+    return inst, w[1:1 + n_public].copy(), w[1 + n_public:].copy()

@@ -135,9 +135,23 @@ class Prover:
             check(lib.dvp_prover_set_matrix(h, which, inst.n_rows, ptr(mat.row_ptr), ptr(mat.wire), ptr(mat.coeff)),
                   "dvp_prover_set_matrix")
 
+    @staticmethod
+    def of_cache_dir(cache_dir, num_public_inputs: int, m: int) -> "Prover":
+        """the prover Proof.prove(cache_dir, ..) keeps for cache_dir (opened if need be): a borrowed handle for
+        inspection (debug reads, MSM plans), released by release_cache_dir, never closed from here"""
+        import os
+
+        self = Prover.__new__(Prover)
+        self.inst, self.m, self.log_m, self._borrowed = None, m, m.bit_length() - 1, True
+        h = C.c_void_p()
+        check(lib.dvp_cache_dir_prover(os.fspath(cache_dir).encode(), num_public_inputs, C.byref(h)), "dvp_cache_dir_prover")
+        self._h = h
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            lib.dvp_prover_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib.dvp_prover_destroy(self._h)
             self._h = None
 
     __del__ = close

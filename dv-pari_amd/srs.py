@@ -53,21 +53,22 @@ def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
     l_taul[1::2] = fr.scale(fr.mul(l_taud, z2inv), z_tau)
     # m_j(tau, delta) = sum_i (A_ij + delta B_ij + delta^2 C'_ij) L_i(tau), C' = C - D (Vandermonde on the public wires)
     lt_rows = l_tau[: inst.n_rows]
-    mv = fr.to_ints(fr.spmv(*_t(inst.l, inst.n_wires), inst.coeffs, lt_rows))
-    mb = fr.to_ints(fr.spmv(*_t(inst.r, inst.n_wires), inst.coeffs, lt_rows))
-    mc = fr.to_ints(fr.spmv(*_t(inst.o, inst.n_wires), inst.coeffs, lt_rows))
-    m_vals = [(a + td.delta * b + delta2 * c) % P for a, b, c in zip(mv, mb, mc)]
+    mv = fr.spmv(*_t(inst.l, inst.n_wires), inst.coeffs, lt_rows)
+    mb = fr.spmv(*_t(inst.r, inst.n_wires), inst.coeffs, lt_rows)
+    mc = fr.spmv(*_t(inst.o, inst.n_wires), inst.coeffs, lt_rows)
+    m_vals = fr.axpy(fr.axpy(mv, td.delta, mb), delta2, mc)  # whole vectors on the GPU: n_wires is 2^23 for the SP1 circuit
     pw = fr.vec([1] * m)
     for j in range(inst.num_public_inputs):  # -d_i^j on wire 1+j of every row (src/gnark_r1cs.rs:333-386)
-        m_vals[1 + j] = (m_vals[1 + j] - delta2 * fr.dot(pw, l_tau)) % P
+        m_vals[1 + j] = fr.limbs((fr.to_int(m_vals[1 + j]) - delta2 * fr.dot(pw, l_tau)) % P)
         pw = fr.mul(pw, d)
-    g_m = fr.scale(fr.vec(m_vals), td.epsilon)
+    g_m = fr.scale(m_vals, td.epsilon)
     g_q = fr.scale(l_taud, z_tau * delta2 % P * td.epsilon % P)
     g_k = [l_tau, fr.scale(l_tau, td.delta), fr.scale(l_taul, delta2)]
     return g_m, g_q, g_k
 
 
-def verifier_runs_setup_cache_dir(td: Trapdoor, cache_dir, num_public_inputs: int, write_precomputes: bool = True):
+def verifier_runs_setup_cache_dir(td: Trapdoor, cache_dir, num_public_inputs: int, write_precomputes: bool = True,
+                                  return_scalars: bool = False):
     """SRS::verifier_runs_setup(trapdoor, cache_dir, num_public_inputs, ..), src/srs.rs:177-361, as the reference
     runs it: reads cache_dir/r1cs_to_dvsnark, writes g_m, g_q, g_k_0..2 as point-vector files
     (compute_srs_matrices -> write_point_vec_to_file) and, with write_precomputes, the domain files a reference
@@ -93,6 +94,8 @@ def verifier_runs_setup_cache_dir(td: Trapdoor, cache_dir, num_public_inputs: in
         tree2n.close()
     for which, name in enumerate(A.SRS_FILES):
         pv.set_srs_encoded(which, io_utils.read_point_vec_payload(os.path.join(cache_dir, name)))
+    if return_scalars:  # the discrete logs of the bases just written (tests pin the proof's commitments with them)
+        return inst, pv, (g_m, g_q, g_k)
     return inst, pv
 
 

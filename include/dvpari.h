@@ -106,6 +106,8 @@ int dvp_fr_batch_inverse_dev(void* d_vals, size_t n, void* stream);
  * <a,b> ; sparse rows out[r] = sum coeffs[cid]*x[col] (eval_row, src/gnark_r1cs.rs:273-280) */
 int dvp_fr_vec_mul(const uint64_t* a, const uint64_t* b, size_t n, uint64_t* out);
 int dvp_fr_vec_scale(const uint64_t* a, const uint64_t s[4], size_t n, uint64_t* out);
+/* out[i] = a[i] + s * b[i]: the (A + delta B + delta^2 C) combination of accumulate_m_values' three sums (src/srs.rs:73-80) */
+int dvp_fr_vec_axpy(const uint64_t* a, const uint64_t s[4], const uint64_t* b, size_t n, uint64_t* out);
 int dvp_fr_vec_scalar_sub(const uint64_t s[4], const uint64_t* a, size_t n, uint64_t* out);
 int dvp_fr_vec_dot(const uint64_t* a, const uint64_t* b, size_t n, uint64_t out[4]);
 int dvp_fr_spmv(const uint32_t* row_ptr, const uint32_t* col, const uint32_t* coeff_ids, uint32_t n_rows,
@@ -231,10 +233,16 @@ int dvp_r1cs_dump_fill(const uint8_t* buf, size_t len, uint64_t* coeffs, uint32_
  * (DVP_EDECODE = the reference's assert!(valid)) and returns a ready prover; the witness length is |g_m|. */
 int dvp_prover_open_cache_dir(const char* cache_dir, uint32_t n_public, dvp_prover** out);
 /* Proof::prove(cache_dir, public_inputs, private_inputs) itself: opens cache_dir on first use and keeps the prover in
- * a process-wide table keyed by (cache_dir, n_public); dvp_cache_dir_release(NULL) drops every entry. */
+ * a process-wide table keyed by (cache_dir, n_public, current HIP device); dvp_cache_dir_release(NULL) drops every entry.
+ * Thread safety: concurrent calls are allowed; proofs on the SAME entry are serialised (one prover = one set of device
+ * buffers), a release during a prove takes effect when that prove returns.  Files that change on disk after the first
+ * call are not re-read: release the entry first.  Only SRS files whose 30-byte encodings follow this library's codec
+ * rule are supported until that rule is pinned against xs233 (tools/pin_xsk233.py). */
 int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
                         uint32_t n_private, uint8_t proof[118]);
 void dvp_cache_dir_release(const char* cache_dir);
+/* the cached prover of (cache_dir, n_public), opened if need be -- borrowed, for inspection only (debug reads, plans) */
+int dvp_cache_dir_prover(const char* cache_dir, uint32_t n_public, dvp_prover** out);
 
 #ifdef __cplusplus
 }

@@ -89,12 +89,14 @@ def check_srs_scalars(inst, trap, D, D2, g_m, g_q, g_k, rnd, samples=2):
     return z_tau
 
 
-def check_proof(dvp, pv, inst, trap, pub, prv, proof, scalars, D=None, check_bary=True, rnd=None):
+def check_proof(dvp, pv, inst, trap, pub, prv, proof, scalars, D=None, check_bary=True, rnd=None, w=None):
     """commit_p, kzg_k, alpha, a0, b0 of `proof` against the oracle, from the prover's scalar vectors and the SRS
-    scalars (g_m, g_q, g_k) the bases were generated from"""
+    scalars (g_m, g_q, g_k) the bases were generated from; the assignment either as pub / prv int lists or as the
+    limb array w = [1, pub.., prv..]"""
     g_m, g_q, g_k = scalars
     m = inst.num_constraints
-    w = dvp.fr.vec([1] + list(pub) + list(prv))
+    if w is None:
+        w = dvp.fr.vec([1] + list(pub) + list(prv))
     assert w.shape[0] == inst.n_wires
     q2, ka, kb, kr = (pv.debug(k) for k in ("q2", "ka", "kb", "kr"))
     dl_commit = (np_dot_mod_fast(w, g_m) + np_dot_mod_fast(q2, g_q)) % P

@@ -216,3 +216,57 @@ def test_cpp_host_over_the_c_abi(dvp, tmp_path):
     # missing files are reported with a status, not a crash
     out = subprocess.run([str(exe), str(tmp_path / "nowhere"), "2"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 1 and "i/o" in out.stderr.lower() or "io" in out.stderr.lower()
+
+
+def test_config5_sparse_2_22_through_cache_dir(dvp, tmp_path):
+    """BASELINE config #5 at its stated size: an SP1-like sparse R1CS with ~2^22 rows (3.67 M real rows padded to
+    2^22, 1..8 terms per side, 16.5 M + 16.5 M + 3.7 M terms) is written in the gnark dump format
+    (src/gnark_r1cs.rs:84-91) with its witness file (:58-77,188-198), set up into a cache_dir (SRS point files in the
+    reference's format, src/io_utils.rs:83-111) and proved through dvp_prove_cache_dir = Proof::prove(cache_dir, ..)
+    (src/proving.rs:426).  Oracle-backed as at 2^20 (tests/fullsize.py): sampled rows by eval_row, sampled domain / SRS
+    scalars by their definitions, commit_p and kzg_k by the discrete-log identity, alpha by the oracle transcript, and
+    a0 / b0 by the designated-verifier equation on discrete logs."""
+    import fullsize as fs
+    from util import from_limbs
+
+    A, g = dvp.artifacts, dvp.gnark_r1cs
+    log_m = 22
+    rnd = random.Random(522)
+    inst0, pub_l, prv_l = g.synthetic_sparse_fast(log_m)
+    cache = tmp_path / "sp1_like"
+    cache.mkdir()
+    inst0.write_dump_file(cache / A.R1CS_CONSTRAINTS_FILE)
+    w = np.concatenate([dvp.fr.vec([1]), pub_l, prv_l])
+    g.write_witness_to_file(cache / A.R1CS_WITNESS_FILE, w)
+    trap = (rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    td = dvp.srs.Trapdoor(*trap)
+    inst, pv_setup, scalars = dvp.srs.verifier_runs_setup_cache_dir(td, cache, 2, write_precomputes=False, return_scalars=True)
+    assert (inst.n_rows, inst.num_constraints, inst.n_wires) == (inst0.n_rows, 1 << log_m, inst0.n_wires)
+    assert inst.n_rows > 3_600_000
+    D, D2 = fs.check_domains(pv_setup, log_m, rnd, samples=3)
+    fs.check_srs_scalars(inst, trap, D, D2, *scalars, rnd, samples=1)
+    pv_setup.close()
+    del D2
+    wf = g.load_witness_from_file(cache / A.R1CS_WITNESS_FILE)
+    assert np.array_equal(wf, w)
+    pub = from_limbs(wf[1:3])
+    proof = dvp.proving.Proof.prove(cache, wf[1:3], wf[3:])
+    pv = dvp.proving.Prover.of_cache_dir(cache, 2, inst.num_constraints)
+    assert pv.msm_plan(1)[0] >= 18  # the fixed-base tables are in use at this size
+    # R1CS evaluation (get_matrix_evaluations_from_witness, src/proving.rs:348-403) on sampled rows, incl. a padded one
+    coeffs, a_vec = from_limbs(inst.coeffs), pv.debug("a")
+    for i in [0, inst.n_rows - 1] + [rnd.randrange(inst.n_rows) for _ in range(6)]:
+        lo, hi = int(inst.l.row_ptr[i]), int(inst.l.row_ptr[i + 1])
+        terms = [(int(inst.l.wire[k]), int(inst.l.coeff[k])) for k in range(lo, hi)]
+        ww = {t[0]: from_limbs(w[t[0]:t[0] + 1])[0] for t in terms}
+        assert from_limbs(a_vec[i:i + 1])[0] == sum(coeffs[c] * ww[a] for a, c in terms) % o.P, i
+    assert not a_vec[inst.n_rows:].any()
+    fs.check_proof(dvp, pv, inst, trap, pub, None, proof, scalars, check_bary=False, w=w)
+    assert dvp.srs.verify(td, pub, proof)
+    # an unsatisfied witness is reported with its row, not proved (assert_eq!, src/proving.rs:389-395)
+    bad = wf[3:].copy()
+    bad[12345, 0] ^= np.uint64(1)
+    with pytest.raises(dvp.DvpError) as e:
+        dvp.proving.Proof.prove(cache, wf[1:3], bad)
+    assert e.value.status == -3 and 0 <= e.value.index < inst.n_rows
+    dvp.proving.release_cache_dir()
