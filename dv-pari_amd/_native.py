@@ -97,6 +97,9 @@ _SIGS = {
     "dvp_file_witness_write": (C.c_int, [C.c_char_p, u64p, sz]),
     "dvp_r1cs_dump_sizes": (C.c_int, [u8p, sz, C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_uint64 * 3), C.POINTER(u32)]),
     "dvp_r1cs_dump_fill": (C.c_int, [u8p, sz, u64p, C.POINTER(vp * 3), C.POINTER(vp * 3), C.POINTER(vp * 3)]),
+    "dvp_fftr_sections": (C.c_int, [C.c_char_p, u32, u8p, u64p, C.POINTER(u32)]),
+    "dvp_fftr_read_fr": (C.c_int, [C.c_char_p, u32, C.c_uint8, u64p, sz, C.POINTER(C.c_size_t)]),
+    "dvp_fftr_write": (C.c_int, [C.c_char_p, u32, u8p, vp, u64p]),
     "dvp_prover_open_cache_dir": (C.c_int, [C.c_char_p, u32, C.POINTER(vp)]),
     "dvp_prove_cache_dir": (C.c_int, [C.c_char_p, u64p, u32, u64p, u32, u8p]),
     "dvp_cache_dir_release": (None, [C.c_char_p]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdvpari_hip.so")
-SOURCES = ["capi.cpp", "cache.cpp", "ecfft.hip", "msm.hip", "codec.hip", "fr_ops.hip", "prove.hip"]
+SOURCES = ["capi.cpp", "cache.cpp", "tree_io.cpp", "ecfft.hip", "msm.hip", "codec.hip", "fr_ops.hip", "prove.hip"]
 HEADERS = ["common.h", "fr.cuh", os.path.join("..", "..", "include", "dvpari.h")]
 
 
@@ -27,7 +27,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         obj = os.path.join(CSRC, s.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-c", "-x", "hip",
-               os.path.join(CSRC, s), "-o", obj, "-Wno-pass-failed"]
+               os.path.join(CSRC, s), "-o", obj, "-Wno-pass-failed", "-Wno-int-to-pointer-cast"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

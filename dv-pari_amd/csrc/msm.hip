@@ -951,6 +951,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     return DVP_OK;
   }
   if (n > (1u << 27)) return DVP_EINVAL;
+  {  // entry positions and pre-rotated table indices are 32-bit (0xffffffff = "no partner" in a slot descriptor)
+    const MsmPlan pl = msm_plan(n, fx);
+    const uint64_t tab = fx ? (uint64_t)fx->W * fx->n_total : (uint64_t)n;
+    if ((uint64_t)pl.e_max >= 0xfffffff0ull || tab >= 0xfffffff0ull) return DVP_EINVAL;
+  }
   {
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
@@ -1218,6 +1223,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 // minimises an empirical cost in field multiplications (pair additions + a per-bucket term, see below)
 void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
+  if ((uint64_t)n_total * 32 >= 0xfffffff0ull) return DVP_EINVAL;  // W <= 31 windows of pre-rotated copies, 32-bit indices
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
   double best = 1e300;

@@ -236,6 +236,7 @@ struct DevCsr {
   uint32_t* coeff = nullptr;
   uint32_t n_rows = 0;
   size_t nnz = 0;
+  uint32_t max_coeff_id = 0;  // largest coefficient id stored (re-checked against the table in prover_ready)
 };
 
 struct dvp_prover {
@@ -289,7 +290,9 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
 extern "C" void dvp_prover_destroy(dvp_prover* p);
 
 extern "C" int dvp_prover_create(uint32_t log2_m, uint32_t n_public, uint32_t n_wires, dvp_prover** out) {
-  if (!out || log2_m < 1 || log2_m > 26 || n_wires < 1 + n_public) return DVP_EINVAL;
+  // 2^24 constraints is the largest size the MSM index ranges cover (4m bases x 14 pre-rotated windows must stay below
+  // 2^32, msm.hip) -- the reference's own tree constants stop at 2^27 leaves (src/ec_fft.rs:205), its SP1 circuit is 2^23
+  if (!out || log2_m < 1 || log2_m > DVP_MAX_LOG2_CONSTRAINTS || n_wires < 1 + n_public || (uint64_t)n_wires > (1ull << 25)) return DVP_EINVAL;
   dvp_prover* p = new dvp_prover();
   int rc = prover_init(p, log2_m, n_public, n_wires);
   if (rc != DVP_OK) {
@@ -381,13 +384,20 @@ extern "C" int dvp_prover_set_coeffs(dvp_prover* p, const uint64_t* coeffs, uint
 extern "C" int dvp_prover_set_matrix(dvp_prover* p, int which, uint32_t n_rows, const uint32_t* row_ptr,
                                      const uint32_t* wire_ids, const uint32_t* coeff_ids) {
   if (!p || which < 0 || which > 2 || !row_ptr || n_rows > p->m) return DVP_EINVAL;
+  // a well-formed CSR: row_ptr[0] == 0 and non-decreasing (k_r1cs_eval walks [row_ptr[i], row_ptr[i+1]) unchecked)
+  if (row_ptr[0] != 0) { g_last_error_index = 0; return DVP_EINVAL; }
+  for (uint32_t i = 0; i < n_rows; ++i)
+    if (row_ptr[i + 1] < row_ptr[i]) { g_last_error_index = (int64_t)i; return DVP_EINVAL; }
   size_t nnz = row_ptr[n_rows];
   if (nnz && (!wire_ids || !coeff_ids)) return DVP_EINVAL;
-  for (size_t k = 0; k < nnz; ++k)
+  uint32_t max_cid = 0;
+  for (size_t k = 0; k < nnz; ++k) {
     if (wire_ids[k] >= p->n_wires || (p->n_coeffs && coeff_ids[k] >= p->n_coeffs)) {
       g_last_error_index = (int64_t)k;
       return DVP_EINVAL;
     }
+    if (coeff_ids[k] > max_cid) max_cid = coeff_ids[k];
+  }
   DevCsr& mt = p->mat[which];
   if (mt.row_ptr) { (void)hipFree(mt.row_ptr); (void)hipFree(mt.wire); (void)hipFree(mt.coeff); }
   DVP_HIP(hipMalloc((void**)&mt.row_ptr, ((size_t)n_rows + 1) * 4));
@@ -400,6 +410,7 @@ extern "C" int dvp_prover_set_matrix(dvp_prover* p, int which, uint32_t n_rows, 
   }
   mt.n_rows = n_rows;
   mt.nnz = nnz;
+  mt.max_coeff_id = max_cid;
   return DVP_OK;
 }
 
@@ -500,7 +511,10 @@ extern "C" int dvp_blake3(const uint8_t* data, size_t len, uint8_t out[32]) {
 static bool prover_ready(dvp_prover* p) {
   for (int k = 0; k < 5; ++k)
     if (!p->have_srs[k]) return false;
-  return p->coeffs_m && p->mat[0].row_ptr && p->mat[1].row_ptr && p->mat[2].row_ptr;
+  if (!(p->coeffs_m && p->mat[0].row_ptr && p->mat[1].row_ptr && p->mat[2].row_ptr)) return false;
+  for (int k = 0; k < 3; ++k)  // whatever order set_coeffs / set_matrix were called in, every stored id must be in the table
+    if (p->mat[k].nnz && p->mat[k].max_coeff_id >= p->n_coeffs) return false;
+  return true;
 }
 
 // phase 1 (src/proving.rs:434-508): assignment -> a,b,c',i -> extend -> q2; leaves SA = [w | q2].

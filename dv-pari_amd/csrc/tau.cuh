@@ -20,7 +20,17 @@ static __constant__ uint32_t TAU_D1[4] = {0xcb36bee6u, 0x16aa143cu, 0x2d7ae36eu,
 static __constant__ uint32_t TAU_C0M[4] = {0x10c103abu, 0x3c775348u, 0xffafd49cu, 0x00055d96u};  // D1 - D0
 static __constant__ uint32_t TAU_A0[5] = {0x55720891u, 0x90218207u, 0x3878eea6u, 0x2dff5fa9u, 0x00000abbu};
 static __constant__ uint32_t TAU_A1[5] = {0xcb1ecea9u, 0x79966d7du, 0xdc2d5428u, 0xae5af5c6u, 0x00001105u};
-constexpr int TAU_DIGITS = 240;  // observed maximum over 1e5 random scalars + edge cases: 236
+// TAU_DIGITS = 240 is a PROVEN bound on the length of the expansion, not an observed one (observed maximum: 236):
+//   rho = s - kappa*delta with kappa_i = round(s c_i / r) computed through a 256-bit fixed-point reciprocal, so
+//   rho/delta = e0 + e1 tau with |e_i| <= 1/2 + 2^-24, hence N(rho) = N(delta) (e0^2 - e0 e1 + 2 e1^2) <= r (1 + 2^-21)
+//   and |rho| = sqrt(N(rho)) < 2^115.51 (r < 2^231.01).  One expansion step maps rho to (rho - u)/tau, u in {0,1}, and
+//   |tau| = sqrt 2, so |rho_(k+1)| <= (|rho_k| + 1)/sqrt 2, i.e. |rho_k| < |rho_0| 2^(-k/2) + 1/(sqrt 2 - 1).  After
+//   k = 233 steps |rho_233| < 2^(115.51-116.5) + 2.4143 < 2.92, so N(rho_233) <= 8; every element of Z[tau] of norm
+//   <= 9 has an expansion of at most 7 digits (exhaustive enumeration, tests/test_oracle.py::test_tau_length_bound).
+//   Total <= 233 + 7 = 240.  The windows of both MSM modes cover >= 240 digits (msm.hip: MsmFixedCtx::set_c keeps an
+//   overflow window of c >= 8 digits above digit 234; msm_plan adds ceil(6/c) overflow windows), so the "expansion
+//   longer than the windows" flag of k_recode cannot fire for a canonical scalar; it stays as an internal check.
+constexpr int TAU_DIGITS = 240;
 
 // out[0..no) = low `no` limbs of a[0..na) * b[0..nb)
 template <int NA, int NB, int NO>

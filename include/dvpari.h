@@ -158,6 +158,7 @@ int dvp_points_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b
 /* with the cache_dir artefacts handed over once and kept resident in HBM.                      */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct dvp_prover dvp_prover;
+#define DVP_MAX_LOG2_CONSTRAINTS 24 /* largest validated / index-safe size; dvp_prover_create returns DVP_EINVAL above it */
 
 /* m = 2^log2_m constraints (R1CSInstance::num_constraints, src/gnark_r1cs.rs:291); witness vector
  * = [1, public.., private..] of n_wires entries (src/proving.rs:355-359).  Builds TREE_2N and the
@@ -228,6 +229,15 @@ int dvp_file_witness_write(const char* path, const uint64_t* limbs, size_t n);
 int dvp_r1cs_dump_sizes(const uint8_t* buf, size_t len, uint32_t* n_coeffs, uint32_t* n_rows, uint64_t nnz[3], uint32_t* n_wires);
 int dvp_r1cs_dump_fill(const uint8_t* buf, size_t len, uint64_t* coeffs, uint32_t* const row_ptr[3], uint32_t* const wire[3],
                        uint32_t* const coeff_id[3]);
+/* FFTR tree files (src/tree_io.rs:1-15,144-214,353-433): the sectioned container the reference stores its FFTrees in.
+ * The prover never needs one (twiddles are regenerated from the curve constants); these entries let a host CHECK a
+ * reference-built tree2n / treen against the regenerated domain and write files in the same container.  depth = number
+ * of subtree links (section 12) to follow from the root node.  Blob layout assumed: ark-serialize Vec of field elements,
+ * u64-LE count || count x 29-byte LE canonical (Mat2x2 = 4 elements); anything else is DVP_EIO (csrc/tree_io.cpp). */
+int dvp_fftr_sections(const char* path, uint32_t depth, uint8_t ids[13], uint64_t lens[13], uint32_t* n_sections);
+int dvp_fftr_read_fr(const char* path, uint32_t depth, uint8_t section_id, uint64_t* out, size_t cap, size_t* n_elems);
+int dvp_fftr_write(const char* path, uint32_t n_sections, const uint8_t* ids, const uint64_t* const* data, const uint64_t* elems);
+
 /* The loading half of Proof::prove (src/proving.rs:435-470,509-511,666-672): reads cache_dir/r1cs_to_dvsnark and the
  * SRS vectors g_m, g_q, g_k_0, g_k_1, g_k_2 (src/artifacts.rs:18-27,76), decodes the points on the GPU
  * (DVP_EDECODE = the reference's assert!(valid)) and returns a ready prover; the witness length is |g_m|. */

@@ -156,3 +156,25 @@ def test_extend_consistent_with_enter(dvp):
     c[:m] = rand_fr_np(m, 5)
     e = t.enter(c)
     assert (t.extend(np.ascontiguousarray(e[0::2])) == e[1::2]).all()
+
+
+def test_tree_file_checked_against_regenerated_domain(dvp, tmp_path):
+    """an FFTR tree file (src/tree_io.rs) whose leaves are the oracle's tree2n leaves (what a reference-built
+    file holds: leaves x(C + i*G'), src/ec_fft.rs:158-162) is accepted by check_tree_file against the device-regenerated
+    domain, for the plain and the shifted tree; a file with one damaged leaf is refused with the leaf index."""
+    log_n = 7
+    n = 1 << log_n
+    for shifted in (False, True):
+        ot = o.FFTree(log_n, shifted=shifted)
+        leaves = ot.leaves()
+        path = tmp_path / f"tree_{int(shifted)}"
+        dvp.tree_io.write_tree_file(path, {"f": to_limbs([0] * n + leaves)})
+        t = dvp.ec_fft.FFTree(n, shift_by_one=shifted, base_log_n=log_n if shifted else 0)
+        info = dvp.tree_io.check_tree_file(path, t)
+        assert info["leaves"] == n and info["sections"][0][0] == "f"
+        bad = list(leaves)
+        bad[37] = (bad[37] + 1) % o.P
+        dvp.tree_io.write_tree_file(path, {"f": to_limbs([0] * n + bad)})
+        with pytest.raises(ValueError, match="leaf 37"):
+            dvp.tree_io.check_tree_file(path, t)
+        t.close()

@@ -11,7 +11,7 @@ import pytest
 
 import pyref as o
 import c_oracle as co
-from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast
+from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast, tau_adversarial_scalars
 
 pytestmark = pytest.mark.gpu
 OSSL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k233_openssl.json")))["vectors"]
@@ -228,6 +228,10 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
     s = rand_fr_np(n, 92)
     special = [0, 1, 2, o.P - 1, o.P - 2, (1 << 231) - 1, 1 << 230, (1 << 116) + 1, 0xFFFFFFFFFFFFFFFF, (o.P - 1) // 2, 3 << 200]
+    # worst cases of the tau-adic recoding: corners of the reduction's fundamental region (longest expansions, 236 of the
+    # proven 240 digits) and the rounding boundaries of its fixed-point quotients (tau.cuh)
+    special += tau_adversarial_scalars()
+    assert max(len(co.tau_digits(x)) for x in special) >= 236
     s[: len(special)] = to_limbs(special)
     ks, ss = from_limbs(k), from_limbs(s)
     for c in range(8, 21):

@@ -92,3 +92,22 @@ def test_shard_plan_roles_and_coverage(dvp):
                 assert max(loads) <= 1.03 * (sum(loads) / world) or all(ext)
     assert all(need for _, _, need in d.shard_plan(2, 1 << 20, 1 << 20))       # small worlds: uniform
     assert not d.shard_plan(8, 1 << 20, 1 << 20)[0][2]                           # 8 ranks: some skip the extends
+
+
+def test_pin_xsk233_tool_agrees_with_the_oracle_rule():
+    """tools/pin_xsk233.py (self-contained arithmetic) must name the CURRENT rule for a vector produced by the oracle's
+    candidate codec, and must say so when a vector does not match"""
+    import importlib.util
+    import os
+
+    import c_oracle as co
+
+    spec = importlib.util.spec_from_file_location("pin_xsk233", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pin_xsk233.py"))
+    pin = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pin)
+    k = 0xC0FFEE1234567
+    vec = co.xsk233_encode(co.k233_mulgen(k))
+    lines = []
+    assert pin.pin(k, vec, out=lines.append) == 0 and lines[0].startswith("CURRENT RULE CONFIRMED")
+    bad = bytes([vec[0] ^ 4]) + vec[1:]
+    assert pin.pin(k, bad, out=lines.append) == 2

@@ -186,3 +186,46 @@ def test_toy_r1cs_end_to_end():
     gk = st["g_k"][0] + st["g_k"][1] + st["g_k"][2]
     kzg = co.msm(to_np(pr["s_k"]), bases(gk))
     assert co.xsk233_encode(kzg).hex() == toy["kzg_k"]
+
+
+def test_tau_length_bound():
+    """The two facts the 240-digit bound of dv-pari_amd/csrc/tau.cuh rests on: every element of Z[tau]
+    (tau^2 + tau + 2 = 0) of norm <= 9 expands to at most 7 digits {0,1}, and the partially reduced scalars -- random
+    ones, the corners of the reduction's fundamental region, the rounding boundaries of its quotients -- stay within
+    240 digits under BOTH roundings (the oracle's exact one and the kernel's 256-bit fixed-point one)."""
+    from util import TAU_D0, TAU_D1, tau_adversarial_scalars
+
+    def length(r0, r1):
+        n = 0
+        while r0 or r1:
+            u = r0 & 1
+            h = (r0 - u) // 2
+            r0, r1 = r1 - h, -h
+            n += 1
+            assert n <= 256
+        return n
+
+    worst = 0
+    for a in range(-8, 9):
+        for b in range(-8, 9):
+            if a * a - a * b + 2 * b * b <= 9:
+                worst = max(worst, length(a, b))
+    assert worst == 7
+    p = o.P
+    a0, a1 = ((TAU_D1 - TAU_D0) << 256) // p, (TAU_D1 << 256) // p
+
+    def kernel_reduce(s):  # tau_partial_reduce
+        q0, q1 = (s * a0 + (1 << 255)) >> 256, (s * a1 + (1 << 255)) >> 256
+        return s + q0 * TAU_D0 - 2 * q1 * TAU_D1, q0 * TAU_D1 - q1 * (TAU_D1 - TAU_D0)
+
+    lam = (-TAU_D0 * pow(TAU_D1, -1, p)) % p
+    rnd = random.Random(240)
+    seen = 0
+    for s in tau_adversarial_scalars() + [rnd.randrange(p) for _ in range(3000)] + [0, 1, p - 1]:
+        r0, r1 = kernel_reduce(s)
+        assert (r0 + r1 * lam - s) % p == 0            # rho = s (mod delta)
+        assert 4 * (r0 * r0 - r0 * r1 + 2 * r1 * r1) <= 5 * p  # norm within the bound the proof uses (with slack)
+        lk, lo = length(r0, r1), len(co.tau_digits(s))
+        assert lk <= 240 and lo <= 240
+        seen = max(seen, lk, lo)
+    assert seen >= 236

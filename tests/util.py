@@ -59,3 +59,37 @@ def np_dot_mod_fast(a, b):
             for j in range(16):
                 total += int(M[i, j]) << (16 * (i + j))
     return total % o.P
+
+
+# ---- adversarial scalars for the tau-adic recoding (dv-pari_amd/csrc/tau.cuh) ----------------------------------------
+# delta = D0 + D1 tau with N(delta) = p; tau acts on E[r] as lambda = -D0/D1 mod p
+TAU_D0 = 0x000325402DCB0ED1DA32C0F4BA75BB3B
+TAU_D1 = 0x000882D72D7AE36E16AA143CCB36BEE6
+
+
+def tau_adversarial_scalars(seed=7, n_boundary=40):
+    """scalars whose partial reduction modulo delta lands at the corners of the fundamental region (largest norm,
+    hence the longest {0,1}-digit expansions), and scalars that sit on the rounding boundaries of the two fixed-point
+    quotients round(s * A_i / 2^256) of tau_partial_reduce"""
+    import random
+
+    p = o.P
+    assert TAU_D0 * TAU_D0 - TAU_D0 * TAU_D1 + 2 * TAU_D1 * TAU_D1 == p
+    lam = (-TAU_D0 * pow(TAU_D1, -1, p)) % p
+    assert (lam * lam + lam + 2) % p == 0
+    out = []
+    for e0, e1 in ((1, -1), (-1, 1), (1, 1), (-1, -1), (1, 0), (0, 1), (-1, 0), (0, -1)):
+        n0 = e0 * TAU_D0 - 2 * e1 * TAU_D1          # (e0/2 + e1/2 tau) * delta, doubled
+        n1 = e0 * TAU_D1 + e1 * TAU_D0 - e1 * TAU_D1
+        for a in range(-3, 4):
+            for b in range(-3, 4):
+                out.append(((n0 // 2 + a) + (n1 // 2 + b) * lam) % p)
+    rnd = random.Random(seed)
+    a0 = ((TAU_D1 - TAU_D0) << 256) // p
+    a1 = (TAU_D1 << 256) // p
+    for _ in range(n_boundary):
+        k = rnd.randrange(1 << 116)
+        for A in (a0, a1):
+            s0 = ((2 * k + 1) << 255) // A
+            out += [(s0 + d) % p for d in (-1, 0, 1)]
+    return out
