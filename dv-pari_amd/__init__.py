@@ -11,7 +11,7 @@ The directory name contains a hyphen, so import it with
     import importlib; dvp = importlib.import_module("dv-pari_amd")
 """
 from . import _native  # noqa: F401  (raises if libdvpari_hip.so is missing)
-from ._native import lib, DvpError, check, tune  # noqa: F401
+from ._native import lib, DvpError, check, tune, set_devices  # noqa: F401
 from . import artifacts, curve, ec_fft, fr, gnark_r1cs, io_utils, proving, srs, distributed, tree_io  # noqa: F401
 
 P = 3450873173395281893717377931138512760570940988862252126328087024741343

@@ -30,6 +30,8 @@ _SIGS = {
     "dvp_version": (C.c_int, []),
     "dvp_device_count": (C.c_int, []),
     "dvp_set_device": (C.c_int, [C.c_int]),
+    "dvp_set_devices": (C.c_int, [C.POINTER(C.c_int), C.c_int]),
+    "dvp_points_sum_dev": (C.c_int, [vp, u32, vp, vp, vp]),
     "dvp_last_error_index": (C.c_int64, []),
     "dvp_tune_set": (C.c_int, [C.c_char_p, C.c_longlong]),
     "dvp_tune_reset": (None, []),
@@ -127,6 +129,14 @@ class DvpError(RuntimeError):
 def check(status, where=""):
     if status != 0:
         raise DvpError(status, where)
+
+
+def set_devices(ids):
+    """dvp_set_devices: in-library multi-GPU over the listed devices (ids[0] = the prover's home device; an id may repeat);
+    an empty list or a single id restores single-device proving"""
+    ids = list(ids or [])
+    arr = (C.c_int * max(len(ids), 1))(*ids)
+    check(lib.dvp_set_devices(arr, len(ids)), "dvp_set_devices")
 
 
 class tune:

@@ -59,6 +59,12 @@ static void tune_from_env(Tune& t) {
   t.msm_fixed_min = geti("DVP_MSM_FIXED_MIN", t.msm_fixed_min);
   t.horner_max_pub = geti("DVP_HORNER_MAX_PUB", t.horner_max_pub);
 }
+static std::mutex g_dev_mu;
+static std::vector<int> g_devices;
+std::vector<int> mgpu_devices() {
+  std::lock_guard<std::mutex> g(g_dev_mu);
+  return g_devices;
+}
 Tune& tune() {
   static Tune t = [] { Tune x; tune_from_env(x); return x; }();
   return t;
@@ -115,6 +121,20 @@ extern "C" int dvp_device_count(void) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) return DVP_EHIP;
   return n;
+}
+
+// In-library multi-GPU: the devices dvp_prove / dvp_prove_dev / dvp_prove_cache_dir spread the two MSMs of a proof over
+// (one host thread per entry).  ids[0] should be the device the prover was created on (its "home"); an id may repeat
+// (that is how the path is tested on a one-GPU box).  n <= 1 (or ids == NULL) switches back to single-device proving.
+extern "C" int dvp_set_devices(const int* ids, int n) {
+  int cnt = 0;
+  DVP_HIP(hipGetDeviceCount(&cnt));
+  if (n < 0 || n > 64 || (n > 0 && !ids)) return DVP_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (ids[i] < 0 || ids[i] >= cnt) return DVP_EINVAL;
+  std::lock_guard<std::mutex> g(dvp::g_dev_mu);
+  dvp::g_devices.assign(ids, ids + (n > 1 ? n : 0));
+  return DVP_OK;
 }
 
 extern "C" int dvp_set_device(int id) {

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "../../include/dvpari.h"
 
 namespace dvp {
@@ -75,6 +77,9 @@ struct Tune {
   long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)
 };
 Tune& tune();
+
+// devices of the in-library multi-GPU mode (dvp_set_devices); empty = single device (whatever is current)
+std::vector<int> mgpu_devices();
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -844,6 +844,38 @@ __global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSq
   *out_inf = fin ? 0u : 1u;
 }
 
+// sum of n affine points (the partial MSM results of n GPUs or ranks) -> affine: one quad of lanes, n - 1 mixed
+// additions + one inversion, all through the quad-cooperative multiplier (~15 us per point + ~50 us)
+__global__ void __launch_bounds__(64) k_sum_points(const Aff* __restrict__ pts, const uint32_t* __restrict__ inf, uint32_t n, uint32_t inf_stride,
+                                                  GfSqrTables T, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
+  extern __shared__ char lds_raw[];
+  GfLdsQ L = gf_ldsq_init(lds_raw);
+  if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+  Ld acc = ld_infinity();
+#pragma unroll 1
+  for (uint32_t i = 0; i < n; ++i) {
+    if (inf[(size_t)i * inf_stride]) continue;
+    Aff q = pts[i];
+    ld_madd_ip(acc, q, L);
+  }
+  Aff a;
+  a.x = gf_zero();
+  a.y = gf_zero();
+  const bool fin = !ld_is_inf(acc);
+  if (fin) {
+    Gf zi = gf_inv_fast(acc.Z, T, L);
+    a.x = gf_mul(acc.X, zi, L);
+    a.y = gf_mul(acc.Y, gf_sqr(zi), L);
+  }
+  if (threadIdx.x != 0) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    out_xy[k] = a.x.w[k];
+    out_xy[8 + k] = a.y.w[k];
+  }
+  *out_inf = fin ? 0u : 1u;
+}
+
 // ---- workspace -----------------------------------------------------------------------------------
 struct MsmWorkspace {
   std::mutex mu;
@@ -866,7 +898,10 @@ struct MsmWorkspace {
     return DVP_OK;
   }
 };
-static MsmWorkspace g_ws;
+// one grow-only workspace PER DEVICE: MSMs on different GPUs (in-library multi-GPU: one host thread per device,
+// prove.hip) run concurrently, MSMs on the same GPU take turns
+constexpr int MSM_MAX_DEVICES = 16;
+static MsmWorkspace g_ws_dev[MSM_MAX_DEVICES];
 
 struct MsmPlan {
   uint32_t n;
@@ -956,11 +991,15 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint64_t tab = fx ? (uint64_t)fx->W * fx->n_total : (uint64_t)n;
     if ((uint64_t)pl.e_max >= 0xfffffff0ull || tab >= 0xfffffff0ull) return DVP_EINVAL;
   }
-  {
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-      attr_err = hipFuncSetAttribute((const void*)k_scatter_local, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  int cur_dev = 0;
+  DVP_HIP(hipGetDevice(&cur_dev));
+  if (cur_dev < 0 || cur_dev >= MSM_MAX_DEVICES) return DVP_EINVAL;
+  {  // dynamic-LDS limits are a per-device property of a kernel: set them once on every device that runs an MSM
+    static std::mutex attr_mu;
+    static bool attr_done[MSM_MAX_DEVICES] = {false};
+    std::lock_guard<std::mutex> ga(attr_mu);
+    if (!attr_done[cur_dev]) {
+      hipError_t attr_err = hipFuncSetAttribute((const void*)k_scatter_local, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_hist_local, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
       if (attr_err == hipSuccess)
@@ -972,15 +1011,17 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
-                          (const void*)k_affine_round};
+                          (const void*)k_affine_round, (const void*)k_sum_points};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
-    });
-    DVP_HIP(attr_err);
+      DVP_HIP(attr_err);
+      attr_done[cur_dev] = true;
+    }
   }
   MsmPlan p = msm_plan(n, fx);
   const FxBits fb = fx ? fx->bits() : FxBits{0, 0};
   const uint32_t FX_NP = fb.np();
+  MsmWorkspace& g_ws = g_ws_dev[cur_dev];
   std::lock_guard<std::mutex> g(g_ws.mu);
   // carve the workspace
   size_t o = 0;
@@ -1213,6 +1254,16 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   return DVP_OK;
 }
 
+// d_pts: n affine points (64 B each), d_inf32: n flags (u32, `inf_stride` words apart) -> their sum
+int msm_sum_points_dev(const void* d_pts, const void* d_inf32, uint32_t n, uint32_t inf_stride, void* d_out_xy, void* d_out_inf, hipStream_t st) {
+  GfSqrTables Tsq;
+  DVP_TRY(gf_sqr_tables(&Tsq, st));
+  hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, (const Aff*)d_pts, (const uint32_t*)d_inf32, n, inf_stride, Tsq,
+                     (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+
 int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy,
                    void* d_out_inf, hipStream_t st) {
   return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st);
@@ -1279,6 +1330,21 @@ extern "C" int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy,
                                   void* d_out_xy, void* d_out_inf, void* stream) {
   if ((n && (!d_scalars || !d_bases_xy)) || !d_out_xy || !d_out_inf) return DVP_EINVAL;
   return msm_affine_dev(d_scalars, d_bases_xy, d_bases_inf, n, d_out_xy, d_out_inf, (hipStream_t)stream);
+}
+
+// sum of n partial points laid out as n records of 80 bytes: x || y (64 B) + u32 infinity flag + pad -- the record a rank
+// all-gathers (dv-pari_amd/distributed.py) and the one the in-library device threads hand back
+extern "C" int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out_xy, void* d_out_inf, void* stream) {
+  if (!d_records || !n || !d_out_xy || !d_out_inf) return DVP_EINVAL;
+  // records are 80 B apart but Aff is 64 B: gather into a packed array first (n <= a few dozen)
+  hipStream_t st = (hipStream_t)stream;
+  DevBuf pk;
+  DVP_TRY(pk.alloc((size_t)n * 68));
+  DVP_HIP(hipMemcpy2DAsync(pk.p, 64, d_records, 80, 64, n, hipMemcpyDeviceToDevice, st));
+  DVP_HIP(hipMemcpy2DAsync((char*)pk.p + (size_t)n * 64, 4, (const char*)d_records + 64, 80, 4, n, hipMemcpyDeviceToDevice, st));
+  DVP_TRY(msm_sum_points_dev(pk.p, (char*)pk.p + (size_t)n * 64, n, 1, d_out_xy, d_out_inf, st));
+  DVP_HIP(hipStreamSynchronize(st));  // pk is released on return
+  return DVP_OK;
 }
 
 extern "C" int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n,

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "blake3.h"
@@ -39,6 +40,7 @@ int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out,
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
 struct MsmFixedCtx;
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out);
+int msm_sum_points_dev(const void* d_pts, const void* d_inf32, uint32_t n, uint32_t inf_stride, void* d_out_xy, void* d_out_inf, hipStream_t st);
 void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
@@ -254,6 +256,23 @@ struct dvp_prover {
   // fixed-base MSM contexts over [g_m | g_q] and [g_k_0 | g_k_1 | g_k_2]: bases pre-rotated by tau^(20 w), built
   // lazily once the SRS is complete (12 x the base storage: 4.8 GB at m = 2^20 -- HBM is not the scarce resource)
   MsmFixedCtx* fx[2] = {nullptr, nullptr};
+  size_t fx_lo[2] = {0, 0}, fx_hi[2] = {0, 0};  // index range of the bases the context of MSM `which` was built for
+  bool last_begin_extended = false;            // dvp_prove_begin_partial(need_extend): q2 / k_r are valid only if true
+  // in-library multi-GPU (dvp_set_devices): one shard per listed device, each with its slice of both base vectors
+  struct Shard {
+    int device = 0;
+    size_t lo[2] = {0, 0}, hi[2] = {0, 0};
+    Aff* bases[2] = {nullptr, nullptr};
+    uint8_t* inf[2] = {nullptr, nullptr};
+    Fr* sc[2] = {nullptr, nullptr};
+    MsmFixedCtx* fx[2] = {nullptr, nullptr};
+    uint32_t* out = nullptr;  // 2 x (16 words x||y + 1 word flag + pad)
+    hipStream_t st = nullptr;
+  };
+  std::vector<Shard> shards;
+  std::vector<int> shard_devices;
+  int home_device = 0;
+  uint32_t* mg_parts = nullptr;  // home: 64 records of 80 B (packed for msm_sum_points_dev: 64 x 64 B points, then 64 flags)
   // work buffers
   Fr *w = nullptr, *E = nullptr, *E2 = nullptr, *r2 = nullptr, *SA = nullptr /* [w | q2] */, *den = nullptr, *den2 = nullptr,
      *SK = nullptr, *partial = nullptr, *abir0 = nullptr;
@@ -287,6 +306,7 @@ static Fr host_vanish(const dvp_prover* p, int which, const Fr& x_m) {
 }
 
 static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32_t n_wires);
+static void shards_release(dvp_prover* p);
 extern "C" void dvp_prover_destroy(dvp_prover* p);
 
 extern "C" int dvp_prover_create(uint32_t log2_m, uint32_t n_public, uint32_t n_wires, dvp_prover** out) {
@@ -363,6 +383,8 @@ extern "C" void dvp_prover_destroy(dvp_prover* p) {
   }
   msm_fixed_destroy(p->fx[0]);
   msm_fixed_destroy(p->fx[1]);
+  shards_release(p);
+  if (p->mg_parts) (void)hipFree(p->mg_parts);
   if (p->tree) dvp_ecfft_destroy(p->tree);
   delete p;
 }
@@ -417,6 +439,13 @@ extern "C" int dvp_prover_set_matrix(dvp_prover* p, int which, uint32_t n_rows, 
 // which: 0 g_m (n_wires), 1 g_q (m), 2 g_k_0 (m), 3 g_k_1 (m), 4 g_k_2 (2m) -- src/artifacts.rs names;
 // enc = payload of the reference's point-vector file (n x 30 B, src/io_utils.rs:83-111), decoded ONCE
 // into HBM-resident affine bases (the reference re-reads and re-decodes them on every prove()).
+static void shards_release(dvp_prover* p);
+// a base vector of MSM `slot` changed: its fixed-base tables (and every device shard) are stale
+static void srs_changed(dvp_prover* p, int slot) {
+  msm_fixed_destroy(p->fx[slot]);
+  p->fx[slot] = nullptr;
+  shards_release(p);
+}
 static int srs_slot(dvp_prover* p, int which, Aff** base, uint8_t** inf, size_t* n) {
   size_t m = p->m;
   switch (which) {
@@ -438,9 +467,7 @@ extern "C" int dvp_prover_set_srs_encoded(dvp_prover* p, int which, const uint8_
   DVP_HIP(hipMemcpy(de.p, enc, n * 30, hipMemcpyHostToDevice));
   DVP_TRY(decode_dev(de.as<uint8_t>(), n, base, inf, 0));
   p->have_srs[which] = true;
-  int slot = which < 2 ? 0 : 1;
-  msm_fixed_destroy(p->fx[slot]);
-  p->fx[slot] = nullptr;
+  srs_changed(p, which < 2 ? 0 : 1);
   return DVP_OK;
 }
 extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_t* xy, const uint8_t* inf_in, size_t n) {
@@ -452,9 +479,7 @@ extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_
   if (inf_in) DVP_HIP(hipMemcpy(inf, inf_in, n, hipMemcpyHostToDevice));
   else DVP_HIP(hipMemset(inf, 0, n));
   p->have_srs[which] = true;
-  int slot = which < 2 ? 0 : 1;
-  msm_fixed_destroy(p->fx[slot]);
-  p->fx[slot] = nullptr;
+  srs_changed(p, which < 2 ? 0 : 1);
   return DVP_OK;
 }
 // device-to-device flavour (bases produced on the GPU, e.g. by dvp_mulgen on the same device)
@@ -467,9 +492,7 @@ extern "C" int dvp_prover_set_srs_affine_dev(dvp_prover* p, int which, const voi
   if (d_inf) DVP_HIP(hipMemcpy(inf, d_inf, n, hipMemcpyDeviceToDevice));
   else DVP_HIP(hipMemset(inf, 0, n));
   p->have_srs[which] = true;
-  int slot = which < 2 ? 0 : 1;
-  msm_fixed_destroy(p->fx[slot]);
-  p->fx[slot] = nullptr;
+  srs_changed(p, which < 2 ? 0 : 1);
   return DVP_OK;
 }
 
@@ -528,6 +551,7 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
 // k_r part of the second MSM's scalars are then NOT valid on this prover until the next full begin.
 extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream) {
   if (!p || !d_assignment || !prover_ready(p)) return DVP_EINVAL;
+  p->last_begin_extended = need_extend != 0;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
   const size_t nw = p->n_wires;
@@ -588,13 +612,161 @@ extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_
   const Fr* sc = which ? p->SK : p->SA;
   const Aff* bs = which ? p->bases_k : p->bases_a;
   const uint8_t* inf = which ? p->inf_k : p->inf_a;
-  // fixed-base mode pays off once the shared 2^20-bucket set is well filled
+  // after an extend-free begin (dvp_prove_begin_partial(need_extend = 0)) q2 and the r2 inside k_r were never computed:
+  // a range that reads them would silently sum garbage
+  if (!p->last_begin_extended && hi > lo && hi > (which ? 2 * (size_t)p->m : (size_t)p->n_wires)) return DVP_EINVAL;
+  // fixed-base mode pays off once the shared 2^c-bucket set is well filled.  The pre-rotated table covers only the index
+  // range this prover is asked for (a rank of a multi-process prove always asks for the same slice: W x slice x 64 B of
+  // HBM instead of W x everything); a call outside the covered range rebuilds it for the new range.
   const size_t fixed_min = (size_t)(tune().msm_fixed_min > 0 ? tune().msm_fixed_min : 1);
   if (hi - lo >= fixed_min && total < ((size_t)1 << 27)) {
-    if (!p->fx[which]) DVP_TRY(msm_fixed_create(bs, (uint32_t)total, hi - lo, &p->fx[which]));
-    return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)lo, (uint32_t)hi, d_out_xy, d_out_inf, (hipStream_t)stream);
+    if (p->fx[which] && (lo < p->fx_lo[which] || hi > p->fx_hi[which])) {
+      msm_fixed_destroy(p->fx[which]);
+      p->fx[which] = nullptr;
+    }
+    if (!p->fx[which]) {
+      DVP_TRY(msm_fixed_create(bs + lo, (uint32_t)(hi - lo), hi - lo, &p->fx[which]));
+      p->fx_lo[which] = lo;
+      p->fx_hi[which] = hi;
+    }
+    const size_t o = p->fx_lo[which];
+    return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)(lo - o), (uint32_t)(hi - o), d_out_xy, d_out_inf, (hipStream_t)stream);
   }
   return msm_affine_dev(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, (hipStream_t)stream);
+}
+
+// ---- in-library multi-GPU (dvp_set_devices) ------------------------------------------------------------------------
+// Only the MSMs shard: they are sums over disjoint index ranges and > 85 % of a proof.  Shard k lives on
+// device shard_devices[k]: its slice [lo, hi) of both base vectors (copied once, device to device), the fixed-base
+// tables of that slice, a scalar buffer and a stream.  A proof sends each shard its slice of the scalars
+// (hipMemcpyPeerAsync), runs the partial MSMs concurrently -- one host thread per device -- and adds the partial points
+// on the home device (k_sum_points).  RCCL is not involved: the exchange is N x 8..32 MB of scalars one way and N x 80
+// bytes back, both point-to-point copies over xGMI.
+static void shards_release(dvp_prover* p) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& sh : p->shards) {
+    (void)hipSetDevice(sh.device);
+    for (int w = 0; w < 2; ++w) {
+      if (sh.bases[w]) (void)hipFree(sh.bases[w]);
+      if (sh.inf[w]) (void)hipFree(sh.inf[w]);
+      if (sh.sc[w]) (void)hipFree(sh.sc[w]);
+      msm_fixed_destroy(sh.fx[w]);
+    }
+    if (sh.out) (void)hipFree(sh.out);
+    if (sh.st) (void)hipStreamDestroy(sh.st);
+  }
+  p->shards.clear();
+  p->shard_devices.clear();
+  (void)hipSetDevice(cur);
+}
+static void even_range(size_t total, size_t k, size_t n, size_t* lo, size_t* hi) {
+  size_t base = total / n, rem = total % n;
+  *lo = k * base + (k < rem ? k : rem);
+  *hi = *lo + base + (k < rem ? 1 : 0);
+}
+static int shards_build(dvp_prover* p, const std::vector<int>& devs) {
+  shards_release(p);
+  DVP_HIP(hipGetDevice(&p->home_device));
+  const size_t n = devs.size();
+  if (n > 64) return DVP_EINVAL;
+  if (!p->mg_parts) DVP_HIP(hipMalloc((void**)&p->mg_parts, 64 * 68));
+  p->shards.resize(n);
+  int rc = DVP_OK;
+  for (size_t k = 0; k < n && rc == DVP_OK; ++k) {
+    dvp_prover::Shard& sh = p->shards[k];
+    sh.device = devs[k];
+    auto body = [&]() -> int {
+      DVP_HIP(hipSetDevice(sh.device));
+      if (sh.device != p->home_device) (void)hipDeviceEnablePeerAccess(p->home_device, 0);  // already-enabled / unsupported: staged copies still work
+      DVP_HIP(hipStreamCreateWithFlags(&sh.st, hipStreamNonBlocking));
+      DVP_HIP(hipMalloc((void**)&sh.out, 2 * 80));
+      for (int w = 0; w < 2; ++w) {
+        const size_t total = w ? 4 * (size_t)p->m : (size_t)p->n_wires + p->m;
+        even_range(total, k, n, &sh.lo[w], &sh.hi[w]);
+        const size_t cnt = sh.hi[w] - sh.lo[w];
+        const Aff* src_b = (w ? p->bases_k : p->bases_a) + sh.lo[w];
+        const uint8_t* src_i = (w ? p->inf_k : p->inf_a) + sh.lo[w];
+        DVP_HIP(hipMalloc((void**)&sh.bases[w], (cnt ? cnt : 1) * sizeof(Aff)));
+        DVP_HIP(hipMalloc((void**)&sh.inf[w], cnt ? cnt : 1));
+        DVP_HIP(hipMalloc((void**)&sh.sc[w], (cnt ? cnt : 1) * sizeof(Fr)));
+        if (cnt) {
+          DVP_HIP(hipMemcpyPeer(sh.bases[w], sh.device, src_b, p->home_device, cnt * sizeof(Aff)));
+          DVP_HIP(hipMemcpyPeer(sh.inf[w], sh.device, src_i, p->home_device, cnt));
+        }
+        const size_t fixed_min = (size_t)(tune().msm_fixed_min > 0 ? tune().msm_fixed_min : 1);
+        if (cnt >= fixed_min) DVP_TRY(msm_fixed_create(sh.bases[w], (uint32_t)cnt, cnt, &sh.fx[w]));
+      }
+      return DVP_OK;
+    };
+    rc = body();
+  }
+  (void)hipSetDevice(p->home_device);
+  if (rc != DVP_OK) {
+    shards_release(p);
+    return rc;
+  }
+  p->shard_devices = devs;
+  return DVP_OK;
+}
+
+// MSM `which` over all shards -> home buffers d_out_xy / d_out_inf.  The home stream must have produced the scalars.
+static int mgpu_msm(dvp_prover* p, int which, void* d_out_xy, void* d_out_inf, hipStream_t home_st) {
+  const Fr* sc = which ? p->SK : p->SA;
+  DVP_HIP(hipStreamSynchronize(home_st));
+  const size_t n = p->shards.size();
+  std::vector<int> rcs(n, DVP_OK);
+  std::vector<int64_t> err_idx(n, -1);
+  std::vector<std::thread> th;
+  struct Rec { uint32_t xy[16]; uint32_t inf; };
+  std::vector<Rec> recs(n);
+  for (size_t k = 0; k < n; ++k) {
+    th.emplace_back([&, k]() {
+      dvp_prover::Shard& sh = p->shards[k];
+      auto body = [&]() -> int {
+        DVP_HIP(hipSetDevice(sh.device));
+        const size_t cnt = sh.hi[which] - sh.lo[which];
+        uint32_t* out = sh.out + 20 * which;
+        if (cnt) DVP_HIP(hipMemcpyPeerAsync(sh.sc[which], sh.device, sc + sh.lo[which], p->home_device, cnt * sizeof(Fr), sh.st));
+        if (sh.fx[which])
+          DVP_TRY(msm_fixed_dev(sh.fx[which], sh.sc[which], sh.inf[which], 0, (uint32_t)cnt, out, out + 16, sh.st));
+        else
+          DVP_TRY(msm_affine_dev(sh.sc[which], sh.bases[which], sh.inf[which], cnt, out, out + 16, sh.st));
+        DVP_HIP(hipMemcpyAsync(&recs[k], out, 68, hipMemcpyDeviceToHost, sh.st));
+        DVP_HIP(hipStreamSynchronize(sh.st));
+        return DVP_OK;
+      };
+      rcs[k] = body();
+      err_idx[k] = g_last_error_index;  // thread-local in the worker: carry it back
+    });
+  }
+  for (auto& t : th) t.join();
+  DVP_HIP(hipSetDevice(p->home_device));
+  for (size_t k = 0; k < n; ++k)
+    if (rcs[k] != DVP_OK) {
+      if (err_idx[k] >= 0) g_last_error_index = err_idx[k] + (int64_t)p->shards[k].lo[which];  // index in the whole vector
+      return rcs[k];
+    }
+  // partial points -> home: packed as n points then n flags
+  std::vector<uint32_t> pk(n * 17);
+  for (size_t k = 0; k < n; ++k) {
+    memcpy(&pk[16 * k], recs[k].xy, 64);
+    pk[16 * n + k] = recs[k].inf;
+  }
+  DVP_HIP(hipMemcpyAsync(p->mg_parts, pk.data(), n * 68, hipMemcpyHostToDevice, home_st));
+  DVP_TRY(msm_sum_points_dev(p->mg_parts, p->mg_parts + 16 * n, (uint32_t)n, 1, d_out_xy, d_out_inf, home_st));
+  DVP_HIP(hipStreamSynchronize(home_st));  // pk goes out of scope
+  return DVP_OK;
+}
+// the MSM of a full proof: over the shards when a device list is set, else on the home device alone
+static int prove_msm(dvp_prover* p, int which, void* d_out_xy, void* d_out_inf, void* stream) {
+  const std::vector<int> devs = mgpu_devices();
+  if (devs.size() > 1) {
+    if (devs != p->shard_devices) DVP_TRY(shards_build(p, devs));
+    return mgpu_msm(p, which, d_out_xy, d_out_inf, (hipStream_t)stream);
+  }
+  if (!p->shards.empty()) shards_release(p);
+  return dvp_prover_msm_partial(p, which, 0, dvp_prover_msm_size(p, which), d_out_xy, d_out_inf, stream);
 }
 // window size / window count the fixed-base context of MSM `which` settled on (0,0 before its first use)
 extern "C" int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows) {
@@ -602,6 +774,7 @@ extern "C" int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, 
   *c_bits = 0;
   *windows = 0;
   if (p->fx[which]) return msm_fixed_info(p->fx[which], c_bits, windows);
+  if (!p->shards.empty() && p->shards[0].fx[which]) return msm_fixed_info(p->shards[0].fx[which], c_bits, windows);  // multi-GPU: shard 0's
   return DVP_OK;
 }
 extern "C" size_t dvp_prover_msm_size(const dvp_prover* p, int which) {
@@ -670,9 +843,9 @@ extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t pr
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(PROF_PROVE_TOTAL, st);
   DVP_TRY(dvp_prove_begin(p, d_assignment, stream));
-  DVP_TRY(dvp_prover_msm_partial(p, 0, 0, dvp_prover_msm_size(p, 0), p->pts, p->pts_inf32, stream));
+  DVP_TRY(prove_msm(p, 0, p->pts, p->pts_inf32, stream));
   DVP_TRY(dvp_prove_challenge(p, p->pts, p->pts_inf32, stream));
-  DVP_TRY(dvp_prover_msm_partial(p, 1, 0, dvp_prover_msm_size(p, 1), p->pts + 1, p->pts_inf32 + 1, stream));
+  DVP_TRY(prove_msm(p, 1, p->pts + 1, p->pts_inf32 + 1, stream));
   ps.stop();
   return dvp_prove_finish(p, p->pts + 1, p->pts_inf32 + 1, proof, stream);
 }

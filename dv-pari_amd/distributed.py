@@ -87,19 +87,15 @@ class GpuBackend:
         return self.part
 
     def combine(self, gathered):
-        """gathered: [world, 10] int64 -> one point tensor [10] (sum of the partial points)"""
-        from . import curve
+        """gathered: [world, 10] int64 -- the all-gathered 80-byte records (x || y, u32 infinity flag, pad) -- -> one point
+        tensor [10]: their sum by world - 1 additions (dvp_points_sum_dev)"""
+        from ._native import lib, check
 
         torch = self.torch
-        world = gathered.shape[0]
-        if self.ones is None or self.ones.shape[0] != world:
-            self.ones = torch.zeros((world, 4), dtype=torch.int64, device=self.device)
-            self.ones[:, 0] = 1
-        xy = gathered[:, :8].contiguous()
-        inf = (gathered[:, 8] & 0xFFFFFFFF).to(torch.uint8).contiguous()
+        g = gathered.contiguous()
         out = torch.zeros(10, dtype=torch.int64, device=self.device)
-        curve.multi_scalar_mul_dev(self.ones.data_ptr(), xy.data_ptr(), inf.data_ptr(), world, out.data_ptr(),
-                                   out.data_ptr() + 64, torch.cuda.current_stream().cuda_stream)
+        check(lib.dvp_points_sum_dev(g.data_ptr(), g.shape[0], out.data_ptr(), out.data_ptr() + 64, torch.cuda.current_stream().cuda_stream),
+              "dvp_points_sum_dev")
         return out
 
     def challenge(self, point):

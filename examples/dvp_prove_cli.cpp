@@ -2,7 +2,10 @@
 // against.  It mirrors the reference's `Proof::prove(cache_dir, public_inputs, private_inputs)` call
 // (src/proving.rs:426) from files alone:
 //
-//   dvp_prove_cli <cache_dir> <n_public> [<proof_out>]
+//   dvp_prove_cli <cache_dir> <n_public> [<proof_out>] [--devices 0,1,2,3]
+//
+// --devices d0,d1,..: in-library multi-GPU (dvp_set_devices): the two MSMs of the proof are sharded over the listed
+// devices, one host thread each; d0 is the home device.  An id may repeat.  The proof bytes do not depend on the list.
 //
 // reads <cache_dir>/witness_to_dvsnark (u32-BE count || 32-byte BE elements = [1, public.., private..],
 // src/gnark_r1cs.rs:188-210), lets the library open the R1CS dump and the SRS point files of the same directory, proves on
@@ -17,15 +20,37 @@
 #include "dvpari.h"
 
 int main(int argc, char** argv) {
-  if (argc < 3) {
-    fprintf(stderr, "usage: %s <cache_dir> <n_public> [<proof_out>]\n", argv[0]);
+  std::vector<int> devices;
+  std::vector<char*> pos;
+  for (int i = 1; i < argc; ++i) {
+    if (std::string(argv[i]) == "--devices" && i + 1 < argc) {
+      for (char* tok = argv[++i]; *tok;) {
+        devices.push_back((int)strtol(tok, &tok, 10));
+        if (*tok == ',') ++tok;
+      }
+    } else {
+      pos.push_back(argv[i]);
+    }
+  }
+  if (pos.size() < 2) {
+    fprintf(stderr, "usage: %s <cache_dir> <n_public> [<proof_out>] [--devices 0,1,..]\n", argv[0]);
     return 2;
   }
+  argc = (int)pos.size() + 1;
+  for (size_t i = 0; i < pos.size(); ++i) argv[i + 1] = pos[i];
   const std::string dir = argv[1];
   const uint32_t n_public = (uint32_t)strtoul(argv[2], nullptr, 10);
   if (dvp_device_count() <= 0) {
     fprintf(stderr, "no HIP device visible (the library has no CPU path)\n");
     return 3;
+  }
+  if (!devices.empty()) {
+    int rcd = dvp_set_device(devices[0]);
+    if (rcd == DVP_OK) rcd = dvp_set_devices(devices.data(), (int)devices.size());
+    if (rcd != DVP_OK) {
+      fprintf(stderr, "--devices: %s\n", dvp_strerror(rcd));
+      return 1;
+    }
   }
   const std::string wpath = dir + "/witness_to_dvsnark";
   size_t n = 0;

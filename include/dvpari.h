@@ -49,6 +49,14 @@ int dvp_version(void);
 /* number of visible HIP devices; <0 on error.  The library never falls back to a CPU path. */
 int dvp_device_count(void);
 int dvp_set_device(int device_id);
+/* In-library multi-GPU behind the unchanged prove signatures: after dvp_set_devices(ids, n), n > 1, every
+ * dvp_prove / dvp_prove_dev / dvp_prove_cache_dir call shards the two MSMs of the proof (src/proving.rs:463,512,680) by
+ * index range over the listed devices -- each device keeps its slice of the SRS bases and its fixed-base tables, one host
+ * thread per device runs the partial MSM, scalars and partial points move by hipMemcpyPeer (xGMI), and the home device
+ * (ids[0] = the device the prover was created on) adds the partial points.  The Fr stages (R1CS evaluation, ECFFT
+ * extends, pointwise maps; < 15 % of a proof) stay on the home device.  An id may repeat (a one-GPU box can exercise
+ * the path).  n <= 1 restores single-device proving.  Proof bytes are identical for every device list. */
+int dvp_set_devices(const int* device_ids, int n);
 /* last failing index for DVP_EDECODE / DVP_EUNSAT / DVP_EINVAL (thread-local), or -1 */
 int64_t dvp_last_error_index(void);
 
@@ -123,6 +131,9 @@ int dvp_barycentric_eval(const uint64_t* domain, const uint64_t* bar_weights, co
  * representative; bases_inf[n] (may be NULL) marks neutral elements. */
 int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n,
                    uint64_t out_xy[8], int* out_is_infinity);
+/* sum of n partial points held as 80-byte records (x || y, u32 infinity flag, pad): what the ranks of a multi-process
+ * prove all-gather, combined with n - 1 additions (RCCL has no reduction for curve points) */
+int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out_xy, void* d_out_inf, void* stream);
 int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void* d_bases_inf, size_t n,
                        void* d_out_xy /*8 x u64*/, void* d_out_inf /*u32*/, void* stream);
 /* Fixed-base flavour of the same seam: the reference calls multi_scalar_mul with the SAME bases (the SRS

@@ -210,6 +210,10 @@ def test_cpp_host_over_the_c_abi(dvp, tmp_path):
     assert bytes.fromhex(out.stdout.strip()) == ref.to_bytes()
     assert (tmp_path / "proof.bin").read_bytes() == ref.to_bytes()
     assert dvp.srs.verify(td, pub, dvp.proving.Proof.from_bytes((tmp_path / "proof.bin").read_bytes()))
+    # in-library multi-GPU (dvp_set_devices) from the compiled host: four shards on device 0, identical bytes
+    out = subprocess.run([str(exe), str(cache), str(len(pub)), "--devices", "0,0,0,0"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert bytes.fromhex(out.stdout.strip()) == ref.to_bytes()
     # a different public-input count is a different statement (Vandermonde fold, transcript): other bytes
     out = subprocess.run([str(exe), str(cache), "0"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and bytes.fromhex(out.stdout.strip()) != ref.to_bytes()

@@ -259,3 +259,63 @@ def test_prove_2_20_full_size(dvp):
             pv.challenge(point.data_ptr(), point.data_ptr() + 64, st)
     assert pv.finish(point.data_ptr(), point.data_ptr() + 64, st) == proof
     pv.close()
+
+
+@pytest.mark.parametrize("log_m,devices", [(13, [0, 0]), (13, [0, 0, 0, 0, 0, 0, 0, 0]), (16, [0, 0, 0])])
+def test_in_library_multi_gpu_same_bytes(dvp, log_m, devices):
+    """dvp_set_devices: behind the unchanged dvp_prove signature the two MSMs are sharded over the listed
+    devices -- per-device base slices and fixed-base tables, one host thread per device, partial points added on the home
+    device.  Listing device 0 N times exercises the whole path on a one-GPU box; the bytes must not depend on the list,
+    unsatisfied witnesses are still reported with their row, and a bad scalar index comes back in whole-vector terms."""
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
+    rnd = random.Random(100 + log_m)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    with dvp.tune(DVP_MSM_FIXED_MIN=1):
+        ref = pv.prove(pub, prv)
+        assert dvp.srs.verify(td, pub, ref)
+        try:
+            dvp.set_devices(devices)
+            assert pv.prove(pub, prv) == ref
+            assert pv.prove(pub, prv) == ref          # shards are reused
+            assert pv.msm_plan(1)[0] > 0
+            bad = list(prv)
+            bad[7] = (bad[7] + 1) % o.P
+            with pytest.raises(dvp.DvpError) as e:
+                pv.prove(pub, bad)
+            assert e.value.status == -3
+            dvp.set_devices(devices[:-1] if len(devices) > 2 else [])   # the list may change between proofs
+            assert pv.prove(pub, prv) == ref
+        finally:
+            dvp.set_devices([])
+        assert pv.prove(pub, prv) == ref
+    with pytest.raises(dvp.DvpError):
+        dvp.set_devices([0, 99])
+    pv.close()
+
+
+def test_points_sum_records(dvp):
+    """dvp_points_sum_dev: n 80-byte records (x || y, u32 infinity flag) -> their sum; incl. the neutral element, P + P
+    and P + (-P) (what a rank's all-gathered partial MSM results can be)"""
+    import torch
+
+    ks = [5, 7, 7, o.P - 7, 11]
+    pts = [co.k233_mulgen(k) for k in ks]
+    dev = torch.device("cuda", 0)
+    rec = np.zeros((len(ks) + 1, 10), dtype=np.uint64)
+    for i, pt in enumerate(pts):
+        rec[i, :8] = to_limbs(list(pt)).reshape(8)
+    rec[len(ks), 8] = 1  # a neutral partial
+    d = torch.from_numpy(rec.view(np.int64)).to(dev)
+    out = torch.zeros(10, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for n, exp_k in ((6, sum(ks) % o.P), (2, 12), (3, 19), (4, 12)):
+        dvp.check(dvp.lib.dvp_points_sum_dev(d.data_ptr(), n, out.data_ptr(), out.data_ptr() + 64, st))
+        h = out.cpu().numpy().view(np.uint64)
+        got = None if (int(h[8]) & 0xFFFFFFFF) else tuple(from_limbs(h[:8].reshape(2, 4)))
+        assert got == co.k233_mulgen(exp_k), n
+    # two opposite points alone -> neutral
+    d2 = torch.from_numpy(rec[[2, 3]].copy().view(np.int64)).to(dev)
+    dvp.check(dvp.lib.dvp_points_sum_dev(d2.data_ptr(), 2, out.data_ptr(), out.data_ptr() + 64, st))
+    assert int(out.cpu().numpy().view(np.uint64)[8]) & 0xFFFFFFFF == 1
