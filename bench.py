@@ -4,22 +4,28 @@ bench.py -- DV-Pari prover hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py --gpus N --inproc          (ONE process, in-library multi-GPU: dvp_set_devices(0..N-1))
 
-One "step" = one full Proof::prove (src/proving.rs:426-688) of a synthetic dense R1CS with 2^20
-constraints (BASELINE config #4: the configuration the metric "R1CS constraints/sec (prove) at 2^20" is
-quoted on), witness already resident in HBM.  With N > 1 the two MSMs of the proof are sharded by
-index range over the ranks and combined by all-gather + local add (strong scaling: the proof size is
-fixed).  Rank 0 prints ONE JSON line; the proof of the last step is checked with the designated-
-verifier equation (src/srs.rs:374-428) outside the timed region.
+One "step" = one full Proof::prove (src/proving.rs:426-688) of a synthetic dense R1CS with 2^20 constraints (BASELINE
+config #4, the configuration the metric "R1CS constraints/sec (prove) at 2^20" is quoted on), witness already resident
+in HBM.  With N > 1 the two MSMs of the proof are sharded by index range over the ranks and combined by all-gather +
+local add (strong scaling: the proof size is fixed).  Rank 0 prints ONE JSON line; the proof of the last step is checked
+with the designated-verifier equation (src/srs.rs:374-428) outside the timed region.
 
-roofline: dominant kernel = dvp::k_affine_round<true, B> (first batched-affine pair round of the MSM bucket
-accumulation: it gathers every base once per window); algorithmic bytes = 96 B per (scalar, base) pair
- x pairs per launch, divided by the launch time measured with HIP events on the launch
-stream (dvp_profile_*).  The kernel is bound by GF(2^233) products (integer VALU + LDS; no carry-less
-multiply on gfx950), so the HBM fraction is tiny by construction; the product-rate model is reported
-next to it as "work_model".
-cpu_baseline: the C restatement with the reference's algorithmic shape (oracle/dvp_oracle.c: one
-tau-adic scalar multiplication per point + add tree) timed on this box's host cores on a bounded sample.
+roofline (dominant kernel = dvp::k_affine_round, first batched-affine pair round of each MSM: it gathers every base once
+per window).  `achieved` is the figure the contract asks for -- algorithmic bytes (96 B per (scalar, base) pair, SURVEY 8d,
+x pairs per launch) / the launch time measured live with HIP events on the launch stream -- against the HBM peak; it is
+tiny by construction, because the kernel is bound by GF(2^233) products on the integer VALU + LDS (gfx950 has no
+carry-less multiply), so `bound` says "valu" and the block also carries what actually limits the kernel:
+  * work_model: field-product equivalents per launch / launch time, against the multiplier's own rate measured IN THIS
+    RUN (dvp_ubench_gf_mul, outside the timed loop);
+  * valu_insts_per_simd_cycle / lds_busy_frac from the committed SQ counter pass of the same kernel (profiles/), with the
+    issue-rate ceilings they are to be read against;
+  * traffic: HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes, raw and with the microarchitecture
+    guide's x2 FETCH correction, and their ratio to the algorithmic bytes.
+cpu_baseline: the C restatement with the reference's algorithmic shape (oracle/dvp_oracle.c: one tau-adic scalar
+multiplication per point + add tree; plus the extend butterflies in 4 x 64-bit Montgomery arithmetic) on this box's host
+cores on a bounded sample, and OpenSSL's EC_POINT_mul per point as a third-party datapoint.
 """
 import argparse
 import importlib
@@ -30,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+PROFILE_TAG = "r02"
 
 
 def log(*a):
@@ -49,23 +56,39 @@ def host_cores() -> int:
     return min(n, int(os.environ.get("DVP_CPU_THREADS", "16")))
 
 
+def cpu_mhz() -> float:
+    try:
+        vals = [float(l.split(":")[1]) for l in open("/proc/cpuinfo") if l.startswith("cpu MHz")]
+        return max(vals) if vals else 0.0
+    except Exception:
+        return 0.0
+
+
+def load_profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-m", type=int, default=20, help="log2 of the number of constraints (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--inproc", action="store_true", help="one process, in-library multi-GPU over devices 0..gpus-1 (dvp_set_devices)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = 1 if args.inproc else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0 if args.inproc else int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.inproc else int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs for a one-GPU box (never set by the driver): DVP_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # DVP_DIST_BACKEND=gloo replaces RCCL, so the sharded path can be exercised end to end without a second GPU
     share_gpu = os.environ.get("DVP_BENCH_SHARE_GPU") == "1"
@@ -78,7 +101,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert args.inproc or world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
@@ -94,13 +117,23 @@ def main():
     pv = dvp.proving.Prover(inst)
     srs = dvp.srs.verifier_runs_setup(pv, inst, td)
     pv.set_srs(srs)
-    assignment = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
+    w_host = dvp.fr.vec([1] + pub + prv)
+    assignment = torch.from_numpy(w_host.view(np.int64)).to(dev)
     if rank == 0:
         log(f"[bench] setup m=2^{log_m} n_wires={inst.n_wires} in {time.time() - t0:.1f}s")
-    backend = dvp.distributed.GpuBackend(pv, dev)
+    gpu_backend = dvp.distributed.GpuBackend(pv, dev)
+    n_dev_inproc = 1
+    if args.inproc and args.gpus > 1:
+        ids = [0] * args.gpus if share_gpu else list(range(args.gpus))
+        dvp.set_devices(ids)
+        n_dev_inproc = args.gpus
+
+    stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        return dvp.distributed.prove_sharded(backend, assignment)
+        if args.inproc:
+            return pv.prove_dev(assignment.data_ptr(), stream)
+        return dvp.distributed.prove_sharded(gpu_backend, assignment)
 
     if world > 1:  # communicator set-up is not part of a proof: one throw-away exchange even with --warmup 0
         probe = torch.zeros(10, dtype=torch.int64, device=dev)
@@ -135,6 +168,9 @@ def main():
         return ms.value, n.value
 
     acc_ms, acc_n = prof("msm_affine_round0")
+    rest_ms, _ = prof("msm_affine_rest")
+    sort_ms, _ = prof("msm_sort")
+    tail_ms, _ = prof("msm_tail")
     msm_ms, msm_n = prof("msm_total")
     ext_ms, ext_n = prof("extend_total")
 
@@ -143,39 +179,85 @@ def main():
             dist.destroy_process_group()
         return
 
-    # correctness of what was timed: the proof must verify, and it must be reproducible
+    # correctness of what was timed: the proof must verify
     assert dvp.srs.verify(td, pub, proof), "bench proof does not verify"
+    n_shards = world * n_dev_inproc
     ms_per_step = elapsed / args.steps * 1e3
     value = m * args.steps / elapsed
-    pairs_total = (inst.n_wires + m + 4 * m) * args.steps / world  # (scalar, base) pairs this rank pushed through the kernel
+
+    # ---- outside the timed region: the same proof through the host-pointer seam (dvp_prove = Proof::prove's signature,
+    # src/proving.rs:426: witness in host memory, +32 B/wire of H2D), and the multiplier microbenchmark ----------------
+    host_ms = None
+    mul_rate = None
+    if world == 1 and n_dev_inproc == 1:
+        pv.prove(pub, prv)
+        t1 = time.perf_counter()
+        reps = max(3, args.steps // 2)
+        pub_l, prv_l = w_host[1:1 + len(pub)], w_host[1 + len(pub):]
+        for _ in range(reps):
+            p2 = pv.prove(pub_l, prv_l)
+        host_ms = (time.perf_counter() - t1) / reps * 1e3
+        assert p2 == proof
+        r = C.c_double(0)
+        dvp.check(dvp.lib.dvp_ubench_gf_mul(200, C.byref(r)), "dvp_ubench_gf_mul")
+        mul_rate = r.value
+
+    pairs_total = (inst.n_wires + m + 4 * m) * args.steps / n_shards  # (scalar, base) pairs this rank pushed through the kernel
     pairs_per_launch = pairs_total / max(acc_n, 1)
     acc_avg_ms = acc_ms / max(acc_n, 1)
-    achieved = 96.0 * pairs_per_launch / (acc_avg_ms * 1e-3) / 1e9 if acc_n else 0.0
-    # work model of the dominant kernel (first batched-affine pair round): W windows per pair, half of the
-    # entries are additions, each 5 products + 1 squaring + 1/16 of a table-driven inversion ~ 6.1 field-
-    # multiplication equivalents; ceiling = the LDS-comb multiplier's own microbenchmark rate
-    # (tools/ubench/gfmul_occ.hip, 8 waves/CU as in the hot kernels: 31.6 G products/s chip-wide)
+    alg_bytes = 96.0 * pairs_per_launch
+    achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_n else 0.0
     plans = [pv.msm_plan(0), pv.msm_plan(1)]
     sizes = [pv.msm_size(0), pv.msm_size(1)]
-    # effective windows: tau-adic expansions are ~234 digits long, the last allocated window is mostly empty
-    w_eff = sum(-(-234 // max(c, 1)) * n for (c, _), n in zip(plans, sizes)) / max(sum(sizes), 1) if all(c for c, _ in plans) else 16
-    # per addition: 5 products + 1 squaring (~0.13) + 1/B of a table-driven inversion (~15 product-equivalents); the first
-    # round of an MSM this size runs the B = 32 flavour
-    per_add = 5.13 + 15.0 / (32 if pairs_per_launch * w_eff * 0.5 >= (8 << 20) else 16)
-    mul_eq = pairs_per_launch * w_eff * 0.5 * per_add
-    mul_ceiling = 31.6e9
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_k_affine_round0.json")))
-        if log_m == 20 and world == 1:
-            traffic = pmc["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    # effective windows: tau-adic expansions are ~234 digits long, the overflow window is empty in practice
+    w_eff = sum(-(-234 // max(c, 1)) * n for (c, _), n in zip(plans, sizes)) / max(sum(sizes), 1) if all(c for c, _ in plans) else 13
+    # per addition: 5 products + 1 squaring (~0.13 product) + 1/B of a table-driven inversion (~15 product-equivalents);
+    # B is chosen on the device (25..48 in a first round; 36 is typical at this size)
+    per_add = 5.13 + 15.0 / 36.0
+    adds_per_launch = pairs_per_launch * w_eff * 0.5
+    mul_eq = adds_per_launch * per_add
+    roof = {
+        "kernel": "dvp::k_affine_round (first pair round of each MSM)",
+        "bound": "valu",
+        "bound_note": "integer VALU + LDS issue (GF(2^233) products without a carry-less multiplier); HBM and MFMA are not the limit -- "
+                      "achieved/peak/frac below is the algorithmic-bytes figure against HBM that the metric contract asks for",
+        "achieved": achieved,
+        "peak": 8000.0,
+        "unit": "GB/s",
+        "frac": achieved / 8000.0,
+        "traffic": None,
+        "launches": int(acc_n),
+        "avg_launch_ms": acc_avg_ms,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "work_model": {
+            "note": "W/2 affine additions per (scalar, base) pair, each 5 products + 1 squaring + 1/B shared inversion ~ 5.55 product "
+                    "equivalents; ceiling = dvp_ubench_gf_mul measured in this run (Karatsuba LDS multiplier alone, same occupancy)",
+            "additions_per_launch": adds_per_launch,
+            "mul_equivalents_per_launch": mul_eq,
+            "achieved_mul_per_s": mul_eq / (acc_avg_ms * 1e-3) if acc_n else 0.0,
+            "multiplier_microbench_mul_per_s": mul_rate,
+            "frac": (mul_eq / (acc_avg_ms * 1e-3)) / mul_rate if (acc_n and mul_rate) else None,
+        },
+    }
+    traffic = load_profile("pmc_traffic_k_affine_round0")
+    if traffic and log_m == 20 and n_shards == 1:
+        raw = traffic["traffic_bytes_per_launch_raw"]
+        roof["traffic"] = traffic["traffic_bytes_per_launch_fetch_x2"]
+        roof["traffic_detail"] = {
+            "source": f"profiles/{PROFILE_TAG}_pmc_traffic_k_affine_round0.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
+            "raw_bytes_per_launch": raw,
+            "fetch_x2_bytes_per_launch": traffic["traffic_bytes_per_launch_fetch_x2"],
+            "ratio_to_algorithmic_raw": raw / alg_bytes,
+            "ratio_to_algorithmic_fetch_x2": traffic["traffic_bytes_per_launch_fetch_x2"] / alg_bytes,
+        }
+    sq = load_profile("pmc_sq_k_affine_round0")
+    if sq and log_m == 20 and n_shards == 1:
+        roof["issue"] = sq
     out = {
         "metric": "R1CS constraints/sec (prove)",
         "value": value,
         "unit": "constraints/s",
-        "n_gpus": world,
+        "n_gpus": args.gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -189,44 +271,31 @@ def main():
             "log2_constraints": log_m,
             "n_wires": inst.n_wires,
             "msm_pairs_per_proof": inst.n_wires + 5 * m,
-            "sharding": "MSM index ranges per rank, all-gather of partial points + local add" if world > 1 else "single GPU",
+            "sharding": ("in-library (dvp_set_devices): MSM index ranges per device, one host thread each, partial points added on device 0"
+                         if n_dev_inproc > 1 else
+                         "MSM index ranges per rank, all-gather of partial points + local add" if world > 1 else "single GPU"),
             "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1]}, "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1]}},
             "witness": "resident in HBM",
         },
-        "roofline": {
-            "kernel": "dvp::k_affine_round<true, 32>",
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": 8000.0,
-            "unit": "GB/s",
-            "frac": achieved / 8000.0,
-            "traffic": traffic,
-            "launches": int(acc_n),
-            "avg_launch_ms": acc_avg_ms,
-            "algorithmic_bytes_per_launch": 96.0 * pairs_per_launch,
-            "work_model": {
-                "note": "kernel is bound by GF(2^233) products (integer VALU + LDS table reads; gfx950 has no carry-less "
-                        "multiply): W/2 affine additions per pair at 5 products + 1 squaring + 1/B inversion each (~5.6 at B = 32); "
-                        "ceiling = measured rate of the multiplier alone",
-                "mul_equivalents_per_launch": mul_eq,
-                "achieved_mul_per_s": mul_eq / (acc_avg_ms * 1e-3) if acc_n else 0.0,
-                "multiplier_microbench_mul_per_s": mul_ceiling,
-                "frac": (mul_eq / (acc_avg_ms * 1e-3)) / mul_ceiling if acc_n else 0.0,
-            },
-        },
+        "ms_per_step_host_witness": host_ms,
+        "roofline": roof,
         "stages_ms_per_step": {
             "msm_total": msm_ms / args.steps,
+            "msm_recode_sort": sort_ms / args.steps,
             "msm_affine_round0": acc_ms / args.steps,
+            "msm_affine_later_rounds": rest_ms / args.steps,
+            "msm_merge_frobenius_tail": tail_ms / args.steps,
             "extend": ext_ms / args.steps,
         },
         "msm_mpoints_per_s": (pairs_total / (msm_ms * 1e-3) / 1e6) if msm_ms else None,
     }
 
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and n_dev_inproc == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle as co
 
         cores = host_cores()
+        mhz = cpu_mhz()
         rng = np.random.default_rng(99)
 
         def rand(n):
@@ -234,7 +303,8 @@ def main():
             s[:, 3] &= np.uint64((1 << 38) - 1)
             return s
 
-        probe = 1 << 14
+        pts_per_constraint = (inst.n_wires + 5 * m) / m
+        probe = 1 << 13
         bases = np.ascontiguousarray(srs.g_k[2][0])  # 2m real SRS bases
         cap = bases.shape[0]
         sc = rand(cap)
@@ -243,19 +313,50 @@ def main():
         rate = probe / (time.perf_counter() - t1)
         n_s = int(min(cap, max(probe, rate * args.cpu_seconds)))
         t1 = time.perf_counter()
-        res = co.msm(sc[:n_s], bases[:n_s], threads=cores)
+        co.msm(sc[:n_s], bases[:n_s], threads=cores)
         dt = time.perf_counter() - t1
         pts_per_s = n_s / dt
+        us_core = cores / pts_per_s * 1e6
+        # the four extends of a proof (src/proving.rs:410-422): 2 log2(m) butterfly passes each, 4 Fr products per pair, in the
+        # 4 x 64-bit Montgomery arithmetic of the reference's Fr; timing is data-independent, so one vector with synthetic
+        # matrices is timed and scaled
+        ext_n = 1 << min(log_m, 18)
+        data = rand(ext_n)
+        mats = np.ascontiguousarray(rand(2 * (ext_n // 2) * 4).reshape(2, ext_n // 2, 4, 4))
+        passes = 2 * (ext_n.bit_length() - 1)
+        t1 = time.perf_counter()
+        co.fr_butterfly_passes(data, mats, passes, cores)
+        dt_ext = time.perf_counter() - t1
+        ns_per_frmul = dt_ext / (passes * ext_n * 2) * 1e9 * cores
+        ext_s_per_proof = 4 * (2 * log_m) * (m * 2) * ns_per_frmul * 1e-9 / cores
+        msm_s_per_proof = (inst.n_wires + 5 * m) / pts_per_s
+        cpu_s = msm_s_per_proof + ext_s_per_proof
+        ossl = None
+        try:
+            n_o = max(64 * cores, 256)
+            t1 = time.perf_counter()
+            r = co.openssl_msm(sc[:n_o], bases[:n_o], threads=cores)
+            if r is not NotImplemented:
+                ossl = n_o / (time.perf_counter() - t1)
+        except Exception as e:  # the third-party datapoint is optional
+            log(f"[bench] OpenSSL datapoint unavailable: {e}")
         out["cpu_baseline"] = {
-            "value": pts_per_s / ((inst.n_wires + 5 * m) / m),
+            "value": m / cpu_s,
             "unit": "constraints/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"{n_s}-point reference-shaped MSM (one tau-adic scalar multiplication per point + add tree, "
-                      f"oracle/dvp_oracle.c) in {dt:.1f}s = {pts_per_s:.0f} points/s; a proof needs "
-                      f"{(inst.n_wires + 5 * m) / m:.2f} point multiplications per constraint; ECFFT and pointwise stages "
-                      "(<5% of the CPU path) not included",
+            "sample": f"{n_s}-point reference-shaped MSM (one tau-adic scalar multiplication per point + add tree, oracle/dvp_oracle.c) in "
+                      f"{dt:.1f}s = {pts_per_s:.0f} points/s on {cores} threads = {us_core:.1f} us*core per point"
+                      + (f" (~{us_core * mhz / 1e3:.0f} k cycles at {mhz:.0f} MHz; xs233's own xsk233_mul_frob is quoted at ~29.6 k cycles, so the "
+                         f"reference's C library would be ~{us_core * mhz / 1e3 / 29.6:.1f}x faster than this port)" if mhz else "")
+                      + f"; a proof needs {pts_per_constraint:.2f} point multiplications per constraint = {msm_s_per_proof:.2f}s; plus the four "
+                      f"extends as {passes} butterfly passes over 2^{ext_n.bit_length() - 1} elements in 4x64-bit Montgomery arithmetic "
+                      f"({ns_per_frmul:.0f} ns*core per Fr product) scaled to 2^{log_m} = {ext_s_per_proof:.2f}s per proof; pointwise stages not included",
             "msm_points_per_s": pts_per_s,
+            "msm_us_core_per_point": us_core,
+            "extend_s_per_proof": ext_s_per_proof,
+            "openssl_ec_point_mul_points_per_s": ossl,
+            "openssl_note": "OpenSSL 3 EC_POINT_mul on sect233k1, one per point + EC_POINT_add (the reference's MSM shape on a third-party library)",
         }
     print(json.dumps(out), flush=True)
     if world > 1:

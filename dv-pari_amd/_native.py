@@ -35,6 +35,7 @@ _SIGS = {
     "dvp_last_error_index": (C.c_int64, []),
     "dvp_tune_set": (C.c_int, [C.c_char_p, C.c_longlong]),
     "dvp_tune_reset": (None, []),
+    "dvp_ubench_gf_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),
     "dvp_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -876,6 +876,21 @@ __global__ void __launch_bounds__(64) k_sum_points(const Aff* __restrict__ pts, 
   *out_inf = fin ? 0u : 1u;
 }
 
+// multiplier microbenchmark (bench.py's roofline leg runs it OUTSIDE the timed loop): a dependent chain of products per
+// lane through the Karatsuba LDS multiplier at the occupancy of k_affine_round (256-thread blocks, 3 waves per SIMD)
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3))) k_ubench_mul(Gf* __restrict__ out, int reps) {
+  extern __shared__ char lds_raw[];
+  GfLdsK L = gf_ldsk_init(lds_raw);
+  const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+  Gf x, y;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { x.w[i] = t * 2654435761u + i; y.w[i] = t * 40503u + 7 * i; }
+  x.w[7] &= 0x1ff; y.w[7] &= 0x1ff;
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) { x = gf_mul(x, y, L); y.w[0] ^= x.w[3]; }
+  out[t] = x;
+}
+
 // ---- workspace -----------------------------------------------------------------------------------
 struct MsmWorkspace {
   std::mutex mu;
@@ -1344,6 +1359,36 @@ extern "C" int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out
   DVP_HIP(hipMemcpy2DAsync((char*)pk.p + (size_t)n * 64, 4, (const char*)d_records + 64, 80, 4, n, hipMemcpyDeviceToDevice, st));
   DVP_TRY(msm_sum_points_dev(pk.p, (char*)pk.p + (size_t)n * 64, n, 1, d_out_xy, d_out_inf, st));
   DVP_HIP(hipStreamSynchronize(st));  // pk is released on return
+  return DVP_OK;
+}
+
+// GF(2^233) products per second of the hot kernels' multiplier alone (every CU busy, k_affine_round's occupancy): the
+// ceiling bench.py's work model divides by, measured in the same process instead of quoted
+extern "C" int dvp_ubench_gf_mul(int reps, double* products_per_s) {
+  if (reps < 1 || !products_per_s) return DVP_EINVAL;
+  int dev = 0, n_cu = 256;
+  DVP_HIP(hipGetDevice(&dev));
+  DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  const int blocks = n_cu * 3 * 8;  // eight chip-fulls of 3 blocks per CU
+  DevBuf out;
+  DVP_TRY(out.alloc((size_t)blocks * EC_TPB * sizeof(Gf)));
+  hipEvent_t e0, e1;
+  DVP_HIP(hipEventCreate(&e0));
+  DVP_HIP(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int it = 0; it < 3; ++it) {
+    DVP_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_ubench_mul, dim3(blocks), dim3(EC_TPB), EC_LDS, 0, out.as<Gf>(), reps);
+    DVP_HIP(hipEventRecord(e1, 0));
+    DVP_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    DVP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  DVP_HIP(hipGetLastError());
+  *products_per_s = (double)blocks * EC_TPB * reps / (best * 1e-3);
   return DVP_OK;
 }
 

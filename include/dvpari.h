@@ -70,6 +70,9 @@ void dvp_tune_reset(void);
  * "msm_affine_round0" (first k_affine_round of an MSM, the dominant kernel: it gathers the bases), "msm_affine_rest"
  * (the later pair rounds), "msm_sort" (recode + counting sort), "msm_tail" (merge tree, Frobenius tail), "msm_total",
  * "extend_total", "prove_total". */
+/* microbenchmark of the MSM kernels' GF(2^233) multiplier alone (products per second, whole chip): the ceiling of
+ * bench.py's work model, measured in the same run */
+int dvp_ubench_gf_mul(int reps, double* products_per_s);
 void dvp_profile_enable(int on);
 void dvp_profile_reset(void);
 int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);

@@ -8,12 +8,17 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libdvp_oracle.so")
+OSSL_PATH = os.path.join(_HERE, "_build", "libdvp_oracle_ossl.so")
 
 
 def build(force=False):
     src = os.path.join(_HERE, "dvp_oracle.c")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libdvp_oracle.so"], stdout=subprocess.DEVNULL)
+    src2 = os.path.join(_HERE, "dvp_oracle_ossl.c")
+    if force or not os.path.exists(OSSL_PATH) or os.path.getmtime(OSSL_PATH) < os.path.getmtime(src2):
+        # the OpenSSL datapoint is optional: a box without libcrypto headers still gets the main oracle
+        subprocess.call(["make", "-C", _HERE, "-B", "_build/libdvp_oracle_ossl.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -36,6 +41,9 @@ def lib():
         _lib.dvo_xsk233_encode.argtypes = [vp, C.c_int, vp]
         _lib.dvo_xsk233_decode.argtypes = [vp, vp, C.POINTER(C.c_int)]
         _lib.dvo_xsk233_decode.restype = C.c_int
+        _lib.dvo_fr_mont_mul.argtypes = [vp, vp, vp]
+        _lib.dvo_fr_butterfly_passes.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+        _lib.dvo_fr_butterfly_passes.restype = C.c_int
         for f in ("dvo_gf_mul",):
             getattr(_lib, f).argtypes = [vp, vp, vp]
         for f in ("dvo_gf_sqr", "dvo_gf_inv"):
@@ -131,3 +139,38 @@ def xsk233_decode(buf: bytes):
     oi = C.c_int(0)
     ok = lib().dvo_xsk233_decode(_p(i), _p(o), C.byref(oi))
     return (_pt_out(o, oi) if ok else None), bool(ok)
+
+
+def fr_mont_mul(a, b):
+    """a * b / 2^256 mod p (the Montgomery product the extend butterflies are made of)"""
+    o = np.zeros(4, dtype=np.uint64)
+    lib().dvo_fr_mont_mul(_p(_limbs(a)), _p(_limbs(b)), _p(o))
+    return _int(o)
+
+
+def fr_butterfly_passes(data: np.ndarray, mats: np.ndarray, passes: int, threads: int = 1):
+    """in place: `passes` extend-shaped butterfly passes over data [n,4] with matrices mats [2, n/2, 4, 4] (Montgomery)"""
+    assert data.flags["C_CONTIGUOUS"] and mats.flags["C_CONTIGUOUS"] and mats.shape[:2] == (2, data.shape[0] // 2)
+    return lib().dvo_fr_butterfly_passes(_p(data), _p(mats), data.shape[0], passes, threads)
+
+
+_ossl = None
+
+
+def openssl_msm(scalars: np.ndarray, bases: np.ndarray, threads: int = 1):
+    """the reference's MSM shape on OpenSSL's sect233k1 (EC_POINT_mul per point + add); None if libcrypto is unavailable"""
+    global _ossl
+    if _ossl is None:
+        build()
+        if not os.path.exists(OSSL_PATH):
+            return NotImplemented
+        _ossl = C.CDLL(OSSL_PATH)
+        _ossl.dvo_openssl_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        _ossl.dvo_openssl_msm.restype = C.c_int
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    b = np.ascontiguousarray(bases, dtype=np.uint64)
+    o = np.zeros(8, dtype=np.uint64)
+    oi = C.c_int(0)
+    if _ossl.dvo_openssl_msm(_p(s), _p(b), s.shape[0], threads, _p(o), C.byref(oi)) != 0:
+        raise RuntimeError("dvo_openssl_msm failed")
+    return _pt_out(o, oi)
