@@ -115,6 +115,28 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_local(const uint32_t* __restr
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
+// the same with the division of k_ntask fused in: v = ceil(in / K) is written to vout and scanned
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_local_div(const uint32_t* __restrict__ in, uint32_t K, uint32_t* __restrict__ vout,
+                                                             uint32_t* __restrict__ out, uint32_t* __restrict__ bsum, uint32_t m) {
+  __shared__ uint32_t sh[SCAN_TPB];
+  uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
+  uint32_t v[SCAN_EPT], s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k) {
+    v[k] = (base + k < m) ? (in[base + k] + K - 1) / K : 0;
+    if (base + k < m) vout[base + k] = v[k];
+    s += v[k];
+  }
+  uint32_t tot;
+  uint32_t ex = block_exclusive_scan(s, &tot, sh);
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k) {
+    if (base + k < m) out[base + k] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
 __global__ void __launch_bounds__(SCAN_TPB) k_scan_bsums(uint32_t* __restrict__ bsum, uint32_t nb, uint32_t* total_out) {
   __shared__ uint32_t sh[SCAN_TPB];
   uint32_t carry = 0;
@@ -141,6 +163,16 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_add(uint32_t* __restrict__ ou
 static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st) {
   uint32_t nb = cdiv(m, SCAN_BLK);
   hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
+  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
+  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+
+// vout[i] = ceil(in[i] / K); out = exclusive scan of vout (out[m] = total): the per-round bookkeeping of the bucket reducers
+static int scan_exclusive_div(const uint32_t* in, uint32_t K, uint32_t* vout, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st) {
+  uint32_t nb = cdiv(m, SCAN_BLK);
+  hipLaunchKernelGGL(k_scan_local_div, dim3(nb), dim3(SCAN_TPB), 0, st, in, K, vout, out, bsum, m);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
   hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
   DVP_HIP(hipGetLastError());
@@ -897,6 +929,18 @@ struct MsmWorkspace {
   void* p = nullptr;
   size_t bytes = 0;
   int device = -1;
+  // side channel for the one number the host needs mid-MSM (largest bucket): pinned word + its own stream, so the copy
+  // overtakes the first pair round that is already enqueued on the caller's stream
+  hipStream_t aux = nullptr;
+  hipEvent_t ev = nullptr;
+  uint32_t* pinned = nullptr;
+  int ensure_aux() {
+    if (aux) return DVP_OK;
+    DVP_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    DVP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    DVP_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
+    return DVP_OK;
+  }
   int ensure(size_t need) {
     int dev;
     DVP_HIP(hipGetDevice(&dev));
@@ -1147,14 +1191,12 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t* d_max = (uint32_t*)(err + 1);
   DVP_HIP(hipMemsetAsync(d_max, 0, 4, st));
   hipLaunchKernelGGL(k_max_u32, dim3(64), dim3(256), 0, st, cnt, nk, d_max);
-  uint32_t max_cnt = 0;
-  DVP_HIP(hipMemcpyAsync(&max_cnt, d_max, 4, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipStreamSynchronize(st));
+  DVP_TRY(g_ws.ensure_aux());
+  DVP_HIP(hipEventRecord(g_ws.ev, st));
+  DVP_HIP(hipStreamWaitEvent(g_ws.aux, g_ws.ev, 0));
+  DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
   const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
   const size_t e_est = (size_t)n * (size_t)((234 + p.c - 1) / p.c);  // the overflow windows are empty in practice
-  int ra = 0;
-  if (affine_mode)
-    while (((uint64_t)1 << ra) < max_cnt && (e_est >> (ra + 1)) >= aff_min) ++ra;
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -1163,44 +1205,56 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t cap = p.e_max;
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
-  if (ra > 0) {
-    // resident threads of k_affine_round on this device (3 blocks of 256 per CU on MI355X: 196 608)
-    int dev = 0, n_cu = 256, blk_per_cu = 3;
-    DVP_HIP(hipGetDevice(&dev));
-    DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round, EC_TPB, EC_LDS));
-    if (blk_per_cu < 1) blk_per_cu = 1;
-    const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
-    const uint32_t aff_bmax = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
-    for (int r = 0; r < ra; ++r) {
-      int nxt = (cur + 1) % 3;
-      hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, 2u);
-      DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
-      size_t out_max = cap / 2 + nk + 1;
-      Aff* outp = (r & 1) ? affB : affA;
-      // descriptors: lanes per bucket by the average bucket size of this round
-      const size_t per_key = (e_est >> (r + 1)) / nk;
+  // resident threads of k_affine_round on this device (3 blocks of 256 per CU on MI355X: 196 608)
+  int n_cu = 256, blk_per_cu = 3;
+  DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cur_dev));
+  DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round, EC_TPB, EC_LDS));
+  if (blk_per_cu < 1) blk_per_cu = 1;
+  const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
+  const uint32_t aff_bmax = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
+  auto launch_round = [&](int r) -> int {
+    int nxt = (cur + 1) % 3;
+    DVP_TRY(scan_exclusive_div(pc[cur], 2u, pc[nxt], po[nxt], nk, bsum, st));
+    size_t out_max = cap / 2 + nk + 1;
+    Aff* outp = (r & 1) ? affB : affA;
+    // descriptors: lanes per bucket by the average bucket size of this round
+    const size_t per_key = (e_est >> (r + 1)) / nk;
 #define DVP_DESC_LAUNCH(FIRST, LPK) \
   hipLaunchKernelGGL((k_round_desc<FIRST, LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, items, pc[cur], po[cur], po[nxt], nk, gdesc)
 #define DVP_DESC_PICK(FIRST) \
   do { if (per_key >= 48) DVP_DESC_LAUNCH(FIRST, 64); else if (per_key >= 8) DVP_DESC_LAUNCH(FIRST, 16); else DVP_DESC_LAUNCH(FIRST, 4); } while (0)
-      if (r == 0) DVP_DESC_PICK(true); else DVP_DESC_PICK(false);
+    if (r == 0) DVP_DESC_PICK(true); else DVP_DESC_PICK(false);
 #undef DVP_DESC_PICK
 #undef DVP_DESC_LAUNCH
-      // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
-      const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax);
-      const uint32_t grid = r_max * (aff_cap / EC_TPB) + 1;
-      const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
-      {
-        ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
-        hipLaunchKernelGGL(k_affine_round, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
-        ps0.stop();
-      }
-      pts_in = outp;
-      cap = out_max;
-      cur = nxt;
+    // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
+    const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax);
+    const uint32_t grid = r_max * (aff_cap / EC_TPB) + 1;
+    const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
+    {
+      ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
+      hipLaunchKernelGGL(k_affine_round, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
+      ps0.stop();
     }
+    pts_in = outp;
+    cap = out_max;
+    cur = nxt;
+    return DVP_OK;
+  };
+  // The number of rounds depends on the largest bucket, which only the device knows.  When the average bucket already
+  // holds >= 4 entries the first round is certain to be needed, so it is enqueued BEFORE the host waits for that number:
+  // the round trip (and the launch ramp after it) hides behind ~5 ms of round 0 instead of idling the GPU mid-MSM.
+  int launched = 0;
+  if (affine_mode && (e_est >> 1) >= aff_min && e_est >= 4 * (size_t)nk) {
+    DVP_TRY(launch_round(0));
+    launched = 1;
   }
+  DVP_HIP(hipStreamSynchronize(g_ws.aux));  // the caller's stream keeps running round 0 meanwhile
+  const uint32_t max_cnt = *g_ws.pinned;
+  int ra = 0;
+  if (affine_mode)
+    while (((uint64_t)1 << ra) < max_cnt && (e_est >> (ra + 1)) >= aff_min) ++ra;
+  if (ra < launched) ra = launched;  // a first round over single-entry buckets only passes them through
+  for (int r = launched; r < ra; ++r) DVP_TRY(launch_round(r));
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
   if (rem_max <= 1) {
     if (ra == 0)
@@ -1210,8 +1264,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   } else {
     // level 1: mixed additions from affine inputs
     int nxt = (cur + 1) % 3;
-    hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, p.K);
-    DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
+    DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
     if (ra == 0) {
       ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // small inputs: no pair rounds, this is the dominant kernel
@@ -1224,8 +1277,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     Ld *in = bufA, *outb = bufB;
     for (uint64_t left = (rem_max + p.K - 1) / p.K; left > 1; left = (left + p.K - 1) / p.K) {
       nxt = (cur + 1) % 3;
-      hipLaunchKernelGGL(k_ntask, dim3(cdiv(nk, 256)), dim3(256), 0, st, pc[cur], pc[nxt], nk, p.K);
-      DVP_TRY(scan_exclusive(pc[nxt], po[nxt], nk, bsum, st));
+      DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
       tmax = cap / p.K + nk + 1;
       hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
       cap = tmax;
