@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turns gpurun_out/refresh/ (tools/refresh_profiles.sh) into the committed summaries under profiles/.
 usage: python tools/digest_profiles.py rNN"""
+import collections
 import csv
 import glob
 import json
@@ -11,8 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-KERNEL = "k_affine_round<true"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
 def one(pattern):
@@ -30,40 +30,83 @@ shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench_pro
 shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_prove2p20_under_rocprof.json"))
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))
 shutil.copy(one("msm/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_msm_kernel_stats.csv"))
+shutil.copy(os.path.join(SRC, "msm_bench.log"), os.path.join(DST, f"{tag}_msm_bench.log"))
 
 
-def pmc(dirname, counter):
+def round0_dispatches(dirname):
+    """per dispatch {counter: value, ms}: the k_affine_round launches that directly follow a k_round_desc<true, ..> launch,
+    i.e. the FIRST pair round of each MSM (the dominant kernel; later rounds run the same code on compacted inputs)"""
     rows = list(csv.DictReader(open(one(f"{dirname}/**/*counter_collection.csv"))))
-    vals, durs = [], []
+    disp = collections.OrderedDict()
     for r in rows:
-        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            vals.append(float(r["Counter_Value"]))
-            if "Start_Timestamp" in r and r.get("End_Timestamp"):
-                durs.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    return vals, durs
+        d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+    ids = sorted(disp)
+    out = []
+    for a, b in zip(ids, ids[1:]):
+        if "k_round_desc<true" in disp[a]["name"] and "k_affine_round" in disp[b]["name"]:
+            out.append(disp[b])
+    assert out, dirname
+    return out
 
 
-fetch, d1 = pmc("pmc_fetch", "FETCH_SIZE")
-write, d2 = pmc("pmc_write", "WRITE_SIZE")
-assert fetch and write and len(fetch) == len(write), (len(fetch), len(write))
-avg_f, avg_w = sum(fetch) / len(fetch), sum(write) / len(write)
-out = {
-    "kernel": "dvp::k_affine_round<true, B> (B = 32 additions per inversion in these launches, 16 in small rounds)",
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-    "launches": len(fetch),
-    "avg_FETCH_SIZE_KB": avg_f,
-    "avg_WRITE_SIZE_KB": avg_w,
-    "avg_duration_ms_under_pmc": (sum(d1) / len(d1)) if d1 else None,
-    "calibration": "expected per launch (average of the 2m- and 4m-point MSMs, ~20M pair additions): two 64-B bases gathered in pass 1 "
-                   "and again in pass 2, 8 B of indices, 32 B prefix written + read, 64 B output; the counters are taken as-is (no x2: "
-                   "MI355X_MICROARCH.md's half-counting was measured on wide coalesced streams, these are 64-B gathers, and the un-doubled "
-                   "value already matches the expected byte count); Infinity-Cache hits of the pass-2 re-reads are included by the counter",
-    "traffic_bytes_per_launch": (avg_f + avg_w) * 1024.0,
-}
-json.dump(out, open(os.path.join(DST, f"{tag}_pmc_traffic_k_affine_round0.json"), "w"), indent=1)
+def avg(ds, key):
+    return sum(d[key] for d in ds) / len(ds)
+
+
+fetch = round0_dispatches("pmc_fetch")
+write = round0_dispatches("pmc_write")
 b = last_json_line(os.path.join(SRC, "bench.json"))
-print("bench:", b["value"], "constraints/s", b["ms_per_step"], "ms; roofline", b["roofline"]["avg_launch_ms"], "ms/launch, work_model frac",
+alg = b["roofline"]["algorithmic_bytes_per_launch"]
+f_kb, w_kb = avg(fetch, "FETCH_SIZE"), avg(write, "WRITE_SIZE")
+traffic = {
+    "kernel": "dvp::k_affine_round, first pair round of each MSM (the launches that follow k_round_desc<true, ..>)",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, counters + --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "launches": len(fetch),
+    "avg_FETCH_SIZE_KB": f_kb,
+    "avg_WRITE_SIZE_KB": w_kb,
+    "avg_duration_ms_under_pmc": avg(fetch, "ms"),
+    "traffic_bytes_per_launch_raw": (f_kb + w_kb) * 1024.0,
+    "traffic_bytes_per_launch_fetch_x2": (2 * f_kb + w_kb) * 1024.0,
+    "algorithmic_bytes_per_launch": alg,
+    "conventions": "raw = FETCH_SIZE + WRITE_SIZE as reported; fetch_x2 = 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of "
+                   "MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at 64 B; measured there on wide coalesced streams -- this kernel's "
+                   "reads are 64-B gathers of the bases plus coalesced descriptor / prefix streams, so the true figure lies between the two). "
+                   "Expected per pair addition: two 64-B bases gathered in pass 1 and again in pass 2 (HBM or Infinity-Cache hits, which the "
+                   "counter includes), 8 B descriptor x 2, 32 B prefix product written + read, 64 B output = ~400 B, against 96 B x 2/W "
+                   "algorithmic bytes: the gathers are the price of sharing one inversion among ~36 additions.",
+}
+json.dump(traffic, open(os.path.join(DST, f"{tag}_pmc_traffic_k_affine_round0.json"), "w"), indent=1)
+
+sq = round0_dispatches("pmc_sq")
+n_cu, n_simd = 256, 1024
+cyc = avg(sq, "GRBM_GUI_ACTIVE") / 8.0  # the counter sums the 8 XCDs
+valu, lds = avg(sq, "SQ_INSTS_VALU"), avg(sq, "SQ_INSTS_LDS")
+issue = {
+    "kernel": traffic["kernel"],
+    "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace "
+              "-- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (averages over the first-round launches)",
+    "launches": len(sq),
+    "avg_duration_ms_under_pmc": avg(sq, "ms"),
+    "counters_per_launch": {k: avg(sq, k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE")},
+    "shader_cycles_per_launch": cyc,
+    "effective_clock_ghz": cyc / (avg(sq, "ms") * 1e-3) / 1e9,
+    "valu_insts_per_simd_cycle": valu / n_simd / cyc,
+    "valu_issue_ceiling_insts_per_simd_cycle": "0.5 for full-rate ops (xor/and/bitop3: 2 cycles per wave64 on a SIMD-32), 0.25 for the half-rate ones "
+                                                "(shifts, v_alignbit: ~45 % of the multiplier's instructions) -> ~0.31 for this mix",
+    "valu_issue_frac_of_mix_ceiling": (valu / n_simd / cyc) / 0.31,
+    "lds_busy_frac": lds * 5.34 / n_cu / cyc,
+    "lds_busy_note": "SQ_INSTS_LDS x 5.34 LDS cycles per wave-instruction (per product: 120 ds_read_b128 x 4 + 21 ds_write_b128 x 13 cycles over 141 "
+                     "instructions, MI355X_MICROARCH.md LDS table) / (256 CUs x shader cycles)",
+    "resident_wave_frac": avg(sq, "SQ_WAVE_CYCLES") * 4.0 / (cyc * n_cu * 12),
+    "resident_wave_note": "SQ_WAVE_CYCLES (quad-cycles) x 4 / (shader cycles x 256 CUs x 12 waves per CU)",
+    "valu_insts_per_pair_addition": valu * 64.0 / b["roofline"]["work_model"]["additions_per_launch"],
+}
+json.dump(issue, open(os.path.join(DST, f"{tag}_pmc_sq_k_affine_round0.json"), "w"), indent=1)
+print("bench:", b["value"], "constraints/s", b["ms_per_step"], "ms; round0", b["roofline"]["avg_launch_ms"], "ms/launch; work_model frac",
       b["roofline"]["work_model"]["frac"])
-print("traffic per launch: %.3f GB" % (out["traffic_bytes_per_launch"] / 1e9))
-for r in list(csv.DictReader(open(os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))))[:6]:
-    print(r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e6, "ms avg")
+print("traffic per launch: raw %.3f GB, fetch x2 %.3f GB, algorithmic %.3f GB" % (traffic["traffic_bytes_per_launch_raw"] / 1e9,
+                                                                              traffic["traffic_bytes_per_launch_fetch_x2"] / 1e9, alg / 1e9))
+print("issue:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in issue.items() if k.endswith("frac") or k.endswith("cycle") or k.endswith("ghz") or k.endswith("ceiling")})
+for r in list(csv.DictReader(open(os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))))[:8]:
+    print(r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, "ms avg")

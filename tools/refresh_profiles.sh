@@ -1,13 +1,14 @@
 #!/bin/bash
-# Runs ON THE MI355X BOX (gpurun -- 'bash tools/refresh_profiles.sh'): un-profiled bench line, the same command under
-# rocprofv3 --kernel-trace --stats, and the two separate PMC passes (FETCH_SIZE, WRITE_SIZE) for roofline.traffic.
-# Everything lands in gpurun_out/refresh/; tools/digest_profiles.py then writes the summaries into profiles/.
+# Runs ON THE MI355X BOX (gpurun -- 'bash tools/refresh_profiles.sh'): the un-profiled bench line, the same command under
+# rocprofv3 --kernel-trace --stats, and three separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ issue counters -- counters
+# only, with --kernel-trace, as the pool requires).  Everything lands in gpurun_out/refresh/; tools/digest_profiles.py
+# then writes the summaries into profiles/.
 set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/refresh
 rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
-timeout -k 10 600 python3 bench.py --steps 5 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 600 python3 bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
@@ -16,6 +17,8 @@ timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o
 echo "pmc fetch done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write done"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 20 > $OUT/msm_bench.log 2>&1
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o q --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+echo "pmc sq done"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 20 22 > $OUT/msm_bench.log 2>&1
 echo "msm stats done"
 ls -R $OUT | head -40
