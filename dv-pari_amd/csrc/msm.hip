@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_local(const uint32_t* __restr
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-// the same with the division of k_ntask fused in: v = ceil(in / K) is written to vout and scanned
+// the same with a division fused in: v = ceil(in / K) (outputs per bucket of a pair round, tasks per bucket of the
+// fan-in-K reducer) is written to vout and scanned
 __global__ void __launch_bounds__(SCAN_TPB) k_scan_local_div(const uint32_t* __restrict__ in, uint32_t K, uint32_t* __restrict__ vout,
                                                              uint32_t* __restrict__ out, uint32_t* __restrict__ bsum, uint32_t m) {
   __shared__ uint32_t sh[SCAN_TPB];
@@ -528,11 +529,6 @@ constexpr unsigned EC_LDS_Q = (EC_TPB / 64) * GF_LDS_BYTES_PER_WAVE;
 constexpr uint32_t MERGE_QUAD_MAX = 16384;  // additions per level up to which 4 lanes per addition win (measured: 35 us vs 41 us at 16384)
 
 // ---- segmented reduction by fan-in K ----------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_ntask(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ ntask, uint32_t nkeys, uint32_t K) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < nkeys) ntask[k] = (cnt[k] + K - 1) / K;
-}
-
 // largest key with toff[key] <= tid (toff has nkeys+1 entries, toff[nkeys] = total > tid)
 __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t tid) {
   uint32_t lo = 0, hi = nkeys;  // invariant: toff[lo] <= tid < toff[hi]

@@ -82,11 +82,25 @@ __device__ __forceinline__ void kh_row(u32* acc, const u32* a, const GfLdsH& c, 
     acc[5] ^= v[2].w;
   }
 }
+#ifdef SHL64
+// 64-bit form: (pair << 3) + carry -- v_lshl_add_u64 (one half-rate op per TWO words) + a full-rate v_lshrrev for the carry
+__device__ __forceinline__ void kh_shl3(u32* acc) {
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    uint64_t p = ((uint64_t)acc[2 * i + 1] << 32) | acc[2 * i];
+    uint64_t c = i ? (uint64_t)(acc[2 * i - 1] >> 29) : 0;
+    p = (p << 3) + c;
+    acc[2 * i] = (u32)p;
+    acc[2 * i + 1] = (u32)(p >> 32);
+  }
+}
+#else
 __device__ __forceinline__ void kh_shl3(u32* acc) {
 #pragma unroll
   for (int i = 7; i > 0; --i) acc[i] = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], 29);
   acc[0] <<= 3;
 }
+#endif
 // acc[0..7] = a (4 words, word 3 < 2^21) * table operand
 __device__ __forceinline__ void kh_mul_tab(u32* acc, const u32* a, const GfLdsH& c) {
 #pragma unroll
