@@ -57,7 +57,8 @@ def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
     mb = fr.spmv(*_t(inst.r, inst.n_wires), inst.coeffs, lt_rows)
     mc = fr.spmv(*_t(inst.o, inst.n_wires), inst.coeffs, lt_rows)
     m_vals = fr.axpy(fr.axpy(mv, td.delta, mb), delta2, mc)  # whole vectors on the GPU: n_wires is 2^23 for the SP1 circuit
-    pw = fr.vec([1] * m)
+    pw = np.zeros((m, 4), dtype=np.uint64)  # d_i^0
+    pw[:, 0] = 1
     for j in range(inst.num_public_inputs):  # -d_i^j on wire 1+j of every row (src/gnark_r1cs.rs:333-386)
         m_vals[1 + j] = fr.limbs((fr.to_int(m_vals[1 + j]) - delta2 * fr.dot(pw, l_tau)) % P)
         pw = fr.mul(pw, d)
