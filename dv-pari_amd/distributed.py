@@ -29,7 +29,9 @@ def shard_plan(world: int, n_wires: int, m: int, extend_pairs: float = None):
     s minimises the larger load.  s == world (uniform slices, every rank extends) is what small worlds get."""
     ta, tb = n_wires + m, 4 * m
     cap_a, cap_b = n_wires, 2 * m
-    e = 0.3 * m if extend_pairs is None else extend_pairs  # measured on MI355X: three extends of 2^20 ~ 0.3 M pairs of sharded MSM
+    # measured on MI355X (round 2, tools/shard_profile.py): R1CS evaluation + three extends + quotient of 2^20 = 1.58 ms, the time
+    # the sharded MSMs take for ~0.42 * 2^20 (scalar, base) pairs
+    e = 0.42 * m if extend_pairs is None else extend_pairs
     best = None
     for s in range(world, 0, -1):
         if s == world:

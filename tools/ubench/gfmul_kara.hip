@@ -101,6 +101,45 @@ __device__ __forceinline__ void kh_shl3(u32* acc) {
   acc[0] <<= 3;
 }
 #endif
+#ifdef PIPE
+// software-pipelined rows: the four lookups of row k-1 are issued before the xors of row k (addresses depend only on a)
+__device__ __forceinline__ void kh_issue(gf_u32x4* v, const u32* a, const GfLdsH& c, int k) {
+  const int rsh = 3 * k - 10 > 0 ? 3 * k - 10 : 0, lsh = 10 - 3 * k > 0 ? 10 - 3 * k : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    u32 sh = (a[j] >> rsh) << lsh;
+    v[j] = lds_ld(__builtin_amdgcn_bitop3_b32(sh, 0x1C00u, c.lane_base, 0xEA));   // a[3] has no digits k >= 7: row 0 (zeros)
+  }
+}
+__device__ __forceinline__ void kh_consume(u32* acc, const gf_u32x4* v) {
+  acc[0] ^= v[0].x;
+  acc[1] = x3(acc[1], v[0].y, v[1].x);
+  acc[2] = x3(acc[2], v[0].z, v[1].y) ^ v[2].x;
+  acc[3] = x3(x3(acc[3], v[0].w, v[1].z), v[2].y, v[3].x);
+  acc[4] = x3(acc[4], v[1].w, v[2].z) ^ v[3].y;
+  acc[5] = x3(acc[5], v[2].w, v[3].z);
+  acc[6] ^= v[3].w;
+}
+__device__ __forceinline__ void kh_mul_tab(u32* acc, const u32* a, const GfLdsH& c) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0;
+  gf_u32x4 p[4], q[4];
+  kh_issue(p, a, c, 10);
+#pragma unroll 1
+  for (int k = 10; k >= 2; k -= 2) {   // rows k (in p) and k-1 (in q)
+    kh_issue(q, a, c, k - 1);
+    asm volatile("" ::: "memory");
+    if (k != 10) kh_shl3(acc);
+    kh_consume(acc, p);
+    kh_issue(p, a, c, k - 2);
+    asm volatile("" ::: "memory");
+    kh_shl3(acc);
+    kh_consume(acc, q);
+  }
+  kh_shl3(acc);
+  kh_consume(acc, p);  // row 0
+}
+#else
 // acc[0..7] = a (4 words, word 3 < 2^21) * table operand
 __device__ __forceinline__ void kh_mul_tab(u32* acc, const u32* a, const GfLdsH& c) {
 #pragma unroll
@@ -124,6 +163,7 @@ __device__ __forceinline__ void kh_mul_tab(u32* acc, const u32* a, const GfLdsH&
     kh_row<4>(acc, a, c, 0, 10 - 3 * k);
   }
 }
+#endif
 // x = lo + hi z^117
 __device__ __forceinline__ void kh_split(const Gf& x, u32* lo, u32* hi) {
   lo[0] = x.w[0]; lo[1] = x.w[1]; lo[2] = x.w[2]; lo[3] = x.w[3] & 0x1FFFFFu;
