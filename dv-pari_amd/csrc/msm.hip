@@ -874,8 +874,8 @@ __global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSq
 
 // sum of n affine points (the partial MSM results of n GPUs or ranks) -> affine: one quad of lanes, n - 1 mixed
 // additions + one inversion, all through the quad-cooperative multiplier (~15 us per point + ~50 us)
-__global__ void __launch_bounds__(64) k_sum_points(const Aff* __restrict__ pts, const uint32_t* __restrict__ inf, uint32_t n, uint32_t inf_stride,
-                                                  GfSqrTables T, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
+__global__ void __launch_bounds__(64) k_sum_points(const char* __restrict__ pts, uint32_t pt_stride_bytes, const uint32_t* __restrict__ inf, uint32_t n,
+                                                  uint32_t inf_stride, GfSqrTables T, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
   extern __shared__ char lds_raw[];
   GfLdsQ L = gf_ldsq_init(lds_raw);
   if (threadIdx.x >= 4 || blockIdx.x != 0) return;
@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(64) k_sum_points(const Aff* __restrict__ pts, 
 #pragma unroll 1
   for (uint32_t i = 0; i < n; ++i) {
     if (inf[(size_t)i * inf_stride]) continue;
-    Aff q = pts[i];
+    Aff q = *(const Aff*)(pts + (size_t)i * pt_stride_bytes);
     ld_madd_ip(acc, q, L);
   }
   Aff a;
@@ -1317,12 +1317,13 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   return DVP_OK;
 }
 
-// d_pts: n affine points (64 B each), d_inf32: n flags (u32, `inf_stride` words apart) -> their sum
-int msm_sum_points_dev(const void* d_pts, const void* d_inf32, uint32_t n, uint32_t inf_stride, void* d_out_xy, void* d_out_inf, hipStream_t st) {
+// d_pts: n affine points `pt_stride_bytes` apart (>= 64, a multiple of 16), d_inf32: n flags (u32, `inf_stride` words apart) -> their sum
+int msm_sum_points_dev(const void* d_pts, uint32_t pt_stride_bytes, const void* d_inf32, uint32_t n, uint32_t inf_stride, void* d_out_xy,
+                       void* d_out_inf, hipStream_t st) {
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
-  hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, (const Aff*)d_pts, (const uint32_t*)d_inf32, n, inf_stride, Tsq,
-                     (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  hipLaunchKernelGGL(k_sum_points, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, (const char*)d_pts, pt_stride_bytes, (const uint32_t*)d_inf32, n,
+                     inf_stride, Tsq, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
@@ -1399,45 +1400,8 @@ extern "C" int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy,
 // all-gathers (dv-pari_amd/distributed.py) and the one the in-library device threads hand back
 extern "C" int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out_xy, void* d_out_inf, void* stream) {
   if (!d_records || !n || !d_out_xy || !d_out_inf) return DVP_EINVAL;
-  // records are 80 B apart but Aff is 64 B: gather into a packed array first (n <= a few dozen)
-  hipStream_t st = (hipStream_t)stream;
-  DevBuf pk;
-  DVP_TRY(pk.alloc((size_t)n * 68));
-  DVP_HIP(hipMemcpy2DAsync(pk.p, 64, d_records, 80, 64, n, hipMemcpyDeviceToDevice, st));
-  DVP_HIP(hipMemcpy2DAsync((char*)pk.p + (size_t)n * 64, 4, (const char*)d_records + 64, 80, 4, n, hipMemcpyDeviceToDevice, st));
-  DVP_TRY(msm_sum_points_dev(pk.p, (char*)pk.p + (size_t)n * 64, n, 1, d_out_xy, d_out_inf, st));
-  DVP_HIP(hipStreamSynchronize(st));  // pk is released on return
-  return DVP_OK;
-}
-
-// GF(2^233) products per second of the hot kernels' multiplier alone (every CU busy, k_affine_round's occupancy): the
-// ceiling bench.py's work model divides by, measured in the same process instead of quoted
-extern "C" int dvp_ubench_gf_mul(int reps, double* products_per_s) {
-  if (reps < 1 || !products_per_s) return DVP_EINVAL;
-  int dev = 0, n_cu = 256;
-  DVP_HIP(hipGetDevice(&dev));
-  DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  const int blocks = n_cu * 3 * 8;  // eight chip-fulls of 3 blocks per CU
-  DevBuf out;
-  DVP_TRY(out.alloc((size_t)blocks * EC_TPB * sizeof(Gf)));
-  hipEvent_t e0, e1;
-  DVP_HIP(hipEventCreate(&e0));
-  DVP_HIP(hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int it = 0; it < 3; ++it) {
-    DVP_HIP(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_ubench_mul, dim3(blocks), dim3(EC_TPB), EC_LDS, 0, out.as<Gf>(), reps);
-    DVP_HIP(hipEventRecord(e1, 0));
-    DVP_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    DVP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    if (ms < best) best = ms;
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  DVP_HIP(hipGetLastError());
-  *products_per_s = (double)blocks * EC_TPB * reps / (best * 1e-3);
-  return DVP_OK;
+  // the kernel walks the 80-byte records in place (point at +0, flag at +64): no staging buffer, nothing to wait for
+  return msm_sum_points_dev(d_records, 80, (const char*)d_records + 64, n, 20, d_out_xy, d_out_inf, (hipStream_t)stream);
 }
 
 extern "C" int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n,

@@ -40,7 +40,8 @@ int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out,
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
 struct MsmFixedCtx;
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out);
-int msm_sum_points_dev(const void* d_pts, const void* d_inf32, uint32_t n, uint32_t inf_stride, void* d_out_xy, void* d_out_inf, hipStream_t st);
+int msm_sum_points_dev(const void* d_pts, uint32_t pt_stride_bytes, const void* d_inf32, uint32_t n, uint32_t inf_stride, void* d_out_xy,
+                       void* d_out_inf, hipStream_t st);
 void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
@@ -754,7 +755,7 @@ static int mgpu_msm(dvp_prover* p, int which, void* d_out_xy, void* d_out_inf, h
     pk[16 * n + k] = recs[k].inf;
   }
   DVP_HIP(hipMemcpyAsync(p->mg_parts, pk.data(), n * 68, hipMemcpyHostToDevice, home_st));
-  DVP_TRY(msm_sum_points_dev(p->mg_parts, p->mg_parts + 16 * n, (uint32_t)n, 1, d_out_xy, d_out_inf, home_st));
+  DVP_TRY(msm_sum_points_dev(p->mg_parts, 64, p->mg_parts + 16 * n, (uint32_t)n, 1, d_out_xy, d_out_inf, home_st));
   DVP_HIP(hipStreamSynchronize(home_st));  // pk goes out of scope
   return DVP_OK;
 }
