@@ -107,6 +107,28 @@ class GpuBackend:
         return self.prover.finish(point.data_ptr(), point.data_ptr() + 64, self.torch.cuda.current_stream().cuda_stream)
 
 
+_GATHER_INTO_TENSOR = True  # flips to False the first time the backend refuses all_gather_into_tensor
+
+
+def _all_gather_records(part, world, group):
+    """[world, 10] tensor of every rank's 80-byte record: ONE collective into one preallocated-shape tensor where the
+    backend has all_gather_into_tensor (RCCL does), the list form + stack otherwise"""
+    global _GATHER_INTO_TENSOR
+    import torch
+    import torch.distributed as dist
+
+    if _GATHER_INTO_TENSOR:
+        out = torch.empty((world,) + tuple(part.shape), dtype=part.dtype, device=part.device)
+        try:
+            dist.all_gather_into_tensor(out, part, group=group)
+            return out
+        except (RuntimeError, NotImplementedError):
+            _GATHER_INTO_TENSOR = False
+    gathered = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(gathered, part, group=group)
+    return torch.stack(gathered)
+
+
 def prove_sharded(backend, assignment, group=None):
     """Proof::prove (src/proving.rs:426-688) with both MSMs sharded over the ranks of `group`.
     Every rank returns the same proof."""
@@ -124,9 +146,7 @@ def prove_sharded(backend, assignment, group=None):
         lo, hi = range_a if which == 0 else range_b
         part = backend.msm_partial(which, lo, hi)
         if world > 1:
-            gathered = [torch.empty_like(part) for _ in range(world)]
-            dist.all_gather(gathered, part, group=group)
-            point = backend.combine(torch.stack(gathered))
+            point = backend.combine(_all_gather_records(part, world, group))
         else:
             point = part
         if which == 0:
