@@ -102,6 +102,25 @@ issue = {
     "resident_wave_note": "SQ_WAVE_CYCLES (quad-cycles) x 4 / (shader cycles x 256 CUs x 12 waves per CU)",
     "valu_insts_per_pair_addition": valu * 64.0 / b["roofline"]["work_model"]["additions_per_launch"],
 }
+# the multiplier microbenchmark (k_ubench_mul, run by bench.py outside its timed loop) under the same counters: the rate
+# bench.py's work model divides by is measured at a HIGHER clock than the pair rounds hold (no HBM traffic, less power)
+rows = list(csv.DictReader(open(one("pmc_sq/**/*counter_collection.csv"))))
+ub = collections.defaultdict(dict)
+for r in rows:
+    if "k_ubench_mul" in r["Kernel_Name"]:
+        ub[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        ub[r["Dispatch_Id"]]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+if ub:
+    u = list(ub.values())
+    ucyc = avg(u, "GRBM_GUI_ACTIVE") / 8.0
+    issue["multiplier_microbenchmark_same_counters"] = {
+        "effective_clock_ghz": ucyc / (avg(u, "ms") * 1e-3) / 1e9,
+        "valu_insts_per_simd_cycle": avg(u, "SQ_INSTS_VALU") / n_simd / ucyc,
+        "resident_wave_frac": avg(u, "SQ_WAVE_CYCLES") * 4.0 / (ucyc * n_cu * 12),
+        "reading": "per CYCLE the pair round issues valu_insts_per_simd_cycle / this figure of the microbenchmark's VALU rate, and most of that "
+                   "difference is the resident-wave fraction; the rest of the gap between the kernel's product rate and the microbenchmark's is "
+                   "the CLOCK: the chip holds a lower clock in the pair rounds (VALU + LDS + 2-4 TB/s of HBM gathers) than in the microbenchmark",
+    }
 json.dump(issue, open(os.path.join(DST, f"{tag}_pmc_sq_k_affine_round0.json"), "w"), indent=1)
 print("bench:", b["value"], "constraints/s", b["ms_per_step"], "ms; round0", b["roofline"]["avg_launch_ms"], "ms/launch; work_model frac",
       b["roofline"]["work_model"]["frac"])
