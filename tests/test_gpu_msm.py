@@ -246,3 +246,36 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
                 assert np_to_pt(xy, is_inf) == exp, (c, lo, hi)
                 assert gpu_msm(dvp, s[lo:hi], bases[lo:hi]) == exp, (c, lo, hi)
             fb.close()
+
+
+def test_one_shot_randomised_shapes_and_knobs(dvp):
+    """differential sweep of the ONE-SHOT path (per-window bucket sets): random sizes 1..40 000, scalar populations
+    (uniform / tiny / few distinct values / zeros and p-1 mixed in), neutral bases, every window size the cost model can
+    pick (4..15), several reducer fan-ins, pair rounds all the way down and switched off -- each against the
+    discrete-log identity with the OpenSSL-pinned oracle"""
+    rnd = random.Random(4242)
+    nmax = 40000
+    k = rand_fr_np(nmax, 191)
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
+    ks = from_limbs(k)
+    for trial in range(28):
+        n = rnd.choice([1, 2, 3, 63, 64, 65, 1000, 4097, rnd.randrange(1, nmax)])
+        lo = rnd.randrange(0, nmax - n + 1)
+        kind = trial % 4
+        if kind == 0:
+            sv = [rnd.randrange(o.P) for _ in range(n)]
+        elif kind == 1:
+            sv = [rnd.randrange(0, 16) for _ in range(n)]
+        elif kind == 2:
+            vals = [rnd.randrange(o.P) for _ in range(3)]
+            sv = [rnd.choice(vals) for _ in range(n)]
+        else:
+            sv = [rnd.choice([0, o.P - 1, 1, rnd.randrange(o.P)]) for _ in range(n)]
+        inf = np.zeros(n, dtype=np.uint8)
+        if n > 4 and trial % 3 == 0:
+            inf[rnd.randrange(n)] = 1
+        exp = co.k233_mulgen(sum(s * ks[lo + i] for i, s in enumerate(sv) if not inf[i]) % o.P)
+        knobs = dict(DVP_MSM_C=rnd.choice([0, 4, 7, 11, 15]), DVP_MSM_K=rnd.choice([0, 2, 5, 64]),
+                     DVP_MSM_AFF_MIN=rnd.choice([1, 64, 1 << 19]), DVP_MSM_PROJ=int(trial % 7 == 6), DVP_MSM_AFF_BMAX=rnd.choice([1, 5, 48]))
+        with dvp.tune(**knobs):
+            assert gpu_msm(dvp, to_limbs(sv), bases[lo:lo + n], inf) == exp, (trial, n, knobs)
