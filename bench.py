@@ -331,6 +331,11 @@ def main():
         ext_s_per_proof = 4 * (2 * log_m) * (m * 2) * ns_per_frmul * 1e-9 / cores
         msm_s_per_proof = (inst.n_wires + 5 * m) / pts_per_s
         cpu_s = msm_s_per_proof + ext_s_per_proof
+        # "best CPU" (BASELINE.md B3): a host-side bucket method on the same cores
+        n_p = int(min(cap, max(1 << 16, 4 * n_s)))
+        t1 = time.perf_counter()
+        co.msm_pippenger(sc[:n_p], bases[:n_p], threads=cores)
+        pip_pts_per_s = n_p / (time.perf_counter() - t1)
         ossl = None
         try:
             n_o = max(64 * cores, 256)
@@ -355,6 +360,9 @@ def main():
             "msm_points_per_s": pts_per_s,
             "msm_us_core_per_point": us_core,
             "extend_s_per_proof": ext_s_per_proof,
+            "best_cpu_pippenger_points_per_s": pip_pts_per_s,
+            "best_cpu_pippenger_constraints_per_s": m / ((inst.n_wires + 5 * m) / pip_pts_per_s + ext_s_per_proof),
+            "best_cpu_note": f"host bucket method (tau-adic windows, per-thread bucket sets, oracle/dvp_oracle.c: dvo_msm_pippenger) on {n_p} points",
             "openssl_ec_point_mul_points_per_s": ossl,
             "openssl_note": "OpenSSL 3 EC_POINT_mul on sect233k1, one per point + EC_POINT_add (the reference's MSM shape on a third-party library)",
         }

@@ -1404,6 +1404,36 @@ extern "C" int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out
   return msm_sum_points_dev(d_records, 80, (const char*)d_records + 64, n, 20, d_out_xy, d_out_inf, (hipStream_t)stream);
 }
 
+// GF(2^233) products per second of the hot kernels' multiplier alone (every CU busy, k_affine_round's occupancy): the
+// ceiling bench.py's work model divides by, measured in the same process instead of quoted
+extern "C" int dvp_ubench_gf_mul(int reps, double* products_per_s) {
+  if (reps < 1 || !products_per_s) return DVP_EINVAL;
+  int dev = 0, n_cu = 256;
+  DVP_HIP(hipGetDevice(&dev));
+  DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  const int blocks = n_cu * 3 * 8;  // eight chip-fulls of 3 blocks per CU
+  DevBuf out;
+  DVP_TRY(out.alloc((size_t)blocks * EC_TPB * sizeof(Gf)));
+  hipEvent_t e0, e1;
+  DVP_HIP(hipEventCreate(&e0));
+  DVP_HIP(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int it = 0; it < 3; ++it) {
+    DVP_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_ubench_mul, dim3(blocks), dim3(EC_TPB), EC_LDS, 0, out.as<Gf>(), reps);
+    DVP_HIP(hipEventRecord(e1, 0));
+    DVP_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    DVP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  DVP_HIP(hipGetLastError());
+  *products_per_s = (double)blocks * EC_TPB * reps / (best * 1e-3);
+  return DVP_OK;
+}
+
 extern "C" int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n,
                               uint64_t out_xy[8], int* out_is_infinity) {
   if ((n && (!scalars || !bases_xy)) || !out_xy || !out_is_infinity) return DVP_EINVAL;

@@ -33,11 +33,15 @@ def lib():
         vp = C.c_void_p
         _lib.dvo_msm.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]
         _lib.dvo_msm.restype = C.c_int
+        _lib.dvo_msm_pippenger.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]
+        _lib.dvo_msm_pippenger.restype = C.c_int
         _lib.dvo_k233_mul.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
         _lib.dvo_k233_mulgen.argtypes = [vp, vp, C.POINTER(C.c_int)]
         _lib.dvo_k233_add.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(C.c_int)]
         _lib.dvo_tau_digits.argtypes = [vp, vp]
         _lib.dvo_tau_digits.restype = C.c_int
+        _lib.dvo_tau_digits_fast.argtypes = [vp, vp]
+        _lib.dvo_tau_digits_fast.restype = C.c_int
         _lib.dvo_xsk233_encode.argtypes = [vp, C.c_int, vp]
         _lib.dvo_xsk233_decode.argtypes = [vp, vp, C.POINTER(C.c_int)]
         _lib.dvo_xsk233_decode.restype = C.c_int
@@ -112,6 +116,13 @@ def tau_digits(k):
     return [int(x) for x in d[:n]]
 
 
+def tau_digits_fast(k):
+    """the expansion the timed CPU baselines use (fixed-point quotients, as the GPU kernel rounds)"""
+    d = np.zeros(260, dtype=np.uint8)
+    n = lib().dvo_tau_digits_fast(_p(_limbs(k)), _p(d))
+    return [int(x) for x in d[:n]]
+
+
 def msm(scalars: np.ndarray, bases: np.ndarray, inf: np.ndarray = None, threads: int = 1):
     """scalars [n,4] u64, bases [n,8] u64 -> (point or None).  Reference shape: src/curve.rs:141-158."""
     s = np.ascontiguousarray(scalars, dtype=np.uint64)
@@ -123,6 +134,20 @@ def msm(scalars: np.ndarray, bases: np.ndarray, inf: np.ndarray = None, threads:
     o = np.zeros(8, dtype=np.uint64)
     oi = C.c_int(0)
     lib().dvo_msm(_p(s), _p(b), ip, s.shape[0], threads, _p(o), C.byref(oi))
+    return _pt_out(o, oi)
+
+
+def msm_pippenger(scalars: np.ndarray, bases: np.ndarray, inf: np.ndarray = None, threads: int = 1):
+    """the same sum by a host-side bucket method ("best CPU"): tau-adic windows, per-thread bucket sets"""
+    s = np.ascontiguousarray(scalars, dtype=np.uint64)
+    b = np.ascontiguousarray(bases, dtype=np.uint64)
+    ip = None
+    if inf is not None:
+        inf = np.ascontiguousarray(inf, dtype=np.uint8)
+        ip = _p(inf)
+    o = np.zeros(8, dtype=np.uint64)
+    oi = C.c_int(0)
+    lib().dvo_msm_pippenger(_p(s), _p(b), ip, s.shape[0], threads, _p(o), C.byref(oi))
     return _pt_out(o, oi)
 
 

@@ -229,3 +229,23 @@ def test_tau_length_bound():
         assert lk <= 240 and lo <= 240
         seen = max(seen, lk, lo)
     assert seen >= 236
+
+
+def test_cpu_pippenger_matches_reference_shaped_msm():
+    """BASELINE.md B3 ("best CPU"): the host bucket method returns the same group element as the reference-shaped MSM
+    (and as the discrete-log identity), incl. neutral bases, zero scalars, p-1, one point, more threads than points"""
+    from util import rand_fr_np, pts_to_np, from_limbs, np_dot_mod, to_limbs
+
+    n = 700
+    k, s = rand_fr_np(n, 301), rand_fr_np(n, 302)
+    s[:4] = to_limbs([0, 1, o.P - 1, 2])
+    pts = pts_to_np([co.k233_mulgen(x) for x in from_limbs(k)])
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[9] = 1
+    ks, ss = from_limbs(k), from_limbs(s)
+    exp = co.k233_mulgen(sum(a * b for i, (a, b) in enumerate(zip(ss, ks)) if i != 9) % o.P)
+    for threads in (1, 3):
+        assert co.msm_pippenger(s, pts, inf, threads=threads) == exp == co.msm(s, pts, inf, threads=threads)
+    assert co.msm_pippenger(s[:1], pts[:1], threads=4) is None          # 0 * P
+    assert co.msm_pippenger(s[1:2], pts[1:2], threads=4) == co.k233_mulgen(ks[1])
+    assert co.msm_pippenger(s[:0], pts[:0], threads=2) is None
