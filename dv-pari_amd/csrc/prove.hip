@@ -679,7 +679,11 @@ static int shards_build(dvp_prover* p, const std::vector<int>& devs) {
     sh.device = devs[k];
     auto body = [&]() -> int {
       DVP_HIP(hipSetDevice(sh.device));
-      if (sh.device != p->home_device) (void)hipDeviceEnablePeerAccess(p->home_device, 0);  // already-enabled / unsupported: staged copies still work
+      if (sh.device != p->home_device) {
+        // already-enabled / unsupported are fine (peer copies are staged then); clear the sticky error so that the next
+        // hipGetLastError() check after a kernel launch does not report it
+        if (hipDeviceEnablePeerAccess(p->home_device, 0) != hipSuccess) (void)hipGetLastError();
+      }
       DVP_HIP(hipStreamCreateWithFlags(&sh.st, hipStreamNonBlocking));
       DVP_HIP(hipMalloc((void**)&sh.out, 2 * 80));
       for (int w = 0; w < 2; ++w) {
