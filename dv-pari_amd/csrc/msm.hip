@@ -822,40 +822,46 @@ __global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uin
   }
 }
 
-// E[w*c+t] = tau^(w*c+t)( A[w*2^c + 1 + t] )
-// (window w starts at digit w*c - min(w, n_narrow): the first n_narrow windows are c-1 digits wide)
-__global__ void __launch_bounds__(64)
-k_frob(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ E) {
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (uint32_t)(W * c)) return;
-  uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
-  int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
-  Ld p = A[((size_t)w << c) + 1 + t];
-  p.X = gf_sqr_n_fast(p.X, k, T);  // up to 239 squarings per coordinate: table passes, not a serial chain
-  p.Y = gf_sqr_n_fast(p.Y, k, T);
-  p.Z = gf_sqr_n_fast(p.Z, k, T);
-  E[tid] = p;
-}
-
-// out[i] = in[2i] + in[2i+1]   (in[count] treated as infinity when count is odd)
-// (one addition per quad of lanes, see k_merge<true>)
-__global__ void __launch_bounds__(64) k_pair_add(const Ld* __restrict__ in, uint32_t count, Ld* __restrict__ out) {
+// The whole Frobenius tail of an MSM in ONE single-workgroup launch: E[w*c+t] = tau^k(A[w*2^c + 1 + t]) with k = the first
+// digit of window w plus t (window w starts at digit w*c - min(w, n_narrow): the first n_narrow windows are c-1 digits wide;
+// up to 239 squarings per coordinate, done by table passes, not a serial chain), then the pairwise add tree (in[count]
+// treated as infinity when count is odd), then the projective -> affine conversion.  Every step is pure latency -- 18..240
+// points, log-depth -- so seven launches (each a ~5 us boundary plus a grid ramp) buy nothing over __syncthreads between
+// the levels of one 256-thread block (64 quads, one addition per quad and pass).  buf: 2 * cnt Ld of scratch.
+__global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
+                                                 uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
   extern __shared__ char lds_raw[];
   GfLdsQ L = gf_ldsq_init(lds_raw);
-  uint32_t i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-  if (2 * i >= count) return;
-  Ld a = in[2 * i];
-  if (2 * i + 1 < count) ld_add_ip(a, in[2 * i + 1], L);
-  if (L.r == 0) out[i] = a;
-}
-
-__global__ void __launch_bounds__(64) k_finalize(const Ld* __restrict__ in, GfSqrTables T, uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
-  extern __shared__ char lds_raw[];
-  GfLdsQ L = gf_ldsq_init(lds_raw);
-  if (threadIdx.x >= 4 || blockIdx.x != 0) return;  // one quad: the inversion's 11 products are a serial chain
+  const uint32_t cnt0 = (uint32_t)(W * c);
+  Ld* in = buf;
+  Ld* out = buf + cnt0;
+  for (uint32_t tid = threadIdx.x; tid < cnt0; tid += EC_TPB) {
+    uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
+    int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
+    Ld p = A[((size_t)w << c) + 1 + t];
+    p.X = gf_sqr_n_fast(p.X, k, T);
+    p.Y = gf_sqr_n_fast(p.Y, k, T);
+    p.Z = gf_sqr_n_fast(p.Z, k, T);
+    in[tid] = p;
+  }
+  __syncthreads();
+  uint32_t cnt = cnt0;
+  const uint32_t quad = threadIdx.x >> 2;
+  while (cnt > 1) {
+    const uint32_t half = (cnt + 1) / 2;
+    for (uint32_t i = quad; i < half; i += EC_TPB / 4) {  // whole quads take the same trips
+      Ld a = in[2 * i];
+      if (2 * i + 1 < cnt) ld_add_ip(a, in[2 * i + 1], L);
+      if (L.r == 0) out[i] = a;
+    }
+    __syncthreads();
+    Ld* t = in; in = out; out = t;
+    cnt = half;
+  }
+  if (threadIdx.x >= 4) return;  // one quad: the inversion's products are a serial chain
   Aff a;
   Ld p = in[0];
-  bool fin = !ld_is_inf(p);
+  const bool fin = !ld_is_inf(p);
   a.x = gf_zero();
   a.y = gf_zero();
   if (fin) {
@@ -1066,7 +1072,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
-                          (const void*)k_affine_round, (const void*)k_sum_points};
+                          (const void*)k_affine_round, (const void*)k_sum_points, (const void*)k_tail};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
       DVP_HIP(attr_err);
@@ -1293,16 +1299,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   const int w_tail = fx ? 1 : p.W;  // fixed-base mode has a single bucket set
   uint32_t cntT = (uint32_t)(w_tail * p.c);
-  Ld* ta = tail;
-  Ld* tb = tail + cntT;
-  hipLaunchKernelGGL(k_frob, dim3(cdiv(cntT, 64)), dim3(64), 0, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, Tsq, ta);
-  while (cntT > 1) {
-    uint32_t half = (cntT + 1) / 2;
-    hipLaunchKernelGGL(k_pair_add, dim3(cdiv(4 * half, 64)), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, cntT, tb);
-    Ld* t = ta; ta = tb; tb = t;
-    cntT = half;
-  }
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, ta, Tsq, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
+  (void)cntT;
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, Tsq, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
   ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
