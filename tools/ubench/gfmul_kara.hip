@@ -155,6 +155,17 @@ __device__ __forceinline__ void kh_mul_tab(u32* acc, const u32* a, const GfLdsH&
     kh_shl3(acc);
     kh_row<4>(acc, a, c, 3 * k - 10, 0);
   }
+#ifdef RSH
+  // rows k = 3..0 need a << (10 - 3k): take them as RIGHT shifts (full rate on gfx950) of one pre-shifted copy a << 10
+  u32 ar[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ar[j] = a[j] << 10;
+#pragma unroll 1
+  for (int k = 3; k >= 0; --k) {
+    kh_shl3(acc);
+    kh_row<4>(acc, ar, c, 3 * k, 0);
+  }
+#else
   kh_shl3(acc);
   kh_row<4>(acc, a, c, 0, 1);  // k = 3
 #pragma unroll 1
@@ -162,6 +173,7 @@ __device__ __forceinline__ void kh_mul_tab(u32* acc, const u32* a, const GfLdsH&
     kh_shl3(acc);
     kh_row<4>(acc, a, c, 0, 10 - 3 * k);
   }
+#endif
 }
 #endif
 // x = lo + hi z^117
