@@ -208,9 +208,14 @@ def main():
     alg_bytes = 96.0 * pairs_per_launch
     achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_n else 0.0
     plans = [pv.msm_plan(0), pv.msm_plan(1)]
+    tables = [pv.msm_table(0), pv.msm_table(1)]
     sizes = [pv.msm_size(0), pv.msm_size(1)]
-    # effective windows: tau-adic expansions are ~234 digits long, the overflow window is empty in practice
-    w_eff = sum(-(-234 // max(c, 1)) * n for (c, _), n in zip(plans, sizes)) / max(sum(sizes), 1) if all(c for c, _ in plans) else 13
+    # entries per scalar: tau-adic expansions are ~234 digits long (the overflow window is empty in practice); a sliding
+    # window spans c + 1 digits on average (msm.hip: k_recode_slide), an aligned one exactly c
+    def per_scalar(c, sliding):
+        return 234.0 / (c + 1) + 0.6 if sliding else float(-(-234 // max(c, 1)))
+    w_eff = (sum(per_scalar(c, sl) * n for (c, _), (_, sl), n in zip(plans, tables, sizes)) / max(sum(sizes), 1)
+             if all(c for c, _ in plans) else 13)
     # per addition: 5 products + 1 squaring (~0.13 product) + 1/B of a table-driven inversion (~15 product-equivalents);
     # B is chosen on the device (25..48 in a first round; 36 is typical at this size)
     per_add = 5.13 + 15.0 / 36.0
@@ -274,7 +279,8 @@ def main():
             "sharding": ("in-library (dvp_set_devices): MSM index ranges per device, one host thread each, partial points added on device 0"
                          if n_dev_inproc > 1 else
                          "MSM index ranges per rank, all-gather of partial points + local add" if world > 1 else "single GPU"),
-            "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1]}, "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1]}},
+            "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "sliding": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
+                            "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "sliding": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
             "witness": "resident in HBM",
         },
         "ms_per_step_host_witness": host_ms,

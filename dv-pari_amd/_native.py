@@ -64,6 +64,7 @@ _SIGS = {
     "dvp_msm_ctx_create": (C.c_int, [u64p, u8p, sz, sz, C.POINTER(vp)]),
     "dvp_msm_ctx_destroy": (None, [vp]),
     "dvp_msm_ctx_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dvp_msm_ctx_table_bytes": (C.c_uint64, [vp, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run": (C.c_int, [vp, u64p, sz, sz, u64p, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run_dev": (C.c_int, [vp, vp, sz, sz, vp, vp, vp]),
     "dvp_msm_xsk233": (C.c_int, [u8p, u8p, sz, u8p]),
@@ -85,6 +86,7 @@ _SIGS = {
     "dvp_prove_begin_partial": (C.c_int, [vp, vp, C.c_int, vp]),
     "dvp_prover_msm_size": (C.c_size_t, [vp, C.c_int]),
     "dvp_prover_msm_plan": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dvp_prover_msm_table_bytes": (C.c_uint64, [vp, C.c_int, C.POINTER(C.c_int)]),
     "dvp_prover_msm_partial": (C.c_int, [vp, C.c_int, sz, sz, vp, vp, vp]),
     "dvp_prove_challenge": (C.c_int, [vp, vp, vp, vp]),
     "dvp_prove_finish": (C.c_int, [vp, vp, vp, u8p, vp]),

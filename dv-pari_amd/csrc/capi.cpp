@@ -51,6 +51,7 @@ static void tune_from_env(Tune& t) {
   t.msm_k = geti("DVP_MSM_K", t.msm_k);
   t.msm_fixed_c = geti("DVP_MSM_FIXED_C", t.msm_fixed_c);
   t.fx_hi = geti("DVP_FX_HI", t.fx_hi);
+  t.msm_slide = geti("DVP_MSM_SLIDE", t.msm_slide);
   const char* m = getenv("DVP_MSM_MODE");
   t.msm_proj = (m && !strcmp(m, "proj")) ? 1 : 0;
   t.msm_aff_min = geti("DVP_MSM_AFF_MIN", t.msm_aff_min);
@@ -75,7 +76,7 @@ extern "C" int dvp_tune_set(const char* name, long long value) {
   if (!name) return DVP_EINVAL;
   dvp::Tune& t = dvp::tune();
   struct { const char* n; long long* v; } tab[] = {
-      {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi},
+      {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi}, {"DVP_MSM_SLIDE", &t.msm_slide},
       {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax},
       {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub}};
   for (auto& e : tab)

@@ -69,6 +69,7 @@ struct Tune {
   long long msm_k = 0;          // DVP_MSM_K: fan-in of the projective reducer (0 = default)
   long long msm_fixed_c = 0;    // DVP_MSM_FIXED_C: fixed-base window bits (0 = cost model)
   long long fx_hi = -1;         // DVP_FX_HI: level-1 partition bits of the fixed-base sort (-1 = c/2)
+  long long msm_slide = -1;     // DVP_MSM_SLIDE: sliding-window fixed-base tables (240 rotations per base): 1 on, 0 off, -1 = when HBM allows
   long long msm_proj = 0;       // DVP_MSM_MODE=proj: skip the batched-affine rounds
   long long msm_aff_min = 1ll << 19;   // DVP_MSM_AFF_MIN: pair rounds run while a round has this many additions
   long long msm_aff_bmax = 48;  // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns

@@ -30,6 +30,13 @@
 
 namespace dvp {
 
+// Entry word of the fixed-base mode (one u32 per (slot, scalar)): bit 31 = valid, bits 20..27 = row of the pre-rotated
+// table (the power of tau the base is taken at), bits 0..19 = bucket key.  0 = empty slot.
+constexpr uint32_t FXW_VALID = 0x80000000u, FXW_KEY_MASK = 0xfffffu;
+constexpr int FXW_ROW_SHIFT = 20;
+__host__ __device__ __forceinline__ uint32_t fxw_key(uint32_t d) { return d & FXW_KEY_MASK; }
+__host__ __device__ __forceinline__ uint32_t fxw_row(uint32_t d) { return (d >> FXW_ROW_SHIFT) & 0xffu; }
+
 // One thread per scalar: digits[w][i] (c-bit patterns) + bucket histogram.
 // Scalars >= r are rejected (flag); points flagged infinite contribute nothing.
 template <class DIGIT>
@@ -62,7 +69,11 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
     buf |= (uint64_t)tau_step16(r0, r1) << nb;
     nb += 16;
     while (nb >= width && w < W) {
-      digits[(size_t)w * n + i] = (DIGIT)(buf & ((1ull << width) - 1));
+      const uint32_t dv = (uint32_t)(buf & ((1ull << width) - 1));
+      if (sizeof(DIGIT) == 4)  // fixed-base mode: entry word = valid | table row | bucket key (see FXW_*)
+        digits[(size_t)w * n + i] = (DIGIT)(dv ? (FXW_VALID | ((uint32_t)w << FXW_ROW_SHIFT) | dv) : 0u);
+      else
+        digits[(size_t)w * n + i] = (DIGIT)dv;
       buf >>= width;
       nb -= width;
       ++w;
@@ -73,6 +84,102 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
 #pragma unroll
   for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
   if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than W*c digits
+}
+
+// Sliding-window recode (fixed-base mode with a table of ALL 240 rotations of every base, MsmFixedCtx::slide).
+// A window starts at a nonzero digit, so its value v is odd: only the 2^(c-1) odd patterns need buckets (key = v >> 1)
+// and the zeros between windows cost nothing -- a scalar has ~234/(c+1) + 0.6 entries instead of 234/c at the same
+// number of buckets per bit of window.  Entry = (row = position of the window's first digit, key): it adds
+// tau^row(P_i) -- row `row` of the table -- to bucket `key`, and the merge multiplies bucket `key` by 2*key + 1.
+// Widths are evened out over the whole expansion (slide_window_width): greedy c-digit windows would leave a final window
+// of random width 1..c per scalar, and a window of w digits reaches only the 2^(w-1) smallest keys -- n/c entries per
+// width piled into a handful of buckets (measured: 175 000 entries in key 0 at n = 4.2 M against an average of 190).
+// With R digits to go and a window + the zeros after it spanning c + 1 digits on average, k = ceil((R+1)/(c+1)) windows
+// remain and each takes ceil((R+1)/k) - 1 digits: the slack is spread one digit at a time (windows are c or c-1 wide,
+// rarely less), the entry count stays at 234/(c+1) + 0.6 and the fullest keys hold ~2.7x the average.
+__host__ __device__ __forceinline__ int slide_window_width(int R, int c) {
+  const int k = (R + 1 + c) / (c + 1);
+  if (k <= 1) return R < c ? R : c;
+  const int w = (R + k) / k - 1;  // ceil((R+1)/k) - 1, in [1, c]
+  return w < R ? w : R;
+}
+// entry slots a scalar can need: the all-ones expansion (no zeros to skip) of the full length
+static int slide_slots(int c) {
+  int best = 0;
+  for (int len = 1; len <= TAU_DIGITS; ++len) {
+    int cnt = 0;
+    for (int R = len; R > 0; R -= slide_window_width(R, c)) ++cnt;
+    if (cnt > best) best = cnt;
+  }
+  return best;
+}
+__global__ void __launch_bounds__(256)
+k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int slots,
+               uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
+  bool skip = inf && inf[i];
+  if (!tau_scalar_is_canonical(s)) {
+    atomicMin(err, (unsigned long long)i);
+    skip = true;
+  }
+  uint32_t r0[5], r1[5];
+  tau_partial_reduce(s, r0, r1);
+  if (skip) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
+  }
+  // the digits, least significant first: 8 words of 2 x 16 digits pushed through a shift register (static indices, one
+  // copy of the expansion step in the code); digits >= TAU_DIGITS = 240 land in the top half of d[7] and must be zero
+  uint32_t d[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = 0;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    uint32_t wlo = tau_step16(r0, r1);
+    uint32_t whi = tau_step16(r0, r1);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) d[q] = d[q + 1];
+    d[7] = wlo | (whi << 16);
+  }
+  uint32_t rest = d[7] >> (TAU_DIGITS - 224);
+  d[7] &= (1u << (TAU_DIGITS - 224)) - 1;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
+  if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than TAU_DIGITS (proven impossible, tau.cuh)
+  int len = 0;  // number of significant digits
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (d[k]) len = 32 * k + 32 - __clz(d[k]);
+  auto shr = [&](int sh) {  // 0 <= sh < 32
+#pragma unroll
+    for (int k = 0; k < 7; ++k) d[k] = __funnelshift_r(d[k], d[k + 1], sh);
+    d[7] >>= sh;
+  };
+  int pos = 0, slot = 0;
+#pragma unroll 1
+  while (pos < len) {
+    while (d[0] == 0) {  // terminates: a significant digit lies above pos
+#pragma unroll
+      for (int k = 0; k < 7; ++k) d[k] = d[k + 1];
+      d[7] = 0;
+      pos += 32;
+    }
+    const int z = __ffs(d[0]) - 1;
+    shr(z);
+    pos += z;
+    const int width = slide_window_width(len - pos, c);  // >= 1 digits are left, the lowest of them is 1
+    const uint32_t v = d[0] & ((1u << width) - 1);
+    if (slot < slots) words[(size_t)slot * n + i] = FXW_VALID | ((uint32_t)pos << FXW_ROW_SHIFT) | (v >> 1);
+    else atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: slots = slide_slots(c)
+    ++slot;
+    shr(width);
+    pos += width;
+  }
+  for (; slot < slots; ++slot) words[(size_t)slot * n + i] = 0;
 }
 
 // ---- exclusive scan of u32 (3 kernels; up to 4096*1024 elements) ---------------------------------
@@ -250,7 +357,8 @@ k_scatter_local(const uint16_t* __restrict__ digits, uint32_t n, int c, const ui
 // entry costs a whole sector (1.3 GB of HBM writes for 160 MB of entries), with 2^9 level-1 bins the two level-1
 // streams thrash the L2 instead.  The split is a per-context knob (MsmFixedCtx::hi_bits); staging each chunk in LDS
 // and writing whole runs would remove the trade-off and is the known next step for this stage.
-// An entry is the pair (window w, scalar i); its id e = w * n_total + i0 + i indexes the pre-rotated base table.
+// An entry is the pair (table row, scalar i) (FXW_* entry words); its id e = row * n_total + i0 + i indexes the
+// pre-rotated base table.
 constexpr int FX_C_MAX = 20, FX_NP_MAX = 1 << (FX_C_MAX / 2);  // c = lo + hi bits, chosen per context
 constexpr uint32_t FX_CHUNK = 16384;  // entries per block at both levels: the staged scatters keep a whole chunk in LDS
 struct FxBits {
@@ -268,7 +376,7 @@ k_part_hist(const uint32_t* __restrict__ digits, size_t total, FxBits fb, uint32
   size_t lo = (size_t)blockIdx.x * FX_CHUNK, hi = min(total, lo + FX_CHUNK);
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
     uint32_t d = digits[e];
-    if (d) atomicAdd(&h[d >> FX_LO], 1u);
+    if (d) atomicAdd(&h[fxw_key(d) >> FX_LO], 1u);
   }
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) phist[(size_t)blockIdx.x * FX_NP + k] = h[k];
@@ -335,10 +443,10 @@ k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, ui
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
     uint32_t d = digits[e];
     if (!d) continue;
-    uint32_t w = (uint32_t)(e / n), i = (uint32_t)(e - (size_t)w * n);
-    uint32_t pos = atomicAdd(&cur[d >> FX_LO], 1u);
-    plo[pos] = (uint16_t)(d & ((1u << FX_LO) - 1));
-    pid[pos] = w * n_total + i0 + i;
+    const uint32_t i = (uint32_t)(e % n), key = fxw_key(d);
+    uint32_t pos = atomicAdd(&cur[key >> FX_LO], 1u);
+    plo[pos] = (uint16_t)(key & ((1u << FX_LO) - 1));
+    pid[pos] = fxw_row(d) * n_total + i0 + i;
   }
 }
 // the partition whose chunk range [cstart[k], cstart[k+1]) holds chunk g (empty partitions share their start with the
@@ -452,15 +560,12 @@ k_part_scatter_staged(const uint32_t* __restrict__ digits, size_t total, uint32_
   for (size_t e = lo + t; e < hi; e += SORT_TPB) {
     uint32_t d = digits[e];
     if (!d) continue;
-    uint32_t w = w0;
-    size_t i = e - (size_t)w0 * n;
-    while (i >= n) {
-      i -= n;
-      ++w;
-    }
-    uint32_t pos = atomicAdd(&cur[d >> FX_LO], 1u);
-    st_d[pos] = d;
-    st_id[pos] = w * n_total + i0 + (uint32_t)i;
+    size_t i = e - (size_t)w0 * n;  // e mod n: a chunk spans few slots
+    while (i >= n) i -= n;
+    const uint32_t key = fxw_key(d);
+    uint32_t pos = atomicAdd(&cur[key >> FX_LO], 1u);
+    st_d[pos] = key;
+    st_id[pos] = fxw_row(d) * n_total + i0 + (uint32_t)i;
   }
   __syncthreads();
   const uint32_t mask = (1u << FX_LO) - 1;
@@ -518,6 +623,21 @@ k_frob_table(const Aff* __restrict__ bases, uint32_t n, int FX_C, int FX_W, int 
     p.x = gf_sqr_n(p.x, width);
     p.y = gf_sqr_n(p.y, width);
     table[(size_t)w * n + i] = p;
+  }
+}
+
+// sliding-window mode: every rotation, T[j][i] = tau^j(P_i), j < rows
+__global__ void __launch_bounds__(256)
+k_frob_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, Aff* __restrict__ table) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff p = bases[i];
+  table[i] = p;
+#pragma unroll 1
+  for (int j = 1; j < rows; ++j) {
+    p.x = gf_sqr(p.x);
+    p.y = gf_sqr(p.y);
+    table[(size_t)j * n + i] = p;
   }
 }
 
@@ -828,17 +948,20 @@ __global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uin
 // treated as infinity when count is odd), then the projective -> affine conversion.  Every step is pure latency -- 18..240
 // points, log-depth -- so seven launches (each a ~5 us boundary plus a grid ramp) buy nothing over __syncthreads between
 // the levels of one 256-thread block (64 quads, one addition per quad and pass).  buf: 2 * cnt Ld of scratch.
+// n_narrow < 0 = sliding-window mode (W = 1): bucket key b stands for the odd pattern 2b + 1, so the result is
+// A[0] (the sum of all buckets, power 0) + sum_t tau^t(A[t]) for t = 1 .. c-1 (A[t] = the buckets whose key has bit t-1).
 __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
                                                  uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
   extern __shared__ char lds_raw[];
   GfLdsQ L = gf_ldsq_init(lds_raw);
   const uint32_t cnt0 = (uint32_t)(W * c);
+  const bool slide = n_narrow < 0;
   Ld* in = buf;
   Ld* out = buf + cnt0;
   for (uint32_t tid = threadIdx.x; tid < cnt0; tid += EC_TPB) {
     uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
-    int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
-    Ld p = A[((size_t)w << c) + 1 + t];
+    int k = slide ? (int)tid : (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
+    Ld p = slide ? A[tid] : A[((size_t)w << c) + 1 + t];
     p.X = gf_sqr_n_fast(p.X, k, T);
     p.Y = gf_sqr_n_fast(p.Y, k, T);
     p.Z = gf_sqr_n_fast(p.Z, k, T);
@@ -988,8 +1111,19 @@ struct MsmFixedCtx {
     n_narrow = w_main * cc - 234;
     W = w_main + 1;
   }
+  // sliding-window mode (k_recode_slide): the table holds all TAU_DIGITS rotations, W = entry slots per scalar, keys are
+  // the odd c-digit patterns (c - 1 key bits)
+  bool slide = false;
+  void set_c_slide(int cc) {
+    c = cc;
+    n_narrow = 0;
+    W = slide_slots(cc);
+    slide = true;
+  }
+  int rows() const { return slide ? TAU_DIGITS : W; }
+  int key_bits() const { return slide ? c - 1 : c; }
   int hi_bits = -1;  // level-1 partition bits of the sort (set at creation)
-  FxBits bits() const { FxBits b; b.hi = hi_bits; b.lo = c - b.hi; return b; }
+  FxBits bits() const { FxBits b; b.hi = hi_bits; b.lo = key_bits() - b.hi; return b; }
 };
 static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   const bool fixed = fx != nullptr;
@@ -1019,7 +1153,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
     p.c = fx->c;
     p.W = fx->W;
     p.n_narrow = fx->n_narrow;
-    p.nkeys = 1u << fx->c;
+    p.nkeys = 1u << fx->key_bits();
   }
   p.e_max = n * (size_t)p.W;
   // fan-in: keep >= ~256k level-1 tasks in flight when the input allows it
@@ -1049,7 +1183,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   if (n > (1u << 27)) return DVP_EINVAL;
   {  // entry positions and pre-rotated table indices are 32-bit (0xffffffff = "no partner" in a slot descriptor)
     const MsmPlan pl = msm_plan(n, fx);
-    const uint64_t tab = fx ? (uint64_t)fx->W * fx->n_total : (uint64_t)n;
+    const uint64_t tab = fx ? (uint64_t)fx->rows() * fx->n_total : (uint64_t)n;
     if ((uint64_t)pl.e_max >= 0xfffffff0ull || tab >= 0xfffffff0ull) return DVP_EINVAL;
   }
   int cur_dev = 0;
@@ -1153,7 +1287,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
-  if (fx)
+  const bool slide = fx && fx->slide;
+  if (slide)
+    hipLaunchKernelGGL(k_recode_slide, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
+                       p.c, p.W, digits32, err);
+  else if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
                        (uint32_t)n, p.c, p.W, p.n_narrow, digits32, err);
   else
@@ -1198,7 +1336,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipStreamWaitEvent(g_ws.aux, g_ws.ev, 0));
   DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
   const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
-  const size_t e_est = (size_t)n * (size_t)((234 + p.c - 1) / p.c);  // the overflow windows are empty in practice
+  // entries that really exist: the overflow windows are empty in practice; a sliding window spans c + 1 digits on average
+  const size_t e_est = slide ? (size_t)((double)n * (234.0 / (p.c + 1) + 0.6)) : (size_t)n * (size_t)((234 + p.c - 1) / p.c);
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -1289,7 +1428,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     hipLaunchKernelGGL(k_bucket_gather, dim3(cdiv(nk, 256)), dim3(256), 0, st, in, pc[cur], po[cur], nk, bkt);
   }
   ProfScope ps_tail(PROF_MSM_TAIL, st);  // merge tree, Frobenius tail, final add tree
-  for (int j = 0; j < p.c; ++j) {
+  const int merge_levels = fx ? fx->key_bits() : p.c;
+  for (int j = 0; j < merge_levels; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
     if (total <= quad_max)
@@ -1301,7 +1441,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
   (void)cntT;
-  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, Tsq, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf);
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, slide ? -1 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
+                     (uint32_t*)d_out_inf);
   ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
@@ -1336,42 +1477,76 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 // range_hint = number of bases a typical call will cover (the per-GPU shard): the shared window size c
 // minimises an empirical cost in field multiplications (pair additions + a per-bucket term, see below)
 void msm_fixed_destroy(MsmFixedCtx* c);
-int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
-  if ((uint64_t)n_total * 32 >= 0xfffffff0ull) return DVP_EINVAL;  // W <= 31 windows of pre-rotated copies, 32-bit indices
+static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hint, bool slide, MsmFixedCtx** out, hipError_t* alloc_err) {
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
   double best = 1e300;
   int best_c = 8;
-  for (int cc = 8; cc <= FX_C_MAX; ++cc) {
-    int w_main = (234 + cc - 1) / cc;
+  const int c_max = FX_C_MAX + (slide ? 1 : 0);  // <= 20 key bits either way
+  for (int cc = 8; cc <= c_max; ++cc) {
     // pair additions at ~5.6 product-equivalents + a per-bucket term for merge/reducer/sort; measured on MI355X at 2^20
-    // constraints: c = 18 beats 16, 17, 19 and 20 for every shard from 0.26 M to 4.2 M pairs, c = 20 wins from ~8 M pairs
-    double cost = (double)w_main * (double)range_hint * 5.6 + 10.0 * (double)(1u << cc) +
-                  (cc > 18 ? 25.0 * (double)((1u << cc) - (1u << 18)) : 0.0);
+    // constraints: 2^18 buckets beat 2^16, 2^17, 2^19 and 2^20 for every shard from 0.26 M to 4.2 M pairs of the aligned
+    // windows (2^20 wins from ~8 M pairs); with sliding windows 2^18 and 2^19 buckets tie at 2.1 M and 2^19 wins at 4.2 M
+    const int kb = slide ? cc - 1 : cc;
+    const double per_scalar = slide ? 234.0 / (cc + 1) + 0.6 : (double)((234 + cc - 1) / cc);
+    double cost = per_scalar * (double)range_hint * 5.6 + 10.0 * (double)(1u << kb) + (kb > 18 ? 25.0 * (double)((1u << kb) - (1u << 18)) : 0.0);
     if (cost < best) { best = cost; best_c = cc; }
   }
-  if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= FX_C_MAX) best_c = (int)tune().msm_fixed_c;
-  c->set_c(best_c);
-  c->hi_bits = c->c / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
-  if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && c->c - h <= 15 && c->c - h >= 1) c->hi_bits = h;
-  hipError_t e = hipMalloc((void**)&c->table, (size_t)c->W * n_total * sizeof(Aff));
+  if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= c_max) best_c = (int)tune().msm_fixed_c;
+  if (slide) c->set_c_slide(best_c); else c->set_c(best_c);
+  const int kb = c->key_bits();
+  c->hi_bits = kb / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
+  if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && kb - h <= 15 && kb - h >= 1) c->hi_bits = h;
+  hipError_t e = hipMalloc((void**)&c->table, (size_t)c->rows() * n_total * sizeof(Aff));
+  *alloc_err = e;
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
+    if (slide)
+      hipLaunchKernelGGL(k_frob_table_all, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->rows(), c->table);
+    else
+      hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
+    c->table = *alloc_err == hipSuccess ? c->table : nullptr;
     msm_fixed_destroy(c);
     return hip_fail(e, "msm_fixed_create", __FILE__, __LINE__);
   }
   *out = c;
   return DVP_OK;
 }
+int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
+  if ((uint64_t)n_total * 32 >= 0xfffffff0ull) return DVP_EINVAL;  // W <= 31 windows of pre-rotated copies, 32-bit indices
+  // Sliding windows need every rotation of every base: TAU_DIGITS x n_total x 64 B (15 KB per base; 64 GB for the 4m
+  // bases of a 2^20-constraint prover, 97 GB for both of its SRS vectors) and buy ~8 % fewer bucket additions.  MI355X
+  // has 288 GB, so by default (Tune::msm_slide < 0) the mode is on whenever the table fits in 40 % of what is free on the
+  // device right now -- a second or third prover, or a 2^22 circuit, gets the aligned windows and their W-row table on
+  // its own -- and an allocation failure falls back to the aligned windows as well.
+  const uint64_t slide_bytes = (uint64_t)TAU_DIGITS * n_total * sizeof(Aff);
+  const long long mode = tune().msm_slide;
+  bool slide = false;
+  if ((uint64_t)TAU_DIGITS * n_total < 0xfffffff0ull && mode != 0) {
+    size_t free_b = 0, total_b = 0;
+    slide = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes <= (uint64_t)(0.4 * (double)free_b));
+  }
+  hipError_t alloc_err = hipSuccess;
+  int rc = msm_fixed_build(d_bases, n_total, range_hint, slide, out, &alloc_err);
+  if (rc != DVP_OK && slide && mode < 0 && alloc_err == hipErrorOutOfMemory) {
+    (void)hipGetLastError();  // the failed hipMalloc is not an error of this call
+    rc = msm_fixed_build(d_bases, n_total, range_hint, false, out, &alloc_err);
+  }
+  return rc;
+}
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows) {
   if (!c) return DVP_EINVAL;
   *cbits = c->c;
   *windows = c->W;
   return DVP_OK;
+}
+// bytes of the pre-rotated table; *sliding = 1 when it holds all TAU_DIGITS rotations (sliding windows)
+uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* sliding) {
+  if (sliding) *sliding = c && c->slide ? 1 : 0;
+  return c ? (uint64_t)c->rows() * c->n_total * sizeof(Aff) : 0;
 }
 void msm_fixed_destroy(MsmFixedCtx* c) {
   if (!c) return;
@@ -1491,6 +1666,7 @@ extern "C" int dvp_msm_ctx_plan(const dvp_msm_ctx* c, int* c_bits, int* windows)
   if (!c || !c_bits || !windows) return DVP_EINVAL;
   return msm_fixed_info(c->fx, c_bits, windows);
 }
+extern "C" uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* c, int* sliding) { return c ? msm_fixed_table_bytes(c->fx, sliding) : 0; }
 // sum_{i in [lo,hi)} scalars[i - lo] * base[i]; d_scalars holds hi - lo canonical scalars (device)
 extern "C" int dvp_msm_ctx_run_dev(dvp_msm_ctx* c, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
   if (!c || !d_scalars || !d_out_xy || !d_out_inf || lo > hi || hi > c->n) return DVP_EINVAL;

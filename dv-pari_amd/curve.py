@@ -127,6 +127,12 @@ class FixedBaseMsm:
         check(lib.dvp_msm_ctx_plan(self._h, C.byref(c), C.byref(w)), "dvp_msm_ctx_plan")
         return c.value, w.value
 
+    def table(self):
+        """(bytes of HBM, sliding-window flavour?) of the pre-rotated table"""
+        s = C.c_int(0)
+        b = int(lib.dvp_msm_ctx_table_bytes(self._h, C.byref(s)))
+        return b, bool(s.value)
+
     def run(self, scalars: np.ndarray, lo: int = 0, hi: int = None):
         hi = self.n if hi is None else hi
         s = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)

@@ -224,6 +224,12 @@ class Prover:
         check(lib.dvp_prover_msm_plan(self._h, which, C.byref(c), C.byref(w)), "dvp_prover_msm_plan")
         return c.value, w.value
 
+    def msm_table(self, which: int):
+        """(bytes of HBM, sliding-window flavour?) of the fixed-base tables of MSM `which`"""
+        s = C.c_int(0)
+        b = int(lib.dvp_prover_msm_table_bytes(self._h, which, C.byref(s)))
+        return b, bool(s.value)
+
     def msm_partial(self, which: int, lo: int, hi: int, d_out_xy: int, d_out_inf: int, stream: int = 0):
         check(lib.dvp_prover_msm_partial(self._h, which, lo, hi, d_out_xy, d_out_inf, stream), "dvp_prover_msm_partial")
 

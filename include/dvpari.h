@@ -146,8 +146,14 @@ int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void
 typedef struct dvp_msm_ctx dvp_msm_ctx;
 int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out);
 void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
-/* window bits c (all windows share one set of 2^c buckets) and window count the context settled on */
+/* window bits c and window count (aligned windows: all W windows share one set of 2^c buckets; sliding windows: entry
+ * slots per scalar, 2^(c-1) buckets of odd patterns) the context settled on */
 int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
+/* HBM held by the context's pre-rotated table.  Two flavours: aligned windows keep W ~ 14 rotations of every base
+ * (0.9 KB per base); sliding windows keep all 240 (15 KB per base: 64 GB for the 4m bases of a 2^20-constraint prover)
+ * and need ~8 % fewer bucket additions.  The sliding table is chosen when it fits in 40 % of the device memory that is
+ * free when the context is built (DVP_MSM_SLIDE = 1 / 0 forces it on / off); *sliding reports which one this is. */
+uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 /* same seam with the reference's own wire formats: scalars n x 32 B canonical LE, bases n x 30 B
@@ -206,6 +212,8 @@ int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_ex
 size_t dvp_prover_msm_size(const dvp_prover* p, int which);
 /* window bits / window count chosen for MSM `which` (0,0 until its fixed-base tables exist) */
 int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows);
+/* HBM held by the fixed-base tables of MSM `which` on all devices (see dvp_msm_ctx_table_bytes) */
+uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, int* sliding);
 int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream);
 int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream);

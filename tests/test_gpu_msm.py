@@ -125,18 +125,22 @@ def test_msm_wire_format(dvp):
     assert out == co.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)))
 
 
+@pytest.mark.parametrize("slide", [0, 1])
 @pytest.mark.parametrize("hint", [0, 1 << 10, 1 << 24])
-def test_fixed_base_msm_context(dvp, hint):
+def test_fixed_base_msm_context(dvp, hint, slide):
     """dvp_msm_ctx_*: pre-rotated bases, shared bucket set; full range, sub-ranges (the per-GPU shards) and a
-    neutral base, for several window sizes (range_hint drives the choice; 2^24 forces c = 20, two-level sort)."""
+    neutral base, for several window sizes (range_hint drives the choice; 2^24 forces c = 20, two-level sort), with the
+    aligned windows (W-row table) and the sliding windows (240-row table, odd patterns only)."""
     n = 6000
     k, s = rand_fr_np(n, 61), rand_fr_np(n, 62)
     bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
     inf = np.zeros(n, dtype=np.uint8)
     inf[5] = 1
-    fb = dvp.curve.FixedBaseMsm(bases, inf, hint if hint <= n else 0) if hint <= n else None
-    if fb is None:
-        with dvp.tune(DVP_MSM_FIXED_C=20):
+    if hint <= n:
+        with dvp.tune(DVP_MSM_SLIDE=slide):
+            fb = dvp.curve.FixedBaseMsm(bases, inf, hint)
+    else:
+        with dvp.tune(DVP_MSM_FIXED_C=20, DVP_MSM_SLIDE=slide):
             fb = dvp.curve.FixedBaseMsm(bases, inf, 0)
     ks, ss = from_limbs(k), from_limbs(s)
 
@@ -219,9 +223,25 @@ def test_msm_full_size_dlog_and_linearity(dvp, log_n):
     fb.close()
 
 
+def slide_slots(c):
+    """entry slots per scalar of the sliding-window recode (msm.hip: slide_window_width / slide_slots)"""
+    def width(R):
+        k = (R + 1 + c) // (c + 1)
+        return min(R, c) if k <= 1 else min((R + k) // k - 1, R)
+    best = 0
+    for length in range(1, 241):
+        cnt, R = 0, length
+        while R > 0:
+            R -= width(R)
+            cnt += 1
+        best = max(best, cnt)
+    return best
+
+
 def test_fixed_base_vs_one_shot_randomised(dvp):
-    """differential sweep: every fixed-base window size 8..20 (evened windows, both sort flavours, 4/8/16-slot pair rounds)
-    against the one-shot path on random sub-ranges, plus scalars with long runs of zero / one digits"""
+    """differential sweep: every fixed-base window size 8..20 of the aligned and 8..21 of the sliding windows (both sort
+    flavours, 4/8/16-slot pair rounds) against the one-shot path on random sub-ranges, plus scalars with long runs of
+    zero / one digits"""
     rnd = random.Random(2026)
     n = 3000
     k = rand_fr_np(n, 91)
@@ -234,17 +254,18 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     assert max(len(co.tau_digits(x)) for x in special) >= 236
     s[: len(special)] = to_limbs(special)
     ks, ss = from_limbs(k), from_limbs(s)
-    for c in range(8, 21):
-        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]), DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
+    for c, slide in [(c, 0) for c in range(8, 21)] + [(c, 1) for c in range(8, 22)]:
+        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_SLIDE=slide, DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
+                      DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
             fb = dvp.curve.FixedBaseMsm(bases)
-            assert fb.plan()[0] == c
+            assert fb.plan() == (c, slide_slots(c) if slide else (234 + c - 1) // c + 1)
             for _ in range(3):
                 lo = rnd.randrange(0, n - 1)
                 hi = rnd.randrange(lo + 1, n + 1)
                 xy, is_inf = fb.run(s[lo:hi], lo, hi)
                 exp = co.k233_mulgen(sum(ss[i] * ks[i] for i in range(lo, hi)) % o.P)
-                assert np_to_pt(xy, is_inf) == exp, (c, lo, hi)
-                assert gpu_msm(dvp, s[lo:hi], bases[lo:hi]) == exp, (c, lo, hi)
+                assert np_to_pt(xy, is_inf) == exp, (c, slide, lo, hi)
+                assert gpu_msm(dvp, s[lo:hi], bases[lo:hi]) == exp, (c, slide, lo, hi)
             fb.close()
 
 
