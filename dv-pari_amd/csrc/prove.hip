@@ -37,6 +37,7 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
                    void* d_out_inf, hipStream_t st);
 int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipStream_t st);
 int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st);
+int encode_point_dev(const Aff* d_pt, const uint32_t* d_inf32, uint8_t* d_out, hipStream_t st);
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
 struct MsmFixedCtx;
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out);
@@ -228,7 +229,6 @@ __global__ void __launch_bounds__(256) k_from_mont_vec(const Fr* __restrict__ in
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = fr_from_mont(in[i]);
 }
-__global__ void k_inf32_to_8(const uint32_t* in, uint8_t* out) { out[0] = in[0] ? 1 : 0; out[1] = in[1] ? 1 : 0; }
 
 }  // namespace dvp
 
@@ -243,6 +243,7 @@ struct DevCsr {
   uint32_t max_coeff_id = 0;  // largest coefficient id stored (re-checked against the table in prover_ready)
 };
 
+static constexpr size_t FIN_BYTES = 4 * sizeof(Fr) + 16 + 64;  // a0 b0 i0 r0 | flags | commit_p, kzg_k encodings
 struct dvp_prover {
   uint32_t log_m = 0, m = 0, n_pub = 0, n_wires = 0;
   dvp_ecfft* tree = nullptr;  // 2m leaves (tree2n)
@@ -288,6 +289,7 @@ struct dvp_prover {
   Fr alpha_canon, abir0_host[4];
   std::vector<uint64_t> pub_host;
   uint8_t commit_p_host[30];
+  uint8_t* fin_host = nullptr;  // pinned mirror of the device block [abir0 | flags | enc]
 };
 
 static const int PT = 256;
@@ -351,12 +353,14 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
   p->den2 = p->den + m;
   DVP_TRY(A((void**)&p->SK, 4 * m * sizeof(Fr)));
   DVP_TRY(A((void**)&p->partial, 3 * 1024 * sizeof(Fr)));
-  DVP_TRY(A((void**)&p->abir0, 4 * sizeof(Fr)));
-  DVP_TRY(A((void**)&p->flags, 16));
+  // what the host reads back at the end of a proof, in ONE block and one copy: a0 b0 i0 r0 | flags | encoded points
+  DVP_TRY(A((void**)&p->abir0, FIN_BYTES));
+  p->flags = (unsigned long long*)((char*)p->abir0 + 4 * sizeof(Fr));
+  p->enc = (uint8_t*)p->abir0 + 4 * sizeof(Fr) + 16;
+  DVP_HIP(hipHostMalloc((void**)&p->fin_host, FIN_BYTES, hipHostMallocDefault));
   DVP_TRY(A((void**)&p->pts, 2 * sizeof(Aff)));
   DVP_TRY(A((void**)&p->pts_inf32, 8));
   DVP_TRY(A((void**)&p->pts_inf8, 8));
-  DVP_TRY(A((void**)&p->enc, 64));
   DVP_HIP(hipMemset(p->inf_a, 0, n_wires + m));
   DVP_HIP(hipMemset(p->inf_k, 0, 4 * m));
   dvp_ecfft* t = p->tree;
@@ -374,10 +378,11 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
 extern "C" void dvp_prover_destroy(dvp_prover* p) {
   if (!p) return;
   void* ptrs[] = {p->dD, p->dD2, p->barw, p->z2inv, p->coeffs_m, p->bases_a, p->inf_a, p->bases_k, p->inf_k, p->w, p->E,
-                  p->E2, p->r2, p->SA, p->den, p->SK, p->partial, p->abir0, p->flags, p->pts, p->pts_inf32,
-                  p->pts_inf8, p->enc};
+                  p->E2, p->r2, p->SA, p->den, p->SK, p->partial, p->abir0 /* + flags + enc */, p->pts, p->pts_inf32,
+                  p->pts_inf8};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
+  if (p->fin_host) (void)hipHostFree(p->fin_host);
   for (auto& mt : p->mat) {
     if (mt.row_ptr) (void)hipFree(mt.row_ptr);
     if (mt.wire) (void)hipFree(mt.wire);
@@ -808,8 +813,7 @@ extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const
   dim3 gm(cdiv(m, PT)), bt(PT);
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(k_inf32_to_8, dim3(1), dim3(1), 0, st, p->pts_inf32, p->pts_inf8);
-  DVP_TRY(encode_dev(p->pts, p->pts_inf8, 1, p->enc, st));
+  DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
   DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
   uint8_t ch[32];
@@ -836,14 +840,13 @@ extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void*
   hipStream_t st = (hipStream_t)stream;
   if (d_kzg_xy != p->pts + 1) DVP_HIP(hipMemcpyAsync(p->pts + 1, d_kzg_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_kzg_inf != p->pts_inf32 + 1) DVP_HIP(hipMemcpyAsync(p->pts_inf32 + 1, d_kzg_inf, 4, hipMemcpyDeviceToDevice, st));
-  hipLaunchKernelGGL(k_inf32_to_8, dim3(1), dim3(1), 0, st, p->pts_inf32, p->pts_inf8);
-  DVP_TRY(encode_dev(p->pts + 1, p->pts_inf8 + 1, 1, p->enc + 30, st));
-  uint8_t kz[30];
-  unsigned long long f[2];
-  DVP_HIP(hipMemcpyAsync(kz, p->enc + 30, 30, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipMemcpyAsync(p->abir0_host, p->abir0, 4 * sizeof(Fr), hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
+  DVP_TRY(encode_point_dev(p->pts + 1, p->pts_inf32 + 1, p->enc + 30, st));
+  DVP_HIP(hipMemcpyAsync(p->fin_host, p->abir0, FIN_BYTES, hipMemcpyDeviceToHost, st));  // pinned: one DMA, no staging
   DVP_HIP(hipStreamSynchronize(st));
+  unsigned long long f[2];
+  memcpy(p->abir0_host, p->fin_host, 4 * sizeof(Fr));
+  memcpy(f, p->fin_host + 4 * sizeof(Fr), 16);
+  const uint8_t* kz = p->fin_host + 4 * sizeof(Fr) + 16 + 30;
   if (f[1] != ~0ull) {
     g_last_error_index = (int64_t)f[1];
     return DVP_ECHALLENGE;  // alpha in D u D', src/proving.rs:548-556
