@@ -1522,15 +1522,16 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
   if ((uint64_t)n_total * 32 >= 0xfffffff0ull) return DVP_EINVAL;  // W <= 31 windows of pre-rotated copies, 32-bit indices
   // Sliding windows need every rotation of every base: TAU_DIGITS x n_total x 64 B (15 KB per base; 64 GB for the 4m
   // bases of a 2^20-constraint prover, 97 GB for both of its SRS vectors) and buy ~8 % fewer bucket additions.  MI355X
-  // has 288 GB, so by default (Tune::msm_slide < 0) the mode is on whenever the table fits in 40 % of what is free on the
-  // device right now -- a second or third prover, or a 2^22 circuit, gets the aligned windows and their W-row table on
-  // its own -- and an allocation failure falls back to the aligned windows as well.
+  // has 288 GB, so by default (Tune::msm_slide < 0) the mode is on whenever the table leaves a reserve of a quarter of the
+  // device (72 GB: MSM workspaces, ECFFT trees, the prover's vectors) free on the device right now -- both SRS vectors
+  // up to 2^21 constraints, the first one at 2^22; a third prover on the same device or a larger circuit gets the aligned
+  // windows and their W-row table on its own -- and an allocation failure falls back to the aligned windows as well.
   const uint64_t slide_bytes = (uint64_t)TAU_DIGITS * n_total * sizeof(Aff);
   const long long mode = tune().msm_slide;
   bool slide = false;
   if ((uint64_t)TAU_DIGITS * n_total < 0xfffffff0ull && mode != 0) {
     size_t free_b = 0, total_b = 0;
-    slide = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes <= (uint64_t)(0.4 * (double)free_b));
+    slide = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes + (uint64_t)total_b / 4 <= (uint64_t)free_b);
   }
   hipError_t alloc_err = hipSuccess;
   int rc = msm_fixed_build(d_bases, n_total, range_hint, slide, out, &alloc_err);
