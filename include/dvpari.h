@@ -151,8 +151,8 @@ void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
 int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
 /* HBM held by the context's pre-rotated table.  Two flavours: aligned windows keep W ~ 14 rotations of every base
  * (0.9 KB per base); sliding windows keep all 240 (15 KB per base: 64 GB for the 4m bases of a 2^20-constraint prover)
- * and need ~8 % fewer bucket additions.  The sliding table is chosen when it fits in 40 % of the device memory that is
- * free when the context is built (DVP_MSM_SLIDE = 1 / 0 forces it on / off); *sliding reports which one this is. */
+ * and need ~8 % fewer bucket additions.  The sliding table is chosen when it leaves a quarter of the device memory
+ * free at the moment the context is built (DVP_MSM_SLIDE = 1 / 0 forces it on / off); *sliding reports which one this is. */
 uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
