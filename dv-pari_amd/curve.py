@@ -115,7 +115,7 @@ class FixedBaseMsm:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # lib is None while the interpreter shuts down
             lib.dvp_msm_ctx_destroy(self._h)
             self._h = None
 
