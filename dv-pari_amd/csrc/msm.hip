@@ -114,8 +114,13 @@ static int slide_slots(int c) {
   return best;
 }
 __global__ void __launch_bounds__(256)
-k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int slots,
-               uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
+k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, const uint8_t* __restrict__ width_tab,
+               int slots, uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
+  // width_tab[R] = slide_window_width(R, c) for R <= TAU_DIGITS (two integer divisions per window otherwise: they cost
+  // more than the rest of the window loop)
+  __shared__ uint8_t wtab[256];
+  wtab[threadIdx.x] = width_tab[threadIdx.x];
+  __syncthreads();
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[8];
@@ -171,7 +176,7 @@ k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__
     const int z = __ffs(d[0]) - 1;
     shr(z);
     pos += z;
-    const int width = slide_window_width(len - pos, c);  // >= 1 digits are left, the lowest of them is 1
+    const int width = wtab[len - pos];  // >= 1 digits are left, the lowest of them is 1
     const uint32_t v = d[0] & ((1u << width) - 1);
     if (slot < slots) words[(size_t)slot * n + i] = FXW_VALID | ((uint32_t)pos << FXW_ROW_SHIFT) | (v >> 1);
     else atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: slots = slide_slots(c)
@@ -1114,6 +1119,7 @@ struct MsmFixedCtx {
   // sliding-window mode (k_recode_slide): the table holds all TAU_DIGITS rotations, W = entry slots per scalar, keys are
   // the odd c-digit patterns (c - 1 key bits)
   bool slide = false;
+  uint8_t* width_tab = nullptr;  // device, 256 entries: slide_window_width(R, c)
   void set_c_slide(int cc) {
     c = cc;
     n_narrow = 0;
@@ -1293,7 +1299,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const bool slide = fx && fx->slide;
   if (slide)
     hipLaunchKernelGGL(k_recode_slide, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
-                       p.c, p.W, digits32, err);
+                       fx->width_tab, p.W, digits32, err);
   else if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
                        (uint32_t)n, p.c, p.W, p.n_narrow, digits32, err);
@@ -1502,6 +1508,12 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
   if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && kb - h <= 15 && kb - h >= 1) c->hi_bits = h;
   hipError_t e = hipMalloc((void**)&c->table, (size_t)c->rows() * n_total * sizeof(Aff));
   *alloc_err = e;
+  if (e == hipSuccess && slide) {
+    uint8_t wt[256] = {0};
+    for (int R = 1; R <= TAU_DIGITS; ++R) wt[R] = (uint8_t)slide_window_width(R, c->c);
+    e = hipMalloc((void**)&c->width_tab, sizeof(wt));
+    if (e == hipSuccess) e = hipMemcpy(c->width_tab, wt, sizeof(wt), hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) {
     if (slide)
       hipLaunchKernelGGL(k_frob_table_all, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->rows(), c->table);
@@ -1555,6 +1567,7 @@ uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* sliding) {
 void msm_fixed_destroy(MsmFixedCtx* c) {
   if (!c) return;
   if (c->table) (void)hipFree(c->table);
+  if (c->width_tab) (void)hipFree(c->width_tab);
   delete c;
 }
 // partial sum over bases [lo, hi) of the context; d_scalars / d_inf point at element lo
