@@ -9,6 +9,9 @@
 //              Because the window multipliers are powers of tau, the final combination uses the
 //              Frobenius (3 squarings) where an integer-window Pippenger needs doublings -- on a
 //              GPU that turns a ~230-step serial doubling chain into a log-depth tree.
+//              Fixed-base contexts (the prover's SRS vectors) pre-rotate the bases so that all windows share ONE bucket
+//              set, and -- when HBM allows the 240-rotation table -- let a window start at any nonzero digit (sliding
+//              windows: odd patterns only, ~8 % fewer entries; k_recode_slide, MsmFixedCtx).
 //  2. sort     counting sort of (key, point index): histogram (atomics) -> scan -> scatter.
 //  3. reduce   segmented sum per key by fixed fan-in K: level 1 gathers affine bases and does mixed
 //              Lopez-Dahab additions; further levels add projective partials.  Tasks never span
