@@ -222,7 +222,7 @@ def main():
     adds_per_launch = pairs_per_launch * w_eff * 0.5
     mul_eq = adds_per_launch * per_add
     roof = {
-        "kernel": "dvp::k_affine_round (first pair round of each MSM)",
+        "kernel": "dvp::k_affine_round<true> (first pair round of each MSM; the later rounds are k_affine_round<false>)",
         "bound": "valu",
         "bound_note": "integer VALU + LDS issue (GF(2^233) products without a carry-less multiplier); HBM and MFMA are not the limit -- "
                       "achieved/peak/frac below is the algorithmic-bytes figure against HBM that the metric contract asks for",

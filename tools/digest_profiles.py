@@ -44,7 +44,7 @@ def round0_dispatches(dirname):
     ids = sorted(disp)
     out = []
     for a, b in zip(ids, ids[1:]):
-        if "k_round_desc<true" in disp[a]["name"] and "k_affine_round" in disp[b]["name"]:
+        if "k_round_desc<true" in disp[a]["name"] and "k_affine_round<true>" in disp[b]["name"]:
             out.append(disp[b])
     assert out, dirname
     return out
@@ -60,7 +60,7 @@ b = last_json_line(os.path.join(SRC, "bench.json"))
 alg = b["roofline"]["algorithmic_bytes_per_launch"]
 f_kb, w_kb = avg(fetch, "FETCH_SIZE"), avg(write, "WRITE_SIZE")
 traffic = {
-    "kernel": "dvp::k_affine_round, first pair round of each MSM (the launches that follow k_round_desc<true, ..>)",
+    "kernel": "dvp::k_affine_round<true>, first pair round of each MSM (the launches that follow k_round_desc<true, ..>)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, counters + --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
     "launches": len(fetch),
     "avg_FETCH_SIZE_KB": f_kb,
