@@ -1635,6 +1635,38 @@ extern "C" int dvp_ubench_gf_mul(int reps, double* products_per_s) {
   return DVP_OK;
 }
 
+// Parity-test access to the sliding-window recode alone (the counterpart of dvp_prover_debug_read for the MSM): entry
+// words of n canonical scalars for window size c, out_words[slot * n + i] = 0 (empty) or
+// 0x80000000 | position << 20 | pattern >> 1; *slots = entry slots per scalar (out_words holds *slots * n words; pass
+// out_words = NULL to query *slots).
+extern "C" int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots) {
+  if (!slots || c < 8 || c > FX_C_MAX + 1 || n > (1u << 24)) return DVP_EINVAL;
+  *slots = slide_slots(c);
+  if (!out_words) return DVP_OK;
+  if (!scalars || !n) return DVP_EINVAL;
+  uint8_t wt[256] = {0};
+  for (int R = 1; R <= TAU_DIGITS; ++R) wt[R] = (uint8_t)slide_window_width(R, c);
+  DevBuf ds, dw, dt, de;
+  DVP_TRY(ds.alloc(n * 32));
+  DVP_TRY(dw.alloc((size_t)*slots * n * 4));
+  DVP_TRY(dt.alloc(sizeof(wt)));
+  DVP_TRY(de.alloc(8));
+  DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  DVP_HIP(hipMemcpy(dt.p, wt, sizeof(wt), hipMemcpyHostToDevice));
+  DVP_HIP(hipMemset(de.p, 0xff, 8));
+  hipLaunchKernelGGL(k_recode_slide, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
+                     *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*slots * n * 4, hipMemcpyDeviceToHost));
+  unsigned long long e = 0;
+  DVP_HIP(hipMemcpy(&e, de.p, 8, hipMemcpyDeviceToHost));
+  if (e != ~0ull) {
+    g_last_error_index = (int64_t)(e & 0xffffffffull);
+    return DVP_EINVAL;
+  }
+  return DVP_OK;
+}
+
 extern "C" int dvp_msm_affine(const uint64_t* scalars, const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n,
                               uint64_t out_xy[8], int* out_is_infinity) {
   if ((n && (!scalars || !bases_xy)) || !out_xy || !out_is_infinity) return DVP_EINVAL;

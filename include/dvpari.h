@@ -154,6 +154,10 @@ int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
  * and need ~8 % fewer bucket additions.  The sliding table is chosen when it leaves a quarter of the device memory
  * free at the moment the context is built (DVP_MSM_SLIDE = 1 / 0 forces it on / off); *sliding reports which one this is. */
 uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
+/* parity-test access to the sliding-window recode alone: entry words of n canonical scalars for window size c (8..21),
+ * out_words[slot * n + i] = 0 (empty slot) or 0x80000000 | first digit position << 20 | odd pattern >> 1;
+ * *slots = entry slots per scalar (out_words must hold *slots * n words; out_words = NULL only queries *slots). */
+int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 /* same seam with the reference's own wire formats: scalars n x 32 B canonical LE, bases n x 30 B

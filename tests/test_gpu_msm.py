@@ -11,7 +11,7 @@ import pytest
 
 import pyref as o
 import c_oracle as co
-from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast, tau_adversarial_scalars
+from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast, tau_adversarial_scalars, slide_slots
 
 pytestmark = pytest.mark.gpu
 OSSL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k233_openssl.json")))["vectors"]
@@ -223,21 +223,6 @@ def test_msm_full_size_dlog_and_linearity(dvp, log_n):
     fb.close()
 
 
-def slide_slots(c):
-    """entry slots per scalar of the sliding-window recode (msm.hip: slide_window_width / slide_slots)"""
-    def width(R):
-        k = (R + 1 + c) // (c + 1)
-        return min(R, c) if k <= 1 else min((R + k) // k - 1, R)
-    best = 0
-    for length in range(1, 241):
-        cnt, R = 0, length
-        while R > 0:
-            R -= width(R)
-            cnt += 1
-        best = max(best, cnt)
-    return best
-
-
 def test_fixed_base_vs_one_shot_randomised(dvp):
     """differential sweep: every fixed-base window size 8..20 of the aligned and 8..21 of the sliding windows (both sort
     flavours, 4/8/16-slot pair rounds) against the one-shot path on random sub-ranges, plus scalars with long runs of
@@ -300,3 +285,49 @@ def test_one_shot_randomised_shapes_and_knobs(dvp):
                      DVP_MSM_AFF_MIN=rnd.choice([1, 64, 1 << 19]), DVP_MSM_PROJ=int(trial % 7 == 6), DVP_MSM_AFF_BMAX=rnd.choice([1, 5, 48]))
         with dvp.tune(**knobs):
             assert gpu_msm(dvp, to_limbs(sv), bases[lo:lo + n], inf) == exp, (trial, n, knobs)
+
+
+@pytest.mark.parametrize("c", [8, 13, 19, 20, 21])
+def test_sliding_recode_words_vs_restatement(dvp, c):
+    """k_recode_slide word for word: the entries of random and adversarial scalars (i) are disjoint windows that
+    reassemble to a {0,1}-digit expansion whose value sum d_j tau^j is the scalar (tau acts on the group as the root
+    lambda of x^2 + x + 2 mod r), (ii) are exactly what the window rule restated in tests/util.py cuts out of that
+    expansion, slot count and empty slots included, and (iii) for scalars away from the rounding boundaries of the
+    partial reduction the expansion is the C oracle's, digit for digit (on a boundary the GPU's fixed-point quotient may
+    pick the neighbouring representative modulo delta: another valid expansion of the same scalar)"""
+    import ctypes as C
+    from util import slide_windows, TAU_D0, TAU_D1
+    lam = (-TAU_D0 * pow(TAU_D1, -1, o.P)) % o.P
+    assert (lam * lam + lam + 2) % o.P == 0
+    probe = list(co.tau_digits(12345))
+    if sum(d * pow(lam, j, o.P) for j, d in enumerate(probe)) % o.P != 12345:
+        lam = (-1 - lam) % o.P                      # the other root of x^2 + x + 2: the one tau acts as
+    assert sum(d * pow(lam, j, o.P) for j, d in enumerate(probe)) % o.P == 12345
+    rnd = random.Random(300 + c)
+    adv = tau_adversarial_scalars()[:200]
+    vals = [0, 1, 2, 3, o.P - 1, (1 << 231) - 1, 1 << 230] + adv + [rnd.randrange(o.P) for _ in range(1500)]
+    s = to_limbs(vals)
+    slots = C.c_int(0)
+    dvp.check(dvp.lib.dvp_debug_recode_slide(None, 0, c, None, C.byref(slots)), "slots")
+    assert slots.value == slide_slots(c)
+    words = np.zeros((slots.value, len(vals)), dtype=np.uint32)
+    dvp.check(dvp.lib.dvp_debug_recode_slide(s.ctypes.data, len(vals), c, words.ctypes.data, C.byref(slots)), "recode")
+    same_as_oracle = 0
+    for i, x in enumerate(vals):
+        got = [(int(w >> 20) & 0xFF, 2 * int(w & 0xFFFFF) + 1) for w in words[:, i] if w]
+        assert all(int(w) >> 31 for w in words[: len(got), i]) and not words[len(got):, i].any()
+        digits, end, value = [0] * 262, 0, 0
+        for pos, v in got:
+            assert pos >= end and v < (1 << c)
+            for t in range(c):
+                digits[pos + t] = (v >> t) & 1
+            end = pos + v.bit_length()
+            value = (value + sum(((v >> t) & 1) * pow(lam, pos + t, o.P) for t in range(c))) % o.P
+        assert end <= 240 and value == x % o.P, (c, i, hex(x))
+        assert slide_windows(digits, c) == got, (c, i, hex(x))
+        ref = list(co.tau_digits(x))
+        same = digits[: max(len(ref), end)] == (ref + [0] * 262)[: max(len(ref), end)]
+        same_as_oracle += same
+        if i >= 7 + len(adv):
+            assert same, (c, i, hex(x))
+    assert same_as_oracle >= len(vals) - len(adv)
