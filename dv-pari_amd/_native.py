@@ -90,6 +90,8 @@ _SIGS = {
     "dvp_prover_msm_table_bytes": (C.c_uint64, [vp, C.c_int, C.POINTER(C.c_int)]),
     "dvp_prover_msm_partial": (C.c_int, [vp, C.c_int, sz, sz, vp, vp, vp]),
     "dvp_prove_challenge": (C.c_int, [vp, vp, vp, vp]),
+    "dvp_prove_challenge_partial": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, vp, vp]),
+    "dvp_prove_challenge_finish": (C.c_int, [vp, vp, C.c_uint32, C.c_size_t, C.c_size_t, vp]),
     "dvp_prove_finish": (C.c_int, [vp, vp, vp, u8p, vp]),
     "dvp_prover_debug_read": (C.c_int, [vp, C.c_char_p, u64p, sz]),
     "dvp_prover_domains": (C.c_int, [vp, u64p, u64p]),

@@ -17,6 +17,7 @@
 // 1/Z_D on D' -- are regenerated on the device from the isogeny chain (k_domain_tables), so neither
 // z_poly nor the FFTR tree cache is needed.
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -221,6 +222,109 @@ k_kscalars(const Fr* __restrict__ E, const Fr* __restrict__ r2, const Fr* __rest
   S[2 * (size_t)m + 2 * (size_t)i + 1] = fr_mul(di2, fr_sub(r2[i], r0));
 }
 
+// ---- index-sharded challenge phase (pointwise / barycentric row): every stage below works on a slice ----
+// den[i] = dom[i] - alpha for i in [lo, hi) of ONE domain (canonical); flags alpha in that slice of the domain
+__global__ void __launch_bounds__(256)
+k_alpha_denoms_range(const Fr* __restrict__ dom_m, Fr alpha_m, uint32_t lo, uint32_t hi, Fr* __restrict__ den, unsigned long long* __restrict__ hit) {
+  uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hi) return;
+  Fr x = fr_sub(dom_m[i], alpha_m);
+  if (fr_is_zero(x)) atomicMin(hit, (unsigned long long)i);
+  den[i] = fr_from_mont(x);
+}
+// the partial sums of k_bary3_partial over [lo, hi) only
+__global__ void __launch_bounds__(256)
+k_bary3_partial_range(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, const Fr* __restrict__ dinv, uint32_t m, uint32_t lo,
+                      uint32_t hi, Fr* __restrict__ partial /* [3][nb] Montgomery */) {
+  __shared__ Fr sh[256];
+  Fr s[3] = {fr_zero(), fr_zero(), fr_zero()};
+  for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
+    Fr k = fr_mul(barw_m[i], fr_to_mont(dinv[i]));
+    s[0] = fr_add(s[0], fr_mul(k, fr_to_mont(E[i])));
+    s[1] = fr_add(s[1], fr_mul(k, fr_to_mont(E[(size_t)m + i])));
+    s[2] = fr_add(s[2], fr_mul(k, fr_to_mont(E[3 * (size_t)m + i])));
+  }
+  for (int v = 0; v < 3; ++v) {
+    sh[threadIdx.x] = s[v];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = sh[0];
+    __syncthreads();
+  }
+}
+// block partials -> one 128-byte record: 3 Montgomery sums (this rank's share of sum y w / (d - alpha), y in {a, b, i}),
+// then the rank's alpha-in-domain flag
+__global__ void __launch_bounds__(256)
+k_bary3_record(const Fr* __restrict__ partial, uint32_t nb, const unsigned long long* __restrict__ hit, Fr* __restrict__ rec) {
+  __shared__ Fr sh[256];
+  for (int v = 0; v < 3; ++v) {
+    Fr s = fr_zero();
+    for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[(size_t)v * nb + i]);
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) rec[v] = sh[0];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Fr f = fr_zero();
+    const unsigned long long h = *hit;
+    f.v[0] = (uint32_t)h;
+    f.v[1] = (uint32_t)(h >> 32);
+    rec[3] = f;
+  }
+}
+// n gathered records -> a0, b0, i0, r0 (what k_bary3_final does with block partials) and the combined flag
+__global__ void __launch_bounds__(64)
+k_bary3_from_records(const Fr* __restrict__ recs /* n x 4 Fr */, uint32_t n, Fr neg_z_alpha_m, Fr* __restrict__ out,
+                     unsigned long long* __restrict__ hit) {
+  if (threadIdx.x != 0) return;
+  Fr res[3];
+  unsigned long long h = ~0ull;
+  for (int v = 0; v < 3; ++v) {
+    Fr s = fr_zero();
+    for (uint32_t r = 0; r < n; ++r) s = fr_add(s, recs[(size_t)r * 4 + v]);
+    res[v] = fr_mul(s, neg_z_alpha_m);
+  }
+  for (uint32_t r = 0; r < n; ++r) {
+    const Fr& f = recs[(size_t)r * 4 + 3];
+    h = min(h, (unsigned long long)f.v[0] | ((unsigned long long)f.v[1] << 32));
+  }
+  out[0] = fr_from_mont(res[0]);
+  out[1] = fr_from_mont(res[1]);
+  out[2] = fr_from_mont(res[2]);
+  out[3] = fr_from_mont(fr_sub(fr_mul(res[0], res[1]), res[2]));
+  *hit = h;
+}
+// S[k] for k in [k_lo, k_hi) of S = [k_a | k_b | k_r] (k_kscalars restricted to a range of the OUTPUT index)
+__global__ void __launch_bounds__(256)
+k_kscalars_range(const Fr* __restrict__ E, const Fr* __restrict__ r2, const Fr* __restrict__ dinv, const Fr* __restrict__ dinv2,
+                 const Fr* __restrict__ abir0, uint32_t m, size_t k_lo, size_t k_hi, Fr* __restrict__ S) {
+  size_t k = k_lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= k_hi) return;
+  if (k < m) {
+    S[k] = fr_mul(fr_to_mont(dinv[k]), fr_sub(E[k], abir0[0]));
+  } else if (k < 2 * (size_t)m) {
+    size_t i = k - m;
+    S[k] = fr_mul(fr_to_mont(dinv[i]), fr_sub(E[(size_t)m + i], abir0[1]));
+  } else {
+    size_t j = k - 2 * (size_t)m, i = j >> 1;
+    Fr r0 = abir0[3];
+    if (j & 1) {
+      S[k] = fr_mul(fr_to_mont(dinv2[i]), fr_sub(r2[i], r0));
+    } else {
+      Fr r = fr_sub(fr_mul(fr_to_mont(E[i]), E[(size_t)m + i]), E[3 * (size_t)m + i]);
+      S[k] = fr_mul(fr_to_mont(dinv[i]), fr_sub(r, r0));
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_to_mont_vec(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = fr_to_mont(in[i]);
@@ -287,6 +391,7 @@ struct dvp_prover {
   Fr ctop_host[2];                      // layer log_m leaves (collapse points of D, D'), Montgomery
   // last-proof intermediates kept for parity tests
   Fr alpha_canon, abir0_host[4];
+  Fr neg_z_alpha_m;  // -Z_D(alpha), kept between dvp_prove_challenge_partial and dvp_prove_challenge_finish
   std::vector<uint64_t> pub_host;
   uint8_t commit_p_host[30];
   uint8_t* fin_host = nullptr;  // pinned mirror of the device block [abir0 | flags | enc]
@@ -834,6 +939,85 @@ extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const
   return DVP_OK;
 }
 
+// ---- phase 2 for index-sharded provers (one process per GPU; SURVEY 8e "pointwise / batch-inverse / barycentric": slice by
+// index, all-gather of the partial Fr sums + local add, batch inversion per shard) ------------------------------------------
+// part 1: alpha from the commitment; 1/(d - alpha) only where this rank needs it -- its slice [d_lo, d_hi) of the barycentric
+// sums and the part of D / D' its K-scalar range [k_lo, k_hi) reads -- and the rank's 128-byte record: three partial sums
+// (Montgomery) + its alpha-in-domain flag.  part 2 (after the ranks exchanged their records, any order): a0 b0 i0 r0 from
+// the n records, then the K scalars of [k_lo, k_hi) only.  dvp_prove_challenge == part 1 over everything + part 2 on the own
+// record; the rest of S and of den / den2 is NOT valid on this prover afterwards.
+extern "C" int dvp_prove_challenge_partial(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, size_t d_lo, size_t d_hi,
+                                           size_t k_lo, size_t k_hi, void* d_record_out, void* stream) {
+  if (!p || !d_commit_xy || !d_commit_inf || !d_record_out) return DVP_EINVAL;
+  const uint32_t m = p->m;
+  if (d_lo > d_hi || d_hi > m || k_lo > k_hi || k_hi > 4 * (size_t)m) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 bt(PT);
+  if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
+  if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
+  DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  uint8_t ch[32];
+  transcript_challenge(p->commit_p_host, p->pub_host.data(), p->n_pub, ch);
+  Fr alpha;
+  memcpy(alpha.v, ch, 32);
+  p->alpha_canon = alpha;
+  const Fr alpha_m = fr_to_mont(alpha);
+  p->neg_z_alpha_m = fr_neg(host_vanish(p, 0, alpha_m));
+  // index intervals of D whose inverse denominators this rank reads: its barycentric slice, k_a, k_b and the even half of
+  // k_r ([D_i, D'_i] interleaved); of D': the odd half of k_r.  Overlaps are merged (inverting twice would undo it).
+  std::vector<std::pair<size_t, size_t>> iv;
+  auto clip = [&](size_t a, size_t b, size_t base) {  // [k_lo, k_hi) n [a, b), rebased
+    size_t lo = std::max(k_lo, a), hi = std::min(k_hi, b);
+    return lo < hi ? std::make_pair(lo - base, hi - base) : std::make_pair((size_t)0, (size_t)0);
+  };
+  iv.push_back({d_lo, d_hi});
+  iv.push_back(clip(0, m, 0));
+  iv.push_back(clip(m, 2 * (size_t)m, m));
+  std::pair<size_t, size_t> kr = clip(2 * (size_t)m, 4 * (size_t)m, 2 * (size_t)m);
+  std::pair<size_t, size_t> kri = {kr.first >> 1, (kr.second + 1) >> 1};
+  if (kr.first == kr.second) kri = {0, 0};
+  iv.push_back(kri);
+  std::sort(iv.begin(), iv.end());
+  std::vector<std::pair<size_t, size_t>> merged;
+  for (auto& x : iv) {
+    if (x.first == x.second) continue;
+    if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
+    else merged.push_back(x);
+  }
+  for (auto& x : merged) {
+    const uint32_t cnt = (uint32_t)(x.second - x.first);
+    hipLaunchKernelGGL(k_alpha_denoms_range, dim3(cdiv(cnt, PT)), bt, 0, st, p->dD, alpha_m, (uint32_t)x.first, (uint32_t)x.second, p->den, p->flags + 1);
+    DVP_TRY(batch_inverse_dev(p->den + x.first, cnt, st));
+  }
+  if (kri.first < kri.second) {
+    const uint32_t cnt = (uint32_t)(kri.second - kri.first);
+    hipLaunchKernelGGL(k_alpha_denoms_range, dim3(cdiv(cnt, PT)), bt, 0, st, p->dD2, alpha_m, (uint32_t)kri.first, (uint32_t)kri.second, p->den2, p->flags + 1);
+    DVP_TRY(batch_inverse_dev(p->den2 + kri.first, cnt, st));
+  }
+  uint32_t nb = 0;
+  if (d_lo < d_hi) {
+    nb = cdiv((uint32_t)(d_hi - d_lo), PT);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_bary3_partial_range, dim3(nb), bt, 0, st, p->E, p->barw, p->den, m, (uint32_t)d_lo, (uint32_t)d_hi, p->partial);
+  }
+  hipLaunchKernelGGL(k_bary3_record, dim3(1), bt, 0, st, p->partial, nb, p->flags + 1, (Fr*)d_record_out);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+extern "C" int dvp_prove_challenge_finish(dvp_prover* p, const void* d_records, uint32_t n_records, size_t k_lo, size_t k_hi, void* stream) {
+  if (!p || !d_records || !n_records) return DVP_EINVAL;
+  const uint32_t m = p->m;
+  if (k_lo > k_hi || k_hi > 4 * (size_t)m) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bary3_from_records, dim3(1), dim3(64), 0, st, (const Fr*)d_records, n_records, p->neg_z_alpha_m, p->abir0, p->flags + 1);
+  if (k_lo < k_hi)
+    hipLaunchKernelGGL(k_kscalars_range, dim3(cdiv(k_hi - k_lo, PT)), dim3(PT), 0, st, p->E, p->r2, p->den, p->den2, p->abir0, m, k_lo, k_hi, p->SK);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+
 // phase 3 (src/proving.rs:682-687): kzg_k -> bytes; proof = commit_p | kzg_k | a0 | b0.
 extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream) {
   if (!p || !d_kzg_xy || !d_kzg_inf || !proof) return DVP_EINVAL;
@@ -906,7 +1090,8 @@ extern "C" int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* 
   else if (s == "a0" || s == "b0" || s == "i0" || s == "r0") {
     if (n_elems != 1) return DVP_EINVAL;
     int k = s == "a0" ? 0 : s == "b0" ? 1 : s == "i0" ? 2 : 3;
-    memcpy(out, p->abir0_host[k].v, 32);
+    DVP_HIP(hipDeviceSynchronize());  // straight from the device: valid after the challenge phase, before finish
+    DVP_HIP(hipMemcpy(out, p->abir0 + k, 32, hipMemcpyDeviceToHost));
     return DVP_OK;
   } else return DVP_EINVAL;
   if (n_elems != n) return DVP_EINVAL;

@@ -9,6 +9,10 @@ ECFFT extends and take a larger share of the MSM work in exchange.  RCCL has no 
 so "all-reduce of partial bucket sums" is realised as all-gather + local add; the message is
 latency-bound (<= 640 B on 8 GPUs), xGMI bandwidth is irrelevant here.
 
+The challenge phase between the two MSMs is sharded by index as well: each rank inverts 1/(d - alpha) only where it
+needs it, sums its slice of the three barycentric sums, the ranks all-gather 128-byte records (partial sums + the
+alpha-in-domain flag), and each rank then forms only the K scalars of its own MSM range.
+
 The GPU work is injected through `backend` so the orchestration is testable on CPU with gloo
 (tests/test_distributed_cpu.py uses an oracle-backed backend)."""
 from dataclasses import dataclass
@@ -103,6 +107,18 @@ class GpuBackend:
     def challenge(self, point):
         self.prover.challenge(point.data_ptr(), point.data_ptr() + 64, self.torch.cuda.current_stream().cuda_stream)
 
+    def challenge_partial(self, point, d_range, k_range):
+        """this rank's share of the challenge phase -> its 128-byte record (16 int64 words) for the all-gather"""
+        if getattr(self, "rec", None) is None:
+            self.rec = self.torch.zeros(16, dtype=self.torch.int64, device=self.device)
+        self.prover.challenge_partial(point.data_ptr(), point.data_ptr() + 64, d_range, k_range, self.rec.data_ptr(),
+                                      self.torch.cuda.current_stream().cuda_stream)
+        return self.rec
+
+    def challenge_finish(self, gathered, k_range):
+        g = gathered.contiguous()
+        self.prover.challenge_finish(g.data_ptr(), g.shape[0], k_range, self.torch.cuda.current_stream().cuda_stream)
+
     def finish(self, point):
         return self.prover.finish(point.data_ptr(), point.data_ptr() + 64, self.torch.cuda.current_stream().cuda_stream)
 
@@ -150,7 +166,13 @@ def prove_sharded(backend, assignment, group=None):
         else:
             point = part
         if which == 0:
-            backend.challenge(point)
+            if world > 1 and hasattr(backend, "challenge_partial"):
+                # pointwise stages, batch inversions and barycentric sums by index: every rank sums its slice
+                # of D, one all-gather of 128-byte records, then only the K scalars of its own MSM range
+                rec = backend.challenge_partial(point, shard_range(m, rank, world), range_b)
+                backend.challenge_finish(_all_gather_records(rec, world, group), range_b)
+            else:
+                backend.challenge(point)
         else:
             proof = backend.finish(point)
     return proof

@@ -236,6 +236,16 @@ class Prover:
     def challenge(self, d_commit_xy: int, d_commit_inf: int, stream: int = 0):
         check(lib.dvp_prove_challenge(self._h, d_commit_xy, d_commit_inf, stream), "dvp_prove_challenge")
 
+    def challenge_partial(self, d_commit_xy: int, d_commit_inf: int, d_range, k_range, d_record: int, stream: int = 0):
+        """phase 2, part 1 of an index-sharded prove: this rank's slice of the barycentric sums (d_range of D) and the inverse
+        denominators its K-scalar range needs -> a 128-byte record at d_record (dvp_prove_challenge_partial)"""
+        check(lib.dvp_prove_challenge_partial(self._h, d_commit_xy, d_commit_inf, d_range[0], d_range[1], k_range[0], k_range[1], d_record, stream),
+              "dvp_prove_challenge_partial")
+
+    def challenge_finish(self, d_records: int, n_records: int, k_range, stream: int = 0):
+        """part 2: a0 b0 i0 r0 from the records of all ranks, then the K scalars of k_range only"""
+        check(lib.dvp_prove_challenge_finish(self._h, d_records, n_records, k_range[0], k_range[1], stream), "dvp_prove_challenge_finish")
+
     def finish(self, d_kzg_xy: int, d_kzg_inf: int, stream: int = 0) -> Proof:
         out = np.zeros(118, dtype=np.uint8)
         check(lib.dvp_prove_finish(self._h, d_kzg_xy, d_kzg_inf, ptr(out), stream), "dvp_prove_finish")

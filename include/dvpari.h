@@ -220,6 +220,16 @@ int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* window
 uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, int* sliding);
 int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream);
+/* The same phase for provers that share one proof by INDEX (one process per GPU): the pointwise stages, the batch
+ * inversions and the barycentric sums (src/proving.rs:561-654) are computed only where this rank needs them.
+ * part 1: alpha from the commitment, 1/(d - alpha) on this rank's slice [d_lo, d_hi) of D (its share of the three
+ *   barycentric sums) and on the part of D / D' that its K-scalar range [k_lo, k_hi) of [k_a | k_b | k_r] reads;
+ *   d_record_out receives a 128-byte record (three partial sums + the rank's alpha-in-domain flag).
+ * part 2: d_records = the n records of all ranks (all-gathered, any order; the slices must partition [0, m)):
+ *   a0 b0 i0 r0, then the K scalars of [k_lo, k_hi) only -- the only range dvp_prover_msm_partial(1, ..) may then cover. */
+int dvp_prove_challenge_partial(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, size_t d_lo, size_t d_hi,
+                                size_t k_lo, size_t k_hi, void* d_record_out, void* stream);
+int dvp_prove_challenge_finish(dvp_prover* p, const void* d_records, uint32_t n_records, size_t k_lo, size_t k_hi, void* stream);
 int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream);
 /* intermediates of the last proof, for parity tests (names: see prove.hip) */
 int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);

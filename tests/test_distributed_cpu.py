@@ -97,6 +97,37 @@ def _worker(rank, world, port, q):
         def challenge(self, point):
             self.commit = unpack(point)
 
+        # the challenge phase sharded by index (distributed.prove_sharded uses it when world > 1): this rank's slice of the
+        # three barycentric sums as a 128-byte record, then -- from the records of all ranks -- a0 b0 i0, which must equal the
+        # oracle's, and only the K scalars of the rank's own MSM range (everything else poisoned)
+        def challenge_partial(self, point, d_range, k_range):
+            self.commit = unpack(point)
+            tb = st["tables"]
+            alpha = self.pr["alpha"]
+            sums = []
+            for y in (self.pr["a"], self.pr["b"], self.pr["i"]):
+                acc = 0
+                for i in range(d_range[0], d_range[1]):
+                    acc = (acc + y[i] * tb["bar_wts"][i] % o.P * o.fr_inv((alpha - tb["D"][i]) % o.P)) % o.P
+                sums.append(acc)
+            rec = torch.zeros(16, dtype=torch.int64)
+            rec[:12] = torch.from_numpy(to_limbs(sums).reshape(-1).view(np.int64))
+            rec[12] = -1  # alpha-in-domain flag: none
+            return rec
+
+        def challenge_finish(self, gathered, k_range):
+            assert gathered.shape == (world, 16) and all(int(row[12]) == -1 for row in gathered)
+            tot = [0, 0, 0]
+            for row in gathered:
+                limbs = row[:12].numpy().view(np.uint64).reshape(3, 4)
+                for v in range(3):
+                    tot[v] = (tot[v] + sum(int(limbs[v][k]) << (64 * k) for k in range(4))) % o.P
+            z = self.pr["z_alpha"]
+            assert [t * z % o.P for t in tot] == [self.pr["a0"], self.pr["b0"], self.pr["i0"]]
+            lo, hi = k_range
+            self.sc[1] = [s if lo <= k < hi else 999 for k, s in enumerate(self.sc[1])]
+            self.sharded_challenge = True
+
         def finish(self, point):
             return (co.xsk233_encode(self.commit), co.xsk233_encode(unpack(point)), self.pr["a0"], self.pr["b0"])
 
@@ -105,7 +136,7 @@ def _worker(rank, world, port, q):
     proof = dist_mod.prove_sharded(be, assignment)
     exp_commit = co.xsk233_encode(co.k233_mulgen(be.pr["dl_commit_p"]))
     exp_kzg = co.xsk233_encode(co.k233_mulgen(be.pr["dl_kzg"]))
-    ok = proof[0] == exp_commit and proof[1] == exp_kzg
+    ok = proof[0] == exp_commit and proof[1] == exp_kzg and getattr(be, "sharded_challenge", False)
     q.put((rank, ok, proof[0].hex()))
     dist.destroy_process_group()
 

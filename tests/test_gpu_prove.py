@@ -212,6 +212,56 @@ def test_sharded_prove_simulated_ranks(dvp, world):
     assert proof == ref and dvp.srs.verify(td, pub, proof)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_challenge_simulated_ranks(dvp, world):
+    """The challenge phase sharded by index (dvp_prove_challenge_partial / _finish): every simulated rank
+    inverts 1/(d - alpha) only on its slice of D and where its K-scalar range needs it, sums its slice of the three
+    barycentric sums into a 128-byte record, the records are stacked as the all-gather would, and each rank forms only the K
+    scalars of its own MSM range -- every rank on its own fresh prover, whose S, den and den2 hold nothing outside the
+    rank's share, so a read outside it changes the result.  a0 b0 i0 r0 must equal the unsharded values on every rank and the proof must be
+    byte-identical to the single-GPU proof."""
+    import torch
+
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(12)
+    rnd = random.Random(78)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    ref = pv.prove(pub, prv)
+    exp_abir0 = [from_limbs(pv.debug(n))[0] for n in ("a0", "b0", "i0", "r0")]
+    dev = torch.device("cuda", 0)
+    n_wires, m = inst.n_wires, pv.m
+    plan = dvp.distributed.shard_plan(world, n_wires, m)
+    assignment = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
+    # one prover per simulated rank, as in a real run (each rank's den / S state is its own)
+    provers = []
+    for r in range(world):
+        q = dvp.proving.Prover(inst)
+        q.set_srs(dvp.srs.verifier_runs_setup(q, inst, td))
+        provers.append(dvp.distributed.GpuBackend(q, dev))
+    parts = []
+    for r, be in enumerate(provers):
+        (lo, hi), _, need = plan[r]
+        be.begin(assignment, need)
+        parts.append(be.msm_partial(0, lo, hi).clone())
+    commit = provers[0].combine(torch.stack(parts))
+    recs = []
+    for r, be in enumerate(provers):
+        rec = be.challenge_partial(commit, dvp.distributed.shard_range(m, r, world), plan[r][1])
+        recs.append(rec.clone())
+    gathered = torch.stack(recs)
+    parts = []
+    for r, be in enumerate(provers):
+        be.challenge_finish(gathered[torch.randperm(world)], plan[r][1])      # the order of the records does not matter
+        assert [from_limbs(be.prover.debug(n))[0] for n in ("a0", "b0", "i0", "r0")] == exp_abir0, r
+        lo, hi = plan[r][1]
+        parts.append(be.msm_partial(1, lo, hi).clone())
+    proof = provers[0].finish(provers[0].combine(torch.stack(parts)))
+    for be in provers:
+        be.prover.close()
+    assert proof == ref and dvp.srs.verify(td, pub, proof)
+
+
 def test_prove_2_20_full_size(dvp):
     """BASELINE config #4 at full size (2^20 constraints), oracle-backed (tests/fullsize.py): the domain and the SRS
     scalars are pinned on sampled indices by their definitions, commit_p / kzg_k by the discrete-log identity against

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase time of ONE rank of a W-way sharded prove, measured on a single GPU (projection of bench.py --gpus W:
-the ranks are symmetric, the exchange is one 80-byte all-gather per MSM).  python tools/shard_profile.py [log_m]"""
+the ranks are symmetric, the exchange is one 80-byte all-gather per MSM and one of 128 bytes in the challenge phase).  python tools/shard_profile.py [log_m]"""
 import importlib
 import os
 import sys
@@ -51,7 +51,14 @@ for world in [int(x) for x in os.environ.get("SHARD_WORLDS", "1,2,4,8").split(",
             ph = {}
             _, ph["begin"] = timed(lambda: be.begin(assignment, need))
             _, ph["msmA_part"] = timed(lambda: be.msm_partial(0, *range_a))
-            _, ph["challenge"] = timed(lambda: be.challenge(full_a))
+            if world > 1:  # the index-sharded challenge: own slice of the sums, (stand-in for the all-gather: the own record
+                # repeated -- the values do not matter for the timing), then the K scalars of the own range only
+                def chal():
+                    rec = be.challenge_partial(full_a, dvp.distributed.shard_range(be.dims()[1], rank, world), range_b)
+                    be.challenge_finish(torch.stack([rec] * world), range_b)
+                _, ph["challenge"] = timed(chal)
+            else:
+                _, ph["challenge"] = timed(lambda: be.challenge(full_a))
             _, ph["msmB_part"] = timed(lambda: be.msm_partial(1, *range_b))
             _, ph["finish"] = timed(lambda: be.finish(full_b))
             if rep:
