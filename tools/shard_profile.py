@@ -51,7 +51,7 @@ for world in [int(x) for x in os.environ.get("SHARD_WORLDS", "1,2,4,8").split(",
             ph = {}
             _, ph["begin"] = timed(lambda: be.begin(assignment, need))
             _, ph["msmA_part"] = timed(lambda: be.msm_partial(0, *range_a))
-            if world > 1:  # the index-sharded challenge: own slice of the sums, (stand-in for the all-gather: the own record
+            if world > 1 and os.environ.get("SHARD_CHALLENGE", "sharded") != "full":  # the index-sharded challenge: own slice of the sums, (stand-in for the all-gather: the own record
                 # repeated -- the values do not matter for the timing), then the K scalars of the own range only
                 def chal():
                     rec = be.challenge_partial(full_a, dvp.distributed.shard_range(be.dims()[1], rank, world), range_b)
