@@ -210,6 +210,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
   return incl - v;
 }
 
+// PAD2: every count is rounded up to even first (fixed-base sort: buckets then start at even positions of the sorted
+// item list, so the list read as uint2 pairs IS the first pair round's descriptor array, see k_pad_odd_buckets)
+template <bool PAD2>
 __global__ void __launch_bounds__(SCAN_TPB) k_scan_local(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                          uint32_t* __restrict__ bsum, uint32_t m) {
   __shared__ uint32_t sh[SCAN_TPB];
@@ -218,6 +221,7 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_local(const uint32_t* __restr
 #pragma unroll
   for (int k = 0; k < SCAN_EPT; ++k) {
     v[k] = (base + k < m) ? in[base + k] : 0;
+    if (PAD2) v[k] = (v[k] + 1u) & ~1u;
     s += v[k];
   }
   uint32_t tot;
@@ -276,9 +280,12 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_add(uint32_t* __restrict__ ou
 }
 
 // out[0..m) = exclusive scan of in[0..m); out[m] = total
-static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st) {
+static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st, bool pad2 = false) {
   uint32_t nb = cdiv(m, SCAN_BLK);
-  hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
+  if (pad2)
+    hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
+  else
+    hipLaunchKernelGGL(k_scan_local<false>, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
   hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
   hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
   DVP_HIP(hipGetLastError());
@@ -764,6 +771,26 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
 // slot k+2 and the operands of slot k+1 are in flight while slot k multiplies, so the random 64-byte gathers of the
 // bases (HBM misses in the first round: the pre-rotated table is 5 GB) are off the critical path.
 constexpr uint32_t AFF_NONE = 0xffffffffu;
+
+// Fixed-base mode: the sort lays every bucket out from an EVEN position of the item list (scan of the counts rounded up to
+// even); an odd bucket's spare slot gets AFF_NONE.  The list read as uint2 pairs is then exactly what k_round_desc<true>
+// would write for the first pair round -- (a, b) table indices, b = NONE for the odd leftover -- so that round needs no
+// descriptor kernel and no scan: its output offsets are the item offsets halved (k_round0_offsets).
+__global__ void __launch_bounds__(256)
+k_pad_odd_buckets(uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t nkeys) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nkeys) return;
+  const uint32_t c = cnt[k];
+  if (c & 1) items[off[k] + c] = AFF_NONE;
+}
+__global__ void __launch_bounds__(256)
+k_round0_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off /* nkeys + 1, even */, uint32_t nkeys,
+                 uint32_t* __restrict__ ocnt, uint32_t* __restrict__ ooff /* nkeys + 1 */) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > nkeys) return;
+  ooff[k] = off[k] >> 1;
+  if (k < nkeys) ocnt[k] = (cnt[k] + 1) >> 1;
+}
 
 template <bool FIRST, int LPK>
 __global__ void __launch_bounds__(256)
@@ -1253,7 +1280,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_cnt2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_bsum = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);
-  size_t o_items = carve(p.e_max * 4);
+  size_t o_items = carve((p.e_max + (fx ? (size_t)p.nkeys + 2 : 0)) * 4);  // fixed-base: odd buckets are padded to even
   const size_t sort_cells = fx ? ((size_t)(fx_nblk + FX_NP + 1) << fb.lo) : ((size_t)p.W * cdiv(n, SORT_CHUNK) << p.c);
   size_t o_hist16 = carve(sort_cells * 2);
   size_t o_choff = carve(sort_cells * 4);
@@ -1328,12 +1355,13 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                          pstart, plo, pid);
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
     hipLaunchKernelGGL(k_hist_scan2, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, cstart, fb, chunk_off, cnt);
-    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
+    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
     if (staged2)
       hipLaunchKernelGGL(k_scatter_local2_staged, dim3(gmax), dim3(SORT_TPB), FX_STAGE2_LDS, st, plo, pid, pstart, cstart, fb, off,
                          chunk_off, hist16, items);
     else
       hipLaunchKernelGGL(k_scatter_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 4, st, plo, pid, pstart, cstart, fb, off, chunk_off, items);
+    hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   } else {
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
@@ -1359,7 +1387,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   int cur = 0;  // index of the live (cnt, off) pair
   const Aff* bases0 = fx ? fx->table : (const Aff*)d_bases;
   const Aff* pts_in = bases0;
-  size_t cap = p.e_max;
+  size_t cap = p.e_max + (fx ? nk : 0);  // upper bound on the entries of the live array (fixed-base: incl. the even padding)
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
   // resident threads of k_affine_round on this device (3 blocks of 256 per CU on MI355X: 196 608)
@@ -1371,7 +1399,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const uint32_t aff_bmax = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
   auto launch_round = [&](int r) -> int {
     int nxt = (cur + 1) % 3;
-    DVP_TRY(scan_exclusive_div(pc[cur], 2u, pc[nxt], po[nxt], nk, bsum, st));
+    const bool items_are_desc = r == 0 && fx;  // even-aligned buckets: the sorted item list is the descriptor array
+    if (items_are_desc)
+      hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
+    else
+      DVP_TRY(scan_exclusive_div(pc[cur], 2u, pc[nxt], po[nxt], nk, bsum, st));
     size_t out_max = cap / 2 + nk + 1;
     Aff* outp = (r & 1) ? affB : affA;
     // descriptors: lanes per bucket by the average bucket size of this round
@@ -1380,7 +1412,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   hipLaunchKernelGGL((k_round_desc<FIRST, LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, items, pc[cur], po[cur], po[nxt], nk, gdesc)
 #define DVP_DESC_PICK(FIRST) \
   do { if (per_key >= 48) DVP_DESC_LAUNCH(FIRST, 64); else if (per_key >= 8) DVP_DESC_LAUNCH(FIRST, 16); else DVP_DESC_LAUNCH(FIRST, 4); } while (0)
-    if (r == 0) DVP_DESC_PICK(true); else DVP_DESC_PICK(false);
+    if (items_are_desc) { /* nothing to build */ } else if (r == 0) DVP_DESC_PICK(true); else DVP_DESC_PICK(false);
 #undef DVP_DESC_PICK
 #undef DVP_DESC_LAUNCH
     // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
@@ -1390,7 +1422,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     {
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
       if (r == 0)
-        hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
+        hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, items_are_desc ? (const uint2*)items : (const uint2*)gdesc, d_total,
+                           aff_cap, aff_bmax, Tsq, prefix, outp);
       else
         hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
       ps0.stop();
