@@ -34,18 +34,14 @@ shutil.copy(os.path.join(SRC, "msm_bench.log"), os.path.join(DST, f"{tag}_msm_be
 
 
 def round0_dispatches(dirname):
-    """per dispatch {counter: value, ms}: the k_affine_round launches that directly follow a k_round_desc<true, ..> launch,
-    i.e. the FIRST pair round of each MSM (the dominant kernel; later rounds run the same code on compacted inputs)"""
+    """per dispatch {counter: value, ms}: the k_affine_round<true> launches, i.e. the FIRST pair round of each MSM (the
+    dominant kernel; the later rounds, k_affine_round<false>, run the same code on compacted inputs)"""
     rows = list(csv.DictReader(open(one(f"{dirname}/**/*counter_collection.csv"))))
     disp = collections.OrderedDict()
     for r in rows:
         d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
         d[r["Counter_Name"]] = float(r["Counter_Value"])
-    ids = sorted(disp)
-    out = []
-    for a, b in zip(ids, ids[1:]):
-        if "k_round_desc<true" in disp[a]["name"] and "k_affine_round<true>" in disp[b]["name"]:
-            out.append(disp[b])
+    out = [d for d in disp.values() if "k_affine_round<true>" in d["name"]]
     assert out, dirname
     return out
 
@@ -60,7 +56,7 @@ b = last_json_line(os.path.join(SRC, "bench.json"))
 alg = b["roofline"]["algorithmic_bytes_per_launch"]
 f_kb, w_kb = avg(fetch, "FETCH_SIZE"), avg(write, "WRITE_SIZE")
 traffic = {
-    "kernel": "dvp::k_affine_round<true>, first pair round of each MSM (the launches that follow k_round_desc<true, ..>)",
+    "kernel": "dvp::k_affine_round<true>, first pair round of each MSM",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, counters + --kernel-trace only) -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline",
     "launches": len(fetch),
     "avg_FETCH_SIZE_KB": f_kb,
