@@ -141,9 +141,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_prove_sharded_gloo(world):
-    """world 2: uniform slices; world 3: one rank skips the extends (distributed.shard_plan) and owns only [w], [k_a|k_b]"""
+    """world 2: uniform slices; world 3: one rank skips the extends (distributed.shard_plan) and owns only [w], [k_a|k_b];
+    world 8 (the node size the bench is run at): half of the ranks skip the extends, one-element shards, eight records per
+    all-gather"""
     import torch.multiprocessing as mp
 
     s = socket.socket()
