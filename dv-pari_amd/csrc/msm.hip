@@ -772,7 +772,7 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
 // bases (HBM misses in the first round: the pre-rotated table is 5 GB) are off the critical path.
 constexpr uint32_t AFF_NONE = 0xffffffffu;
 
-// Fixed-base mode: the sort lays every bucket out from an EVEN position of the item list (scan of the counts rounded up to
+// Both sorts lay every bucket out from an EVEN position of the item list (scan of the counts rounded up to
 // even); an odd bucket's spare slot gets AFF_NONE.  The list read as uint2 pairs is then exactly what k_round_desc<true>
 // would write for the first pair round -- (a, b) table indices, b = NONE for the odd leftover -- so that round needs no
 // descriptor kernel and no scan: its output offsets are the item offsets halved (k_round0_offsets).
@@ -1280,7 +1280,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_cnt2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_bsum = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);
-  size_t o_items = carve((p.e_max + (fx ? (size_t)p.nkeys + 2 : 0)) * 4);  // fixed-base: odd buckets are padded to even
+  size_t o_items = carve((p.e_max + (size_t)p.nkeys + 2) * 4);  // odd buckets are padded to even (k_pad_odd_buckets)
   const size_t sort_cells = fx ? ((size_t)(fx_nblk + FX_NP + 1) << fb.lo) : ((size_t)p.W * cdiv(n, SORT_CHUNK) << p.c);
   size_t o_hist16 = carve(sort_cells * 2);
   size_t o_choff = carve(sort_cells * 4);
@@ -1366,8 +1366,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
     hipLaunchKernelGGL(k_hist_scan, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, nchunks, p.c, p.W, chunk_off, cnt);
-    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st));
+    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
+    hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   }
   ps_sort.stop();
   // ---- bucket accumulation: batched-affine pair rounds while a round still carries >= aff_min additions,
@@ -1387,7 +1388,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   int cur = 0;  // index of the live (cnt, off) pair
   const Aff* bases0 = fx ? fx->table : (const Aff*)d_bases;
   const Aff* pts_in = bases0;
-  size_t cap = p.e_max + (fx ? nk : 0);  // upper bound on the entries of the live array (fixed-base: incl. the even padding)
+  size_t cap = p.e_max + nk;  // upper bound on the entries of the live array (incl. the even padding of the buckets)
   GfSqrTables Tsq;
   DVP_TRY(gf_sqr_tables(&Tsq, st));
   // resident threads of k_affine_round on this device (3 blocks of 256 per CU on MI355X: 196 608)
@@ -1399,7 +1400,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const uint32_t aff_bmax = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
   auto launch_round = [&](int r) -> int {
     int nxt = (cur + 1) % 3;
-    const bool items_are_desc = r == 0 && fx;  // even-aligned buckets: the sorted item list is the descriptor array
+    const bool items_are_desc = r == 0;  // even-aligned buckets: the sorted item list is the descriptor array
     if (items_are_desc)
       hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
     else
@@ -1412,7 +1413,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   hipLaunchKernelGGL((k_round_desc<FIRST, LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, items, pc[cur], po[cur], po[nxt], nk, gdesc)
 #define DVP_DESC_PICK(FIRST) \
   do { if (per_key >= 48) DVP_DESC_LAUNCH(FIRST, 64); else if (per_key >= 8) DVP_DESC_LAUNCH(FIRST, 16); else DVP_DESC_LAUNCH(FIRST, 4); } while (0)
-    if (items_are_desc) { /* nothing to build */ } else if (r == 0) DVP_DESC_PICK(true); else DVP_DESC_PICK(false);
+    if (!items_are_desc) DVP_DESC_PICK(false);  // round 0 needs none; k_round_desc<true, ..> is kept for reference
 #undef DVP_DESC_PICK
 #undef DVP_DESC_LAUNCH
     // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
