@@ -764,18 +764,18 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
 // projective addition.  Prefix products are parked in HBM ([slot-in-thread][thread] layout, so the
 // traffic is coalesced).  (0,0) -- not a curve point -- marks infinity.
 //
-// A round is two launches.  k_round_desc resolves every output slot to its two input points once -- (a, b) =
-// indices into `pts`, b = NONE for the odd leftover of a bucket -- with a group of lanes per bucket, so the hot
-// kernel neither searches the bucket offsets (18 dependent L2 round trips per slot in the first version) nor chases
-// the sorted item list; k_affine_round then runs two software-pipelined passes over its slots: the descriptor of
+// A round after the first is two launches.  k_round_desc resolves every output slot to its two input points once --
+// (a, b) = indices into `pts`, b = NONE for the odd leftover of a bucket -- with a group of lanes per bucket, so the
+// hot kernel does not search the bucket offsets (18 dependent L2 round trips per slot in the first version); the first
+// round reads the sorted item list itself as its descriptors (below).  k_affine_round then runs two software-pipelined passes over its slots: the descriptor of
 // slot k+2 and the operands of slot k+1 are in flight while slot k multiplies, so the random 64-byte gathers of the
 // bases (HBM misses in the first round: the pre-rotated table is 5 GB) are off the critical path.
 constexpr uint32_t AFF_NONE = 0xffffffffu;
 
 // Both sorts lay every bucket out from an EVEN position of the item list (scan of the counts rounded up to
-// even); an odd bucket's spare slot gets AFF_NONE.  The list read as uint2 pairs is then exactly what k_round_desc<true>
-// would write for the first pair round -- (a, b) table indices, b = NONE for the odd leftover -- so that round needs no
-// descriptor kernel and no scan: its output offsets are the item offsets halved (k_round0_offsets).
+// even); an odd bucket's spare slot gets AFF_NONE.  The list read as uint2 pairs is then exactly the descriptor array of
+// the first pair round -- (a, b) table indices, b = NONE for the odd leftover -- so that round needs no descriptor
+// kernel and no scan: its output offsets are the item offsets halved (k_round0_offsets).
 __global__ void __launch_bounds__(256)
 k_pad_odd_buckets(uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t nkeys) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -792,10 +792,10 @@ k_round0_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
   if (k < nkeys) ocnt[k] = (cnt[k] + 1) >> 1;
 }
 
-template <bool FIRST, int LPK>
+template <int LPK>
 __global__ void __launch_bounds__(256)
-k_round_desc(const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
-             const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */, uint32_t nkeys, uint2* __restrict__ desc) {
+k_round_desc(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */,
+             uint32_t nkeys, uint2* __restrict__ desc) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t key = gid / LPK, lane = gid % LPK;
   if (key >= nkeys) return;
@@ -803,8 +803,8 @@ k_round_desc(const uint32_t* __restrict__ items, const uint32_t* __restrict__ cn
   for (uint32_t j = lane; j < nout; j += LPK) {
     const uint32_t i0 = o + 2 * j;
     uint2 d;
-    d.x = FIRST ? items[i0] : i0;
-    d.y = (2 * j + 1 < c) ? (FIRST ? items[i0 + 1] : i0 + 1) : AFF_NONE;
+    d.x = i0;
+    d.y = (2 * j + 1 < c) ? i0 + 1 : AFF_NONE;
     desc[oo + j] = d;
   }
 }
@@ -1409,12 +1409,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     Aff* outp = (r & 1) ? affB : affA;
     // descriptors: lanes per bucket by the average bucket size of this round
     const size_t per_key = (e_est >> (r + 1)) / nk;
-#define DVP_DESC_LAUNCH(FIRST, LPK) \
-  hipLaunchKernelGGL((k_round_desc<FIRST, LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, items, pc[cur], po[cur], po[nxt], nk, gdesc)
-#define DVP_DESC_PICK(FIRST) \
-  do { if (per_key >= 48) DVP_DESC_LAUNCH(FIRST, 64); else if (per_key >= 8) DVP_DESC_LAUNCH(FIRST, 16); else DVP_DESC_LAUNCH(FIRST, 4); } while (0)
-    if (!items_are_desc) DVP_DESC_PICK(false);  // round 0 needs none; k_round_desc<true, ..> is kept for reference
-#undef DVP_DESC_PICK
+#define DVP_DESC_LAUNCH(LPK) \
+  hipLaunchKernelGGL((k_round_desc<LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, pc[cur], po[cur], po[nxt], nk, gdesc)
+    if (!items_are_desc) {  // round 0 needs none
+      if (per_key >= 48) DVP_DESC_LAUNCH(64); else if (per_key >= 8) DVP_DESC_LAUNCH(16); else DVP_DESC_LAUNCH(4);
+    }
 #undef DVP_DESC_LAUNCH
     // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
     const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax);
