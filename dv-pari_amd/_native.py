@@ -1,4 +1,4 @@
-"""ctypes binding of include/dvpari.h.  No torch types cross this boundary: pointers and sizes only."""
+"""ctypes binding of include/dvpari.h (the drop-in boundary) and include/dvpari_internal.h (test / measurement entries).  No torch types cross this boundary: pointers and sizes only."""
 import ctypes as C
 import os
 
@@ -34,7 +34,12 @@ _SIGS = {
     "dvp_points_sum_dev": (C.c_int, [vp, u32, vp, vp, vp]),
     "dvp_last_error_index": (C.c_int64, []),
     "dvp_tune_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "dvp_tune_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
     "dvp_tune_reset": (None, []),
+    "dvp_ubench_gather": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "dvp_prover_msm_table_ptr": (C.c_int, [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+    "dvp_debug_ecfft_matrices": (C.c_int, [vp, C.c_int, C.c_int, u64p]),
+    "dvp_debug_ecfft_layer": (C.c_int, [vp, u32, u64p]),
     "dvp_ubench_gf_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),
@@ -146,18 +151,25 @@ def set_devices(ids):
 
 
 class tune:
-    """with tune(DVP_MSM_FIXED_C=20, DVP_MSM_AFF_MIN=64): ...  -- run-time tuning knobs (dvp_tune_set), restored on exit"""
+    """with tune(DVP_MSM_FIXED_C=20, DVP_MSM_AFF_MIN=64): ...  -- run-time tuning knobs (dvp_tune_set).  On exit every
+    knob this block changed goes back to the value it had on entry, so blocks nest."""
 
     def __init__(self, **knobs):
         self.knobs = knobs
+        self.saved = {}
 
     def __enter__(self):
         for k, v in self.knobs.items():
+            old = C.c_longlong(0)
+            check(lib.dvp_tune_get(k.encode(), C.byref(old)), f"dvp_tune_get({k})")
+            self.saved[k] = old.value
             check(lib.dvp_tune_set(k.encode(), int(v)), f"dvp_tune_set({k})")
         return self
 
     def __exit__(self, *exc):
-        lib.dvp_tune_reset()
+        for k, v in self.saved.items():
+            lib.dvp_tune_set(k.encode(), v)
+        self.saved = {}
         return False
 
 

@@ -59,6 +59,7 @@ static void tune_from_env(Tune& t) {
   t.msm_quad_max = geti("DVP_MSM_QUAD_MAX", t.msm_quad_max);
   t.msm_fixed_min = geti("DVP_MSM_FIXED_MIN", t.msm_fixed_min);
   t.horner_max_pub = geti("DVP_HORNER_MAX_PUB", t.horner_max_pub);
+  t.msm_table_max_gb = geti("DVP_MSM_TABLE_MAX_GB", t.msm_table_max_gb);
 }
 static std::mutex g_dev_mu;
 static std::vector<int> g_devices;
@@ -72,16 +73,28 @@ Tune& tune() {
 }
 }  // namespace dvp
 
-extern "C" int dvp_tune_set(const char* name, long long value) {
-  if (!name) return DVP_EINVAL;
+static long long* tune_slot(const char* name) {
   dvp::Tune& t = dvp::tune();
   struct { const char* n; long long* v; } tab[] = {
       {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi}, {"DVP_MSM_SLIDE", &t.msm_slide},
       {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax},
-      {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub}};
+      {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub},
+      {"DVP_MSM_TABLE_MAX_GB", &t.msm_table_max_gb}};
   for (auto& e : tab)
-    if (!strcmp(name, e.n)) { *e.v = value; return DVP_OK; }
-  return DVP_EINVAL;
+    if (!strcmp(name, e.n)) return e.v;
+  return nullptr;
+}
+extern "C" int dvp_tune_set(const char* name, long long value) {
+  long long* v = name ? tune_slot(name) : nullptr;
+  if (!v) return DVP_EINVAL;
+  *v = value;
+  return DVP_OK;
+}
+extern "C" int dvp_tune_get(const char* name, long long* value) {
+  long long* v = name ? tune_slot(name) : nullptr;
+  if (!v || !value) return DVP_EINVAL;
+  *value = *v;
+  return DVP_OK;
 }
 extern "C" void dvp_tune_reset(void) { dvp::tune_from_env(dvp::tune()); }
 
@@ -107,7 +120,6 @@ extern "C" const char* dvp_strerror(int s) {
     case DVP_EDECODE: return "invalid xsk233 point encoding";
     case DVP_EUNSAT: return "R1CS constraint not satisfied by the witness";
     case DVP_EHIP: return "HIP runtime error";
-    case DVP_ERCCL: return "RCCL error";
     case DVP_EIO: return "I/O error";
     case DVP_ENOMEM: return "out of memory";
     case DVP_ECHALLENGE: return "Fiat-Shamir challenge lies in the evaluation domain";

@@ -783,3 +783,38 @@ static void free_exit_tables(dvp_ecfft* c) {
   }
   g_exit_tabs.erase(it);
 }
+
+// Parity-test read-out of the butterfly matrices extend() runs on (include/dvpari_internal.h): what the reference keeps
+// in FFTree::{decompose,recombine}_matrices and stores in sections 2 / 1 of its FFTR tree files (src/tree_io.rs:353-433).
+namespace dvp {
+__global__ void __launch_bounds__(256) k_mats_export(const Fr29* __restrict__ in, Fr* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t l[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) l[k] = in[i].l[k];
+  out[i] = fr_from_mont(fr_from29(l));
+}
+}  // namespace dvp
+extern "C" int dvp_debug_ecfft_matrices(dvp_ecfft* c, int to_even, int which, uint64_t* out) {
+  if (!c || !out || (to_even != 0 && to_even != 1) || (which != 0 && which != 1) || c->log_n < 2) return DVP_EINVAL;
+  MatSet* ms;
+  DVP_TRY(build_matset(c, 0, to_even, &ms, 0));
+  const size_t n = ((size_t)(c->n_leaves >> 1) - 1) * 4;
+  DevBuf tmp;
+  DVP_TRY(tmp.alloc(n * sizeof(Fr)));
+  hipLaunchKernelGGL(k_mats_export, dim3(cdiv(n, TPB)), dim3(TPB), 0, 0, which ? ms->rec : ms->dec, tmp.as<Fr>(), n);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, tmp.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+extern "C" int dvp_debug_ecfft_layer(const dvp_ecfft* c, uint32_t d, uint64_t* out) {
+  if (!c || !out || d > (uint32_t)c->log_n) return DVP_EINVAL;
+  const size_t n = c->n_leaves >> d;
+  DevBuf tmp;
+  DVP_TRY(tmp.alloc(n * sizeof(Fr)));
+  hipLaunchKernelGGL(k_from_mont, dim3(cdiv(n, TPB)), dim3(TPB), 0, 0, c->layer((int)d), tmp.as<Fr>(), n);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out, tmp.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
+  return DVP_OK;
+}

@@ -1586,7 +1586,10 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
   bool slide = false;
   if ((uint64_t)TAU_DIGITS * n_total < 0xfffffff0ull && mode != 0) {
     size_t free_b = 0, total_b = 0;
-    slide = mode > 0 || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes + (uint64_t)total_b / 4 <= (uint64_t)free_b);
+    const long long budget_gb = tune().msm_table_max_gb;  // DVP_MSM_TABLE_MAX_GB: explicit byte budget of one table
+    if (mode > 0) slide = true;
+    else if (budget_gb >= 0) slide = slide_bytes <= (uint64_t)budget_gb * 1000000000ull;
+    else slide = hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes + (uint64_t)total_b / 4 <= (uint64_t)free_b;
   }
   hipError_t alloc_err = hipSuccess;
   int rc = msm_fixed_build(d_bases, n_total, range_hint, slide, out, &alloc_err);
@@ -1603,6 +1606,7 @@ int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows) {
   return DVP_OK;
 }
 // bytes of the pre-rotated table; *sliding = 1 when it holds all TAU_DIGITS rotations (sliding windows)
+const void* msm_fixed_table_ptr(const MsmFixedCtx* c) { return c ? (const void*)c->table : nullptr; }
 uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* sliding) {
   if (sliding) *sliding = c && c->slide ? 1 : 0;
   return c ? (uint64_t)c->rows() * c->n_total * sizeof(Aff) : 0;
@@ -1665,6 +1669,59 @@ extern "C" int dvp_ubench_gf_mul(int reps, double* products_per_s) {
   (void)hipEventDestroy(e1);
   DVP_HIP(hipGetLastError());
   *products_per_s = (double)blocks * EC_TPB * reps / (best * 1e-3);
+  return DVP_OK;
+}
+
+// Random 64-byte gathers per second out of a device table (tools/ubench/gather.hip moved behind the ABI so that bench.py
+// measures the ceiling of the first pair round's gathers in the same run, on the prover's own table): every lane reads
+// whole 64-byte lines at hashed positions, four independent lines in flight per lane (the pair round keeps the two
+// operands of the next slot in flight behind the current one's), at full occupancy -- the most the memory system gives.
+__device__ __forceinline__ uint64_t ubench_mix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_ubench_gather(const uint4* __restrict__ t, uint64_t nlines, int per, uint32_t seed, uint32_t* __restrict__ out) {
+  const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll 4
+  for (int k = 0; k < per; ++k) {
+    const uint64_t idx = ubench_mix(tid * (uint64_t)per + k + ((uint64_t)seed << 40)) % nlines;
+    const uint4* p = t + idx * 4;
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    acc.x ^= a.x ^ b.x ^ c.x ^ d.x; acc.y ^= a.y ^ b.y ^ c.y ^ d.y; acc.z ^= a.z ^ b.z ^ c.z ^ d.z; acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;  // keeps the loads alive
+}
+extern "C" int dvp_ubench_gather(const void* d_table, size_t table_bytes, int reps, double* gathers_per_s) {
+  if (reps < 1 || reps > 64 || !gathers_per_s || table_bytes < (1u << 20)) return DVP_EINVAL;
+  int dev = 0, n_cu = 256;
+  DVP_HIP(hipGetDevice(&dev));
+  DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  DevBuf own, out;
+  if (!d_table) {  // contents do not matter for a read-rate figure, but untouched pages may not be backed: write them once
+    DVP_TRY(own.alloc(table_bytes));
+    DVP_HIP(hipMemset(own.p, 0x5a, table_bytes));
+    d_table = own.p;
+  }
+  DVP_TRY(out.alloc(16));
+  const int per = 32;
+  const uint32_t blocks = (uint32_t)n_cu * 3 * 8;
+  const uint64_t nlines = table_bytes / 64;
+  hipEvent_t e0, e1;
+  DVP_HIP(hipEventCreate(&e0));
+  DVP_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, 0, (const uint4*)d_table, nlines, per, 1u, out.as<uint32_t>());
+  DVP_HIP(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, 0, (const uint4*)d_table, nlines, per, 2u + (uint32_t)r, out.as<uint32_t>());
+  DVP_HIP(hipEventRecord(e1, 0));
+  DVP_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DVP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  DVP_HIP(hipGetLastError());
+  *gathers_per_s = (double)reps * blocks * 256.0 * per / (ms * 1e-3);
   return DVP_OK;
 }
 

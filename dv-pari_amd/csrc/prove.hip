@@ -47,6 +47,7 @@ int msm_sum_points_dev(const void* d_pts, uint32_t pt_stride_bytes, const void* 
 void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* sliding);
+const void* msm_fixed_table_ptr(const MsmFixedCtx* c);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
 
@@ -438,6 +439,7 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
   p->n_pub = n_public;
   p->n_wires = n_wires;
   const size_t m = p->m;
+  DVP_HIP(hipGetDevice(&p->home_device));  // every buffer of this prover lives on the device that is current now
   DVP_TRY(dvp_ecfft_create(log2_m + 1, 0, log2_m + 1, &p->tree));  // TREE_2N, src/proving.rs:274
   DVP_TRY(ecfft_device_consts(p->tree));
   auto A = [&](void** q, size_t bytes) -> int { DVP_HIP(hipMalloc(q, bytes ? bytes : 16)); return DVP_OK; };
@@ -779,9 +781,14 @@ static void even_range(size_t total, size_t k, size_t n, size_t* lo, size_t* hi)
 }
 static int shards_build(dvp_prover* p, const std::vector<int>& devs) {
   shards_release(p);
-  DVP_HIP(hipGetDevice(&p->home_device));
   const size_t n = devs.size();
-  if (n > 64) return DVP_EINVAL;
+  if (n > 64 || devs[0] != p->home_device) return DVP_EINVAL;  // ids[0] must be the device the prover's buffers live on
+  // the single-device tables (up to 97 GB of rotations at 2^20 constraints) would sit beside the shard tables: shard 0's
+  // msm_fixed_create would see less free HBM and fall back to the aligned windows
+  for (int w = 0; w < 2; ++w) {
+    msm_fixed_destroy(p->fx[w]);
+    p->fx[w] = nullptr;
+  }
   if (!p->mg_parts) DVP_HIP(hipMalloc((void**)&p->mg_parts, 64 * 68));
   p->shards.resize(n);
   int rc = DVP_OK;
@@ -904,6 +911,13 @@ extern "C" uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, i
     if (s && sliding) *sliding = 1;
   }
   return total;
+}
+// the table the first pair round of MSM `which` gathers from on the home device (bench.py points dvp_ubench_gather at it)
+extern "C" int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_table, uint64_t* bytes) {
+  if (!p || (which != 0 && which != 1) || !d_table || !bytes) return DVP_EINVAL;
+  *d_table = msm_fixed_table_ptr(p->fx[which]);
+  *bytes = msm_fixed_table_bytes(p->fx[which], nullptr);
+  return DVP_OK;
 }
 extern "C" size_t dvp_prover_msm_size(const dvp_prover* p, int which) {
   if (!p) return 0;

@@ -123,31 +123,61 @@ class GpuBackend:
         return self.prover.finish(point.data_ptr(), point.data_ptr() + 64, self.torch.cuda.current_stream().cuda_stream)
 
 
-_GATHER_INTO_TENSOR = True  # flips to False the first time the backend refuses all_gather_into_tensor
+_GATHER_MODE = {}  # process group (id) -> "tensor" | "list", decided ONCE by probe_collectives
 
 
-def _all_gather_records(part, world, group):
-    """[world, 10] tensor of every rank's 80-byte record: ONE collective into one preallocated-shape tensor where the
-    backend has all_gather_into_tensor (RCCL does), the list form + stack otherwise"""
-    global _GATHER_INTO_TENSOR
+def probe_collectives(device, group=None):
+    """Decide once per process group, in a throw-away exchange every rank makes at the same point (bench.py calls it before
+    the warm-up; prove_sharded calls it on first use), whether the backend has all_gather_into_tensor (RCCL does) or only
+    the list form.  Only "this collective does not exist here" is accepted as a reason to fall back, and every rank sees
+    the same answer because the capability is a property of the backend, not of a rank; from then on a RuntimeError of a
+    collective (a communicator fault) propagates, so all ranks fail loudly instead of one of them silently switching to a
+    different collective than its peers."""
     import torch
     import torch.distributed as dist
 
-    if _GATHER_INTO_TENSOR:
-        out = torch.empty((world,) + tuple(part.shape), dtype=part.dtype, device=part.device)
-        try:
-            dist.all_gather_into_tensor(out, part, group=group)
-            return out
-        except (RuntimeError, NotImplementedError):
-            _GATHER_INTO_TENSOR = False
+    key = id(group) if group is not None else 0
+    if key in _GATHER_MODE:
+        return _GATHER_MODE[key]
+    world = dist.get_world_size(group)
+    probe = torch.zeros(10, dtype=torch.int64, device=device)
+    out = torch.empty(world * 10, dtype=torch.int64, device=device)  # flat: the one output shape every backend accepts
+    mode = "tensor"
+    try:
+        dist.all_gather_into_tensor(out, probe, group=group)
+    except NotImplementedError:
+        mode = "list"
+    except RuntimeError as e:
+        msg = str(e).lower()
+        if "not implemented" in msg or "not supported" in msg or "no backend" in msg or "unsupported" in msg:
+            mode = "list"
+        else:
+            raise
+    if mode == "list":
+        dist.all_gather([torch.empty_like(probe) for _ in range(world)], probe, group=group)
+    _GATHER_MODE[key] = mode
+    return mode
+
+
+def _all_gather_records(part, world, group):
+    """[world, k] tensor of every rank's record: ONE collective into one preallocated tensor where the backend has
+    all_gather_into_tensor (RCCL does), the list form + stack otherwise (decided by probe_collectives, never mid-run)"""
+    import torch
+    import torch.distributed as dist
+
+    if probe_collectives(part.device, group) == "tensor":
+        out = torch.empty(world * part.numel(), dtype=part.dtype, device=part.device)
+        dist.all_gather_into_tensor(out, part.reshape(-1), group=group)
+        return out.view((world,) + tuple(part.shape))
     gathered = [torch.empty_like(part) for _ in range(world)]
     dist.all_gather(gathered, part, group=group)
     return torch.stack(gathered)
 
 
-def prove_sharded(backend, assignment, group=None):
+def prove_sharded(backend, assignment, group=None, always_gather=False):
     """Proof::prove (src/proving.rs:426-688) with both MSMs sharded over the ranks of `group`.
-    Every rank returns the same proof."""
+    Every rank returns the same proof.  always_gather runs the collectives and the record combination even in a
+    one-rank group (how a one-GPU box executes the RCCL calls of this path for real)."""
     import torch
     import torch.distributed as dist
 
@@ -161,12 +191,12 @@ def prove_sharded(backend, assignment, group=None):
     for which in (0, 1):
         lo, hi = range_a if which == 0 else range_b
         part = backend.msm_partial(which, lo, hi)
-        if world > 1:
+        if world > 1 or (always_gather and dist.is_initialized()):
             point = backend.combine(_all_gather_records(part, world, group))
         else:
             point = part
         if which == 0:
-            if world > 1 and hasattr(backend, "challenge_partial"):
+            if (world > 1 or (always_gather and dist.is_initialized())) and hasattr(backend, "challenge_partial"):
                 # pointwise stages, batch inversions and barycentric sums by index: every rank sums its slice
                 # of D, one all-gather of 128-byte records, then only the K scalars of its own MSM range
                 rec = backend.challenge_partial(point, shard_range(m, rank, world), range_b)

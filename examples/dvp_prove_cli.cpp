@@ -25,8 +25,14 @@ int main(int argc, char** argv) {
   for (int i = 1; i < argc; ++i) {
     if (std::string(argv[i]) == "--devices" && i + 1 < argc) {
       for (char* tok = argv[++i]; *tok;) {
-        devices.push_back((int)strtol(tok, &tok, 10));
-        if (*tok == ',') ++tok;
+        char* end = tok;
+        const long id = strtol(tok, &end, 10);
+        if (end == tok || (*end != ',' && *end != 0) || id < 0 || id > 1023) {  // not a number / stray character: do not spin on it
+          fprintf(stderr, "--devices: expected a comma-separated list of device ids, got '%s'\n", argv[i]);
+          return 2;
+        }
+        devices.push_back((int)id);
+        tok = *end == ',' ? end + 1 : end;
       }
     } else {
       pos.push_back(argv[i]);

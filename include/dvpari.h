@@ -38,7 +38,8 @@ typedef enum dvp_status {
   DVP_EDECODE = -2, /* invalid 30-byte point (assert!(valid), src/io_utils.rs:223) */
   DVP_EUNSAT = -3,  /* R1CS row unsatisfied (assert_eq!, src/proving.rs:389-395) */
   DVP_EHIP = -4,    /* HIP runtime error */
-  DVP_ERCCL = -5,
+  /* -5 is unused: no entry point of this library calls RCCL -- partial MSM results are combined by the host
+   * (one process per GPU: torch.distributed all-gather + dvp_points_sum_dev) or by peer copies (dvp_set_devices) */
   DVP_EIO = -6,
   DVP_ENOMEM = -7,
   DVP_ECHALLENGE = -8 /* Fiat-Shamir challenge fell inside D u D' (assert!, src/proving.rs:548-556) */
@@ -59,23 +60,6 @@ int dvp_set_device(int device_id);
 int dvp_set_devices(const int* device_ids, int n);
 /* last failing index for DVP_EDECODE / DVP_EUNSAT / DVP_EINVAL (thread-local), or -1 */
 int64_t dvp_last_error_index(void);
-
-/* Tuning knobs for tests, sweeps and A/B runs (tools/README.md lists them; the defaults are the measured optima and
- * the environment variables of the same names are read once, at first use).  dvp_tune_set returns DVP_EINVAL for an
- * unknown name; dvp_tune_reset goes back to defaults + environment.  Not thread-safe against running calls. */
-int dvp_tune_set(const char* name, long long value);
-void dvp_tune_reset(void);
-
-/* Per-kernel HIP-event timers for the measurement harness (bench.py): off by default.  Names:
- * "msm_affine_round0" (first k_affine_round of an MSM, the dominant kernel: it gathers the bases), "msm_affine_rest"
- * (the later pair rounds), "msm_sort" (recode + counting sort), "msm_tail" (merge tree, Frobenius tail), "msm_total",
- * "extend_total", "prove_total". */
-/* microbenchmark of the MSM kernels' GF(2^233) multiplier alone (products per second, whole chip): the ceiling of
- * bench.py's work model, measured in the same run */
-int dvp_ubench_gf_mul(int reps, double* products_per_s);
-void dvp_profile_enable(int on);
-void dvp_profile_reset(void);
-int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
 
 /* ------------------------------------------------------------------------------------------ */
 /* ECFFT over Fr -- replaces ecfft::FFTree as built by build_sect_ecfft_tree                    */
@@ -154,10 +138,6 @@ int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
  * and need ~8 % fewer bucket additions.  The sliding table is chosen when it leaves a quarter of the device memory
  * free at the moment the context is built (DVP_MSM_SLIDE = 1 / 0 forces it on / off); *sliding reports which one this is. */
 uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
-/* parity-test access to the sliding-window recode alone: entry words of n canonical scalars for window size c (8..21),
- * out_words[slot * n + i] = 0 (empty slot) or 0x80000000 | first digit position << 20 | odd pattern >> 1;
- * *slots = entry slots per scalar (out_words must hold *slots * n words; out_words = NULL only queries *slots). */
-int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 /* same seam with the reference's own wire formats: scalars n x 32 B canonical LE, bases n x 30 B
@@ -231,8 +211,6 @@ int dvp_prove_challenge_partial(dvp_prover* p, const void* d_commit_xy, const vo
                                 size_t k_lo, size_t k_hi, void* d_record_out, void* stream);
 int dvp_prove_challenge_finish(dvp_prover* p, const void* d_records, uint32_t n_records, size_t k_lo, size_t k_hi, void* stream);
 int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void* d_kzg_inf, uint8_t proof[118], void* stream);
-/* intermediates of the last proof, for parity tests (names: see prove.hip) */
-int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);
 /* (D, D') = get_both_domains(tree2n), src/ec_fft.rs:179-189 */
 int dvp_prover_domains(dvp_prover* p, uint64_t* d, uint64_t* d2);
 /* which = 0: (1/Z_D'(D_i), 1/Z_D(D'_i)) = (bar_wts, z_vals2inv); which = 1: the D' mirrors

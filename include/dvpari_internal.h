@@ -1,0 +1,65 @@
+/*
+ * dvpari_internal.h -- entry points of libdvpari_hip.so that are NOT part of the drop-in boundary.
+ *
+ * include/dvpari.h is what a host of the reference prover binds (one entry per seam of alpenlabs/dv-pari).  The
+ * symbols below exist for this repository's own tests, sweeps and measurement harness (tests/, tools/, bench.py):
+ * tuning knobs, per-kernel timers, microbenchmarks and read-outs of intermediates.  They may change between builds;
+ * a host program (examples/dvp_prove_cli.cpp) must build against dvpari.h alone.
+ */
+#ifndef DVPARI_INTERNAL_H
+#define DVPARI_INTERNAL_H
+
+#include "dvpari.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning knobs for tests, sweeps and A/B runs (tools/README.md lists them; the defaults are the measured optima and
+ * the environment variables of the same names are read once, at first use).  dvp_tune_set returns DVP_EINVAL for an
+ * unknown name; dvp_tune_reset goes back to defaults + environment; dvp_tune_get reads the current value.  Not
+ * thread-safe against running calls. */
+int dvp_tune_set(const char* name, long long value);
+int dvp_tune_get(const char* name, long long* value);
+void dvp_tune_reset(void);
+
+/* Per-kernel HIP-event timers for the measurement harness (bench.py): off by default.  Names:
+ * "msm_affine_round0" (first k_affine_round of an MSM, the dominant kernel: it gathers the bases), "msm_affine_rest"
+ * (the later pair rounds), "msm_sort" (recode + counting sort), "msm_tail" (merge tree, Frobenius tail), "msm_total",
+ * "extend_total", "prove_total". */
+void dvp_profile_enable(int on);
+void dvp_profile_reset(void);
+int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
+
+/* microbenchmark of the MSM kernels' GF(2^233) multiplier alone (products per second, whole chip, the pair rounds'
+ * occupancy): the ceiling of bench.py's work model, measured in the same run */
+int dvp_ubench_gf_mul(int reps, double* products_per_s);
+/* random 64-byte gathers per second (whole chip, two independent lines in flight per lane and step, as the first pair
+ * round issues them) out of a device table of `table_bytes` bytes starting at d_table; d_table = NULL allocates a scratch
+ * table of that size.  The ceiling of bench.py's gather model for dvp::k_affine_round<true>. */
+int dvp_ubench_gather(const void* d_table, size_t table_bytes, int reps, double* gathers_per_s);
+/* device address and size of the pre-rotated base table MSM `which` of a prover reads in its first pair round
+ * (NULL / 0 before the first proof) -- what dvp_ubench_gather is pointed at */
+int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_table, uint64_t* bytes);
+
+/* parity-test access to the sliding-window recode alone: entry words of n canonical scalars for window size c (8..21),
+ * out_words[slot * n + i] = 0 (empty slot) or 0x80000000 | first digit position << 20 | odd pattern >> 1;
+ * *slots = entry slots per scalar (out_words must hold *slots * n words; out_words = NULL only queries *slots). */
+int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
+
+/* intermediates of the last proof, for parity tests (names: see prove.hip) */
+int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);
+
+/* the 2x2 butterfly matrices extend() runs on, for parity tests against the oracle and against FFTR tree files
+ * (ecfft::FFTree::{decompose,recombine}_matrices, src/tree_io.rs:353-433): direction to_even = 0 is
+ * FFTree::extend(.., Moiety::S1) (even leaves -> odd leaves), 1 the mirrored one; which = 0 decompose, 1 recombine.
+ * out holds (n - 1) matrices of 4 canonical Fr (row-major m00 m01 m10 m11), n = leaves / 2, layer d (n >> (d+1) matrices
+ * built from the pairs (L_d[2i+s], L_d[2i+s+n_d]) of the layer-d leaves) at matrix offset n - (n >> d). */
+int dvp_debug_ecfft_matrices(dvp_ecfft* ctx, int to_even, int which, uint64_t* out);
+/* layer d of the isogeny chain (FFTree::f.get_layers()[d]): leaves >> d canonical Fr, d = 0 .. log2_leaves */
+int dvp_debug_ecfft_layer(const dvp_ecfft* ctx, uint32_t d, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVPARI_INTERNAL_H */

@@ -9,12 +9,16 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_build", "libdvp_oracle.so")
 OSSL_PATH = os.path.join(_HERE, "_build", "libdvp_oracle_ossl.so")
+ECFFT_PATH = os.path.join(_HERE, "_build", "libdvp_oracle_ecfft.so")
 
 
 def build(force=False):
     src = os.path.join(_HERE, "dvp_oracle.c")
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libdvp_oracle.so"], stdout=subprocess.DEVNULL)
+    src3 = os.path.join(_HERE, "dvp_oracle_ecfft.c")
+    if force or not os.path.exists(ECFFT_PATH) or os.path.getmtime(ECFFT_PATH) < os.path.getmtime(src3):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_build/libdvp_oracle_ecfft.so"], stdout=subprocess.DEVNULL)
     src2 = os.path.join(_HERE, "dvp_oracle_ossl.c")
     if force or not os.path.exists(OSSL_PATH) or os.path.getmtime(OSSL_PATH) < os.path.getmtime(src2):
         # the OpenSSL datapoint is optional: a box without libcrypto headers still gets the main oracle
@@ -199,3 +203,88 @@ def openssl_msm(scalars: np.ndarray, bases: np.ndarray, threads: int = 1):
     if _ossl.dvo_openssl_msm(_p(s), _p(b), s.shape[0], threads, _p(o), C.byref(oi)) != 0:
         raise RuntimeError("dvo_openssl_msm failed")
     return _pt_out(o, oi)
+
+
+# ---- ECFFT restatement in C (oracle/dvp_oracle_ecfft.c): pyref.FFTree at sizes python cannot reach -------------------
+_ecfft = None
+
+
+def _ecfft_lib():
+    global _ecfft
+    if _ecfft is None:
+        build()
+        _ecfft = C.CDLL(ECFFT_PATH)
+        vp = C.c_void_p
+        _ecfft.dvo_fftree_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        _ecfft.dvo_fftree_new.restype = vp
+        _ecfft.dvo_fftree_free.argtypes = [vp]
+        _ecfft.dvo_fftree_layer.argtypes = [vp, C.c_int, vp]
+        for f in ("dvo_fftree_enter", "dvo_fftree_exit", "dvo_fftree_eval"):
+            getattr(_ecfft, f).argtypes = [vp, vp, C.c_int, vp]
+            getattr(_ecfft, f).restype = C.c_int
+        _ecfft.dvo_fftree_extend.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+        _ecfft.dvo_fftree_extend.restype = C.c_int
+        _ecfft.dvo_fftree_matrices.argtypes = [vp, C.c_int, C.c_int, vp]
+        _ecfft.dvo_fftree_matrices.restype = C.c_int
+        _ecfft.dvo_fftree_vanish_even_at.argtypes = [vp, vp, C.c_int, vp]
+    return _ecfft
+
+
+class FFTree:
+    """pyref.FFTree in C: arrays are numpy uint64 [n,4] canonical limbs; `sl` = log2 of pyref's `stride`."""
+
+    def __init__(self, log_n: int, shifted: bool = False, base_log_n: int = None):
+        import pyref as o
+
+        self.log_n, self.n = log_n, 1 << log_n
+        consts = np.concatenate([_limbs(v) for v in (o.ECFFT_A, o.ECFFT_GEN[0], o.ECFFT_GEN[1], o.ECFFT_COSET[0], o.ECFFT_COSET[1])])
+        self._h = _ecfft_lib().dvo_fftree_new(log_n, int(shifted), log_n if base_log_n is None else base_log_n, o.ECFFT_LOG_ORDER, _p(consts))
+        if not self._h:
+            raise ValueError("dvo_fftree_new failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ecfft_lib().dvo_fftree_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def layer(self, d: int = 0) -> np.ndarray:
+        out = np.zeros((self.n >> d, 4), dtype=np.uint64)
+        _ecfft_lib().dvo_fftree_layer(self._h, d, _p(out))
+        return out
+
+    def leaves(self) -> np.ndarray:
+        return self.layer(0)
+
+    def _run(self, fn, arr, n, *args):
+        a = np.ascontiguousarray(arr, dtype=np.uint64)
+        assert a.shape == (n, 4), (a.shape, n)
+        out = np.zeros_like(a)
+        rc = fn(self._h, _p(a), *args, _p(out))
+        assert rc == 0
+        return out
+
+    def extend(self, ev, sl: int = 0, to_even: bool = False) -> np.ndarray:
+        return self._run(_ecfft_lib().dvo_fftree_extend, ev, (self.n >> sl) // 2, sl, int(to_even))
+
+    def enter(self, coeffs, sl: int = 0) -> np.ndarray:
+        return self._run(_ecfft_lib().dvo_fftree_enter, coeffs, self.n >> sl, sl)
+
+    def exit(self, ev, sl: int = 0) -> np.ndarray:
+        return self._run(_ecfft_lib().dvo_fftree_exit, ev, self.n >> sl, sl)
+
+    def eval(self, coeffs, sl: int = 0) -> np.ndarray:
+        """Horner at every leaf: the definition of enter"""
+        return self._run(_ecfft_lib().dvo_fftree_eval, coeffs, self.n >> sl, sl)
+
+    def matrices(self, to_even: bool, which: int) -> np.ndarray:
+        """[(n/2 - 1) * 4, 4]: the layer-ordered 2x2 matrices of one direction (which = 0 decompose, 1 recombine)"""
+        out = np.zeros(((self.n // 2 - 1) * 4, 4), dtype=np.uint64)
+        assert _ecfft_lib().dvo_fftree_matrices(self._h, int(to_even), which, _p(out)) == 0
+        return out
+
+    def vanish_even_at(self, x: int, sl: int = 0) -> int:
+        out = np.zeros(4, dtype=np.uint64)
+        _ecfft_lib().dvo_fftree_vanish_even_at(self._h, _p(_limbs(x)), sl, _p(out))
+        return _int(out)

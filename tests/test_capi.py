@@ -1,4 +1,4 @@
-"""CPU tests: the C-ABI library loads and exports every symbol include/dvpari.h declares.
+"""CPU tests: the C-ABI library loads and exports every symbol include/*.h declares.
 No compute call is made here (there is no GPU in the build container)."""
 import ctypes
 import os
@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "dvpari.h")).read()
+def declared_symbols(header="dvpari.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(dvp_[a-z0-9_]+)\s*\(", txt)))
 
@@ -19,6 +19,11 @@ def test_library_exports_every_declared_symbol(dvp, nat):
     lib = ctypes.CDLL(nat.LIB_PATH)
     syms = declared_symbols()
     assert len(syms) >= 20
+    internal = declared_symbols("dvpari_internal.h")
+    # test / sweep / measurement entries live in the internal header only: the boundary header stays what a host binds
+    assert not [s for s in syms if s.startswith(("dvp_debug_", "dvp_ubench_", "dvp_profile_", "dvp_tune_")) or "_debug_" in s]
+    assert not set(syms) & set(internal)
+    syms = syms + internal
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, missing
     # and the python binding knows each of them

@@ -8,6 +8,7 @@ import random
 import numpy as np
 import pytest
 
+import c_oracle as co
 import pyref as o
 from util import to_limbs, from_limbs, rand_fr_np
 
@@ -56,6 +57,108 @@ def test_extend_enter_exit_vs_oracle(dvp, log_n):
     assert from_limbs(t.exit(e)) == c
     ev = [rnd.randrange(o.P) for _ in range(1 << log_n)]
     assert from_limbs(t.exit(to_limbs(ev))) == ot.exit(ev)
+
+
+@pytest.mark.parametrize("log_n,shifted", [(12, False), (13, False), (13, True), (14, False)])
+def test_multiblock_extend_enter_exit_vs_oracle(dvp, log_n, shifted):
+    """The multi-block ECFFT path -- k_butterfly top layers + multi-block k_extend_fused, which run from 2^12 values up
+    (FUSE_LOG = 11) -- element for element against the oracle's FFTree (oracle/dvp_oracle_ecfft.c = pyref.FFTree in C,
+    pinned against pyref in tests/test_oracle_ecfft.py): leaves, extend (batch 1 and 3), enter, exit of evaluations that
+    are NOT an enter image, exit o enter, on the plain and the shifted tree (src/ec_fft.rs:151-155)."""
+    n = 1 << log_n
+    base = log_n + 1 if shifted else 0
+    t = dvp.ec_fft.FFTree(n, shift_by_one=shifted, base_log_n=base)
+    ot = co.FFTree(log_n, shifted, base if shifted else None)
+    assert np.array_equal(t.leaves(), ot.leaves())
+    m = n // 2
+    for batch in (1, 3):
+        ev = rand_fr_np(batch * m, 10 * log_n + batch).reshape(batch, m, 4)
+        out = t.extend(ev)
+        for b in range(batch):
+            assert np.array_equal(out[b], ot.extend(ev[b])), (batch, b)
+    c = rand_fr_np(n, 77 + log_n)
+    e = t.enter(c)
+    assert np.array_equal(e, ot.enter(c))
+    assert np.array_equal(t.exit(e), c)
+    ev = rand_fr_np(n, 99 + log_n)
+    assert np.array_equal(t.exit(ev), ot.exit(ev))
+    t.close()
+
+
+def test_extend_2_20_and_enter_2_18_vs_oracle(dvp, big_tree):
+    """the prover's own extend (m = 2^20, batch 3: a, b, c'; src/proving.rs:410-422) and a 2^18-coefficient enter,
+    every element against the oracle's FFTree"""
+    m = 1 << 20
+    ot = co.FFTree(21)
+    assert np.array_equal(big_tree.leaves(), ot.leaves())
+    ev = rand_fr_np(3 * m, 2020).reshape(3, m, 4)
+    out = big_tree.extend(ev)
+    for b in range(3):
+        assert np.array_equal(out[b], ot.extend(ev[b])), b
+    ot.close()
+    t = dvp.ec_fft.FFTree(1 << 18)
+    o18 = co.FFTree(18)
+    c = rand_fr_np(1 << 18, 1818)
+    assert np.array_equal(t.enter(c), o18.enter(c))
+    t.close()
+
+
+def _oracle_sections(ot, log_n):
+    """f / recombine_matrices / decompose_matrices of an FFTree in the reference's heap layout (tree_io.py states it),
+    assembled from the ORACLE's layers and matrices -- nothing here comes from the product"""
+    N = 1 << log_n
+    f = np.zeros((2 * N, 4), dtype=np.uint64)
+    for d in range(log_n + 1):
+        f[N >> d:2 * (N >> d)] = ot.layer(d)
+    ident = np.zeros((4, 4), dtype=np.uint64)
+    ident[0, 0] = ident[3, 0] = 1
+    rec = np.tile(ident, (N, 1)).reshape(N, 4, 4)
+    dec = rec.copy()
+    n = N // 2
+    mats = {(te, w): ot.matrices(bool(te), w).reshape(n - 1, 4, 4) for te in (0, 1) for w in (0, 1)}
+    for d in range(log_n - 1):
+        nd, off = n >> d, n - (n >> d)
+        sl = slice(off, off + nd // 2)
+        dec[nd:2 * nd:2], dec[nd + 1:2 * nd:2] = mats[(0, 0)][sl], mats[(1, 0)][sl]
+        rec[nd:2 * nd:2], rec[nd + 1:2 * nd:2] = mats[(1, 1)][sl], mats[(0, 1)][sl]
+    return {"f": f, "recombine_matrices": rec.reshape(4 * N, 4), "decompose_matrices": dec.reshape(4 * N, 4)}, mats
+
+
+@pytest.mark.parametrize("log_n", [2, 4, 8, 12])
+def test_butterfly_matrices_and_minimal_tree_file(dvp, nat, tmp_path, log_n):
+    """SURVEY 8f-4, the half beyond the leaves: the minimal reader of src/tree_io.rs:353-433 loads f, recombine_matrices and
+    decompose_matrices.  (1) the 2x2 matrices k_build_mats produced == the oracle's (both directions, every layer);
+    (2) a tree file written in the reference's section layout FROM THE ORACLE is accepted by check_tree_file(matrices=True)
+    against the regenerated tree, section for section; (3) what write_minimal_tree_file writes from the device tables reads
+    back through dvp_fftr_read_fr identical to those sections; a damaged matrix entry is refused with its index."""
+    N = 1 << log_n
+    t = dvp.ec_fft.FFTree(N)
+    ot = co.FFTree(log_n)
+    want, mats = _oracle_sections(ot, log_n)
+    n = N // 2
+    for te in (0, 1):
+        for w in (0, 1):
+            a = np.zeros(((n - 1) * 4, 4), dtype=np.uint64)
+            if n > 1:
+                dvp.check(dvp.lib.dvp_debug_ecfft_matrices(t._h, te, w, nat.ptr(a)))
+            assert np.array_equal(a.reshape(n - 1, 4, 4), mats[(te, w)]), (te, w)
+    path = tmp_path / "tree_oracle"
+    dvp.tree_io.write_tree_file(path, want)
+    info = dvp.tree_io.check_tree_file(path, t, matrices=True)
+    assert [s[0] for s in info["sections"]] == ["f", "recombine_matrices", "decompose_matrices"]
+    assert [s[1] for s in info["sections"]] == [8 + 29 * 2 * N, 8 + 29 * 4 * N, 8 + 29 * 4 * N]
+    mine = tmp_path / "tree_device"
+    dvp.tree_io.write_minimal_tree_file(mine, t)
+    for name in ("f", "recombine_matrices", "decompose_matrices"):
+        assert np.array_equal(dvp.tree_io.read_section(mine, name), want[name]), name
+    if log_n >= 4:
+        bad = {k: v.copy() for k, v in want.items()}
+        entry = 4 * (N // 2 + 3) + 2  # matrix N/2 + 3 (layer 0, pair 3), element m10
+        bad["decompose_matrices"][entry, 0] ^= np.uint64(1)
+        dvp.tree_io.write_tree_file(path, bad)
+        with pytest.raises(ValueError, match=f"decompose_matrices differs.*entry {N // 2 + 3}"):
+            dvp.tree_io.check_tree_file(path, t, matrices=True)
+    t.close()
 
 
 def test_edge_vectors(dvp):

@@ -1,5 +1,7 @@
-"""GPU tests that need MORE THAN ONE MI355X (-m gpu; skipped on a one-GPU box, which is what the builder's and the driver's
-test boxes are -- the RCCL path is otherwise exercised only by the driver's N = 2/4/8 scaling runs of bench.py).
+"""GPU tests of the multi-process / multi-device paths (-m gpu).  On a one-GPU box -- what the builder's and the driver's
+test boxes are -- RCCL runs in a one-rank group and `bench.py --gpus N` is rehearsed with every rank on cuda:0; the tests
+that need MORE THAN ONE MI355X are skipped there (the exchange between devices is otherwise exercised only by the
+driver's N = 2/4/8 scaling runs of bench.py).
 
   * two processes, one GPU each, torch.distributed over RCCL: prove_sharded must return the single-GPU proof bytes;
   * one process, dvp_set_devices([0, 1]): the in-library path over two real devices (peer copies over xGMI) -- same bytes.
@@ -31,7 +33,7 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, log_m, q):
+def _rank(rank, world, port, log_m, q, always_gather=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
     sys.path.insert(0, ROOT)
     import torch
@@ -47,10 +49,53 @@ def _rank(rank, world, port, log_m, q):
     pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
     dev = torch.device("cuda", rank)
     w = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
-    proof = dvp.distributed.prove_sharded(dvp.distributed.GpuBackend(pv, dev), w)
+    proof = dvp.distributed.prove_sharded(dvp.distributed.GpuBackend(pv, dev), w, always_gather=always_gather)
     q.put((rank, proof.to_bytes()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_rccl_collectives_execute_on_one_gpu(dvp):
+    """RCCL for real on a one-GPU box: a one-rank nccl process group, prove_sharded(always_gather=True) -- both 80-byte
+    all-gathers and the 128-byte record all-gather of the challenge phase go through RCCL kernels, the records through
+    dvp_points_sum_dev / dvp_prove_challenge_finish -- and the proof bytes must equal the plain single-GPU proof.  (What a
+    one-rank group cannot show is the exchange BETWEEN devices; that needs the two-GPU tests below.)"""
+    import torch.multiprocessing as mp
+
+    log_m = 13
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
+    td = dvp.srs.Trapdoor(0x1234567 + (1 << 200), 0x7654321 + (1 << 190), 0xABCDEF + (1 << 180))
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    ref = pv.prove(pub, prv).to_bytes()
+    pv.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rank, args=(0, 1, _free_port(), log_m, q, True))
+    p.start()
+    got = dict([q.get(timeout=600)])
+    p.join(timeout=120)
+    assert p.exitcode == 0 and got[0] == ref
+
+
+def test_bench_self_launch_rehearsal(dvp):
+    """`python bench.py --gpus N` with nothing around it must start its own ranks, and rank 0's line must say what ran.
+    Rehearsal knobs of a one-GPU box: every rank on cuda:0, gloo instead of RCCL; 3 ranks = a plan with a rank that skips
+    the extends; the in-library leg (ms_per_step_inproc, dvp_set_devices over a repeated id) runs in the child."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, DVP_BENCH_SHARE_GPU="1", DVP_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--log-m", "14"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["backend"] == "gloo" and len(d["ms_per_step_ranks"]) == 3
+    assert d["ms_per_step_inproc"] is not None and d["ms_per_step"] > 0, d.get("inproc_error")
 
 
 @pytest.mark.parametrize("world", [2])
