@@ -90,6 +90,10 @@ _SIGS = {
     "dvp_prove_dev": (C.c_int, [vp, vp, u8p, vp]),
     "dvp_prove_begin": (C.c_int, [vp, vp, vp]),
     "dvp_prove_begin_partial": (C.c_int, [vp, vp, C.c_int, vp]),
+    "dvp_prover_extend_count": (u32, [vp]),
+    "dvp_prove_extend_vectors": (C.c_int, [vp, u32, vp]),
+    "dvp_prover_extended_ptr": (C.c_int, [vp, u32, C.POINTER(vp)]),
+    "dvp_prove_quotient": (C.c_int, [vp, vp]),
     "dvp_prover_msm_size": (C.c_size_t, [vp, C.c_int]),
     "dvp_prover_msm_plan": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dvp_prover_msm_table_bytes": (C.c_uint64, [vp, C.c_int, C.POINTER(C.c_int)]),

@@ -12,32 +12,72 @@ namespace dvp {
 constexpr int INV_CHUNK = 16;  // elements per thread sharing one Fermat inversion
 
 // in-place element-wise inverse of canonical values; zeros stay zero (ark semantics).
-// Each thread owns INV_CHUNK strided elements (coalesced across the wave): prefix products,
-// one inversion, back-substitution -> 3 multiplications + 1/16 inversion per element (+2 conversions).
-__global__ void __launch_bounds__(256) k_batch_inverse(Fr* __restrict__ v, size_t n) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t stride = (size_t)gridDim.x * blockDim.x;
-  Fr x[INV_CHUNK], pre[INV_CHUNK];
+// Montgomery's trick on two levels.  A thread owns INV_CHUNK strided elements (coalesced across the block) and keeps
+// their prefix products; the 512 thread products of a block then share ONE Fermat inversion: wave 0 multiplies them up
+// (8 per lane, prefixes parked in LDS, a shuffle scan across the 64 lanes), inverts the block product and hands every
+// thread the inverse of its own product.  A wave pays for an inversion (232 squarings + ~116 products) whether one lane
+// needs it or all 64, so the first version -- every thread its own inversion -- spent 22 of its 27 products per element
+// there; this one spends ~3 (8192 elements per inversion): 3 + 2 conversions + ~3 per element.
+constexpr int BI_TPB = 512, BI_PER_LANE = BI_TPB / 64;
+__device__ __forceinline__ Fr fr_shfl(const Fr& a, int src_lane) {
+  Fr r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r.v[k] = (uint32_t)__shfl((int)a.v[k], src_lane);
+  return r;
+}
+__global__ void __launch_bounds__(BI_TPB) k_batch_inverse(Fr* __restrict__ v, size_t n) {
+  __shared__ Fr s_acc[BI_TPB], s_pre2[BI_TPB];
+  const int t = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * (BI_TPB * INV_CHUNK);
+  Fr pre[INV_CHUNK];
   Fr acc = fr_one_mont();
 #pragma unroll
   for (int k = 0; k < INV_CHUNK; ++k) {
-    size_t i = t + (size_t)k * stride;
+    const size_t i = base + (size_t)k * BI_TPB + t;
     Fr e = (i < n) ? v[i] : fr_zero();
-    bool z = fr_is_zero(e);
-    x[k] = z ? fr_one_mont() : fr_to_mont(e);
     pre[k] = acc;
-    acc = fr_mul(acc, x[k]);
-    if (z) x[k] = fr_zero();  // marker: output zero
+    if (!fr_is_zero(e)) acc = fr_mul(acc, fr_to_mont(e));  // a zero stays out of the product (its output is zero)
   }
-  Fr inv = fr_inv(acc);
+  s_acc[t] = acc;
+  __syncthreads();
+  if (t < 64) {
+    // lane t owns the thread products t, 64 + t, ... (conflict-free LDS columns)
+    Fr a2 = fr_one_mont();
+#pragma unroll
+    for (int j = 0; j < BI_PER_LANE; ++j) {
+      s_pre2[j * 64 + t] = a2;
+      a2 = fr_mul(a2, s_acc[j * 64 + t]);
+    }
+    Fr pf = a2, sf = a2;  // inclusive prefix / suffix products across the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      Fr y = fr_shfl(pf, t - o >= 0 ? t - o : t);
+      if (t >= o) pf = fr_mul(pf, y);
+      Fr z = fr_shfl(sf, t + o < 64 ? t + o : t);
+      if (t + o < 64) sf = fr_mul(sf, z);
+    }
+    Fr inv = fr_inv(fr_shfl(pf, 63));
+    Fr left = fr_shfl(pf, t > 0 ? t - 1 : 0), right = fr_shfl(sf, t < 63 ? t + 1 : 63);
+    if (t > 0) inv = fr_mul(inv, left);
+    if (t < 63) inv = fr_mul(inv, right);  // = 1 / a2 of this lane
+#pragma unroll
+    for (int j = BI_PER_LANE - 1; j >= 0; --j) {
+      Fr r = fr_mul(inv, s_pre2[j * 64 + t]);
+      inv = fr_mul(inv, s_acc[j * 64 + t]);
+      s_acc[j * 64 + t] = r;  // 1 / (thread product)
+    }
+  }
+  __syncthreads();
+  Fr inv = s_acc[t];
 #pragma unroll
   for (int k = INV_CHUNK - 1; k >= 0; --k) {
-    size_t i = t + (size_t)k * stride;
-    bool z = fr_is_zero(x[k]);
-    Fr xi = z ? fr_one_mont() : x[k];
-    Fr r = fr_mul(inv, pre[k]);
-    inv = fr_mul(inv, xi);
-    if (i < n) v[i] = z ? fr_zero() : fr_from_mont(r);
+    const size_t i = base + (size_t)k * BI_TPB + t;
+    Fr e = (i < n) ? v[i] : fr_zero();  // re-read instead of kept: 16 more live elements would not fit the register file
+    if (!fr_is_zero(e)) {
+      Fr r = fr_mul(inv, pre[k]);
+      inv = fr_mul(inv, fr_to_mont(e));
+      v[i] = fr_from_mont(r);
+    }
   }
 }
 
@@ -98,8 +138,7 @@ __global__ void __launch_bounds__(256) k_bary_final(const Fr* __restrict__ parti
 
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st) {
   if (!n) return DVP_OK;
-  size_t threads = (n + INV_CHUNK - 1) / INV_CHUNK;
-  hipLaunchKernelGGL(k_batch_inverse, dim3(cdiv(threads, 256)), dim3(256), 0, st, d, n);
+  hipLaunchKernelGGL(k_batch_inverse, dim3(cdiv(n, (size_t)BI_TPB * INV_CHUNK)), dim3(BI_TPB), 0, st, d, n);
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }

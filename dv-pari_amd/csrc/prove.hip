@@ -656,6 +656,9 @@ static bool prover_ready(dvp_prover* p) {
 
 // phase 1 (src/proving.rs:434-508): assignment -> a,b,c',i -> extend -> q2; leaves SA = [w | q2].
 // d_assignment: n_wires canonical Fr = [1, public.., private..] already in HBM.
+static uint32_t prover_n_ext(const dvp_prover* p);
+extern "C" int dvp_prove_extend_vectors(dvp_prover* p, uint32_t mask, void* stream);
+extern "C" int dvp_prove_quotient(dvp_prover* p, void* stream);
 extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream) {
   return dvp_prove_begin_partial(p, d_assignment, 1, stream);
 }
@@ -679,40 +682,69 @@ extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, 
   dim3 gm(cdiv(m, PT)), bt(PT);
   hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, p->n_pub, m, p->E, p->flags);
   DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-  if (!need_extend) {
-    DVP_HIP(hipGetLastError());
-    unsigned long long f0[2];
-    DVP_HIP(hipMemcpyAsync(f0, p->flags, 16, hipMemcpyDeviceToHost, st));
-    DVP_HIP(hipStreamSynchronize(st));
-    if (f0[0] != ~0ull) {
-      g_last_error_index = (int64_t)f0[0];
-      return DVP_EUNSAT;
-    }
-    return DVP_OK;
+  DVP_HIP(hipGetLastError());
+  if (need_extend) {
+    DVP_TRY(dvp_prove_extend_vectors(p, (1u << prover_n_ext(p)) - 1, stream));
+    DVP_TRY(dvp_prove_quotient(p, stream));
   }
-  // extend_evals (src/proving.rs:410-422): a, b, c' always; i only when its degree makes Horner the dearer route
+  unsigned long long f0[2];
+  DVP_HIP(hipMemcpyAsync(f0, p->flags, 16, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  if (f0[0] != ~0ull) {
+    g_last_error_index = (int64_t)f0[0];
+    return DVP_EUNSAT;  // assert_eq!(a*b, c+i), src/proving.rs:389-395
+  }
+  return DVP_OK;
+}
+
+// ---- the extends by VECTOR (option A) ------------------------------------------------------------------------
+// The extends of a, b, c' (and i, when it is not evaluated by Horner) are independent (src/proving.rs:410-422), so the ranks
+// of a multi-process prove that need q2 / r2 each extend only the vectors of `mask` (bit v = vector v of [a, b, c', i]),
+// exchange the extended vectors (distributed.py: one broadcast per vector inside the extender group, straight out of and
+// into dvp_prover_extended_ptr) and then run the quotient.  dvp_prove_begin_partial(need_extend = 1) is
+// begin(need_extend = 0) + extend_vectors(all) + quotient.
+static uint32_t prover_n_ext(const dvp_prover* p) {
   uint32_t hmax = HORNER_MAX_PUB;
   if (tune().horner_max_pub >= 0) hmax = (uint32_t)tune().horner_max_pub;  // tests force either route
-  const bool horner = p->n_pub <= hmax;
-  const uint32_t n_ext = horner ? 3 : 4;
-  DVP_HIP(hipMemcpyAsync(p->E2, p->E, n_ext * (size_t)m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-  {
+  return p->n_pub <= hmax ? 3u : 4u;
+}
+extern "C" uint32_t dvp_prover_extend_count(const dvp_prover* p) { return p ? prover_n_ext(p) : 0; }
+extern "C" int dvp_prover_extended_ptr(dvp_prover* p, uint32_t v, void** d_ptr) {
+  if (!p || v > 3 || !d_ptr) return DVP_EINVAL;
+  *d_ptr = p->E2 + (size_t)v * p->m;
+  return DVP_OK;
+}
+extern "C" int dvp_prove_extend_vectors(dvp_prover* p, uint32_t mask, void* stream) {
+  if (!p || !prover_ready(p)) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t m = p->m, n_ext = prover_n_ext(p);
+  if (mask >> n_ext) return DVP_EINVAL;
+  // runs of consecutive selected vectors share one batched extend (the matrices are read once per run)
+  for (uint32_t v = 0; v < n_ext;) {
+    if (!((mask >> v) & 1)) { ++v; continue; }
+    uint32_t e = v;
+    while (e < n_ext && ((mask >> e) & 1)) ++e;
+    DVP_HIP(hipMemcpyAsync(p->E2 + (size_t)v * m, p->E + (size_t)v * m, (size_t)(e - v) * m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     ProfScope pe(PROF_EXTEND_TOTAL, st);
-    DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2, n_ext, st));
+    DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2 + (size_t)v * m, e - v, st));
     pe.stop();
+    v = e;
   }
-  if (horner)
+  return DVP_OK;
+}
+// r2 = a2 b2 - i2, q2 = (r2 - c2) / Z_D on D' (src/proving.rs:492-508) from the extended vectors in place
+extern "C" int dvp_prove_quotient(dvp_prover* p, void* stream) {
+  if (!p || !prover_ready(p)) return DVP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t m = p->m;
+  const size_t nw = p->n_wires;
+  dim3 gm(cdiv(m, PT)), bt(PT);
+  if (prover_n_ext(p) == 3)
     hipLaunchKernelGGL(k_quotient<true>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
   else
     hipLaunchKernelGGL(k_quotient<false>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
   DVP_HIP(hipGetLastError());
-  unsigned long long f[2];
-  DVP_HIP(hipMemcpyAsync(f, p->flags, 16, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipStreamSynchronize(st));
-  if (f[0] != ~0ull) {
-    g_last_error_index = (int64_t)f[0];
-    return DVP_EUNSAT;  // assert_eq!(a*b, c+i), src/proving.rs:389-395
-  }
+  p->last_begin_extended = true;
   return DVP_OK;
 }
 

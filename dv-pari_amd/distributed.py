@@ -80,6 +80,32 @@ class GpuBackend:
     def begin(self, assignment, need_extend=True):
         self.prover.begin(assignment.data_ptr(), self.torch.cuda.current_stream().cuda_stream, need_extend)
 
+    # ---- the extends by vector (SURVEY 8e option A): extend only `vectors`, hand out views of the extended vectors for the
+    # exchange, then the quotient ------------------------------------------------------------------------------------------
+    def extend_count(self):
+        return self.prover.extend_count()
+
+    def extend_vectors(self, vectors):
+        mask = 0
+        for v in vectors:
+            mask |= 1 << v
+        self.prover.extend_vectors(mask, self.torch.cuda.current_stream().cuda_stream)
+
+    def extended_tensor(self, v):
+        """zero-copy int64 [m, 4] view of extended vector v inside the prover's buffers (what the broadcast sends / fills)"""
+        if getattr(self, "_ext_views", None) is None:
+            self._ext_views = {}
+        if v not in self._ext_views:
+            class _View:  # __cuda_array_interface__: torch wraps the device address without copying
+                pass
+            view = _View()
+            view.__cuda_array_interface__ = {"shape": (self.prover.m, 4), "typestr": "<i8", "data": (self.prover.extended_ptr(v), False), "version": 2}
+            self._ext_views[v] = self.torch.as_tensor(view, device=self.device)
+        return self._ext_views[v]
+
+    def quotient(self):
+        self.prover.quotient(self.torch.cuda.current_stream().cuda_stream)
+
     def dims(self):
         """(n_wires, m) of the instance: what shard_plan needs"""
         return self.prover.inst.n_wires, self.prover.m
@@ -174,18 +200,57 @@ def _all_gather_records(part, world, group):
     return torch.stack(gathered)
 
 
-def prove_sharded(backend, assignment, group=None, always_gather=False):
+_EXT_GROUPS = {}  # (id of the parent group, extender ranks) -> process group of the extender ranks
+
+
+def _extender_group(ext_ranks, group):
+    """the sub-group the extended vectors are exchanged in; dist.new_group is collective over the PARENT group, so every
+    rank calls this at the same point of its first sharded proof (the result is cached)"""
+    import torch.distributed as dist
+
+    key = (id(group) if group is not None else 0, tuple(ext_ranks))
+    if key not in _EXT_GROUPS:
+        _EXT_GROUPS[key] = dist.new_group(ranks=list(ext_ranks)) if len(ext_ranks) < dist.get_world_size(group) else group
+    return _EXT_GROUPS[key]
+
+
+def extend_owner(v, ext_ranks):
+    """the extender rank that computes extended vector v (a, b, c' [, i] round-robin over the extender ranks)"""
+    return ext_ranks[v % len(ext_ranks)]
+
+
+def prove_sharded(backend, assignment, group=None, always_gather=False, shard_extends=True):
     """Proof::prove (src/proving.rs:426-688) with both MSMs sharded over the ranks of `group`.
     Every rank returns the same proof.  always_gather runs the collectives and the record combination even in a
-    one-rank group (how a one-GPU box executes the RCCL calls of this path for real)."""
+    one-rank group (how a one-GPU box executes the RCCL calls of this path for real).
+    shard_extends: the ranks that need q2 / r2 (shard_plan's extenders) split the three extends by VECTOR -- each extends
+    the vectors it owns, one broadcast per vector inside the extender group hands them round, then every extender forms
+    the quotient (SURVEY 8e option A; DESIGN.md section 7 has the byte / latency budget)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_wires, m = backend.dims()
-    range_a, range_b, need_extend = shard_plan(world, n_wires, m)[rank]
-    backend.begin(assignment, need_extend)
+    plan = shard_plan(world, n_wires, m)
+    range_a, range_b, need_extend = plan[rank]
+    ext_ranks = [r for r in range(world) if plan[r][2]]
+    # worth it from three extenders up (one vector each): with two, the rank that owns two vectors saves one extend
+    # (~0.5 ms at 2^20) and pays for it in two 32 MB sends over the one xGMI link it shares with its peer
+    by_vector = shard_extends and len(ext_ranks) >= 3 and hasattr(backend, "extend_vectors")
+    if by_vector:
+        ext_group = _extender_group(ext_ranks, group)  # collective over `group` the first time: before any rank branches
+    if by_vector and need_extend:
+        backend.begin(assignment, False)
+        n_ext = backend.extend_count()
+        backend.extend_vectors([v for v in range(n_ext) if extend_owner(v, ext_ranks) == rank])
+        work = [dist.broadcast(backend.extended_tensor(v), src=dist.get_global_rank(group, extend_owner(v, ext_ranks)) if group is not None
+                               else extend_owner(v, ext_ranks), group=ext_group, async_op=True) for v in range(n_ext)]
+        for wk in work:
+            wk.wait()
+        backend.quotient()
+    else:
+        backend.begin(assignment, need_extend)
     assert backend.msm_size(0) == n_wires + m and backend.msm_size(1) == 4 * m
     proof = None
     for which in (0, 1):

@@ -215,6 +215,21 @@ class Prover:
     def begin(self, d_assignment: int, stream: int = 0, need_extend: bool = True):
         check(lib.dvp_prove_begin_partial(self._h, d_assignment, int(need_extend), stream), "dvp_prove_begin")
 
+    def extend_count(self) -> int:
+        """3 (a, b, c'; i by Horner) or 4: the vectors Proof::extend_evals extends (src/proving.rs:410-422)"""
+        return int(lib.dvp_prover_extend_count(self._h))
+
+    def extend_vectors(self, mask: int, stream: int = 0):
+        check(lib.dvp_prove_extend_vectors(self._h, mask, stream), "dvp_prove_extend_vectors")
+
+    def extended_ptr(self, v: int) -> int:
+        out = C.c_void_p()
+        check(lib.dvp_prover_extended_ptr(self._h, v, C.byref(out)), "dvp_prover_extended_ptr")
+        return out.value
+
+    def quotient(self, stream: int = 0):
+        check(lib.dvp_prove_quotient(self._h, stream), "dvp_prove_quotient")
+
     def msm_size(self, which: int) -> int:
         return int(lib.dvp_prover_msm_size(self._h, which))
 

@@ -193,6 +193,16 @@ int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* stream);
 /* begin for a rank whose MSM shards need neither q2 nor r2 (they lie inside [w] and [k_a | k_b]): need_extend = 0
  * skips the extends and the quotient; need_extend != 0 is dvp_prove_begin */
 int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream);
+/* The extends by VECTOR: the extends of a, b, c' (and i, unless it is evaluated by Horner: dvp_prover_extend_count
+ * says 3 or 4) are independent (src/proving.rs:410-422).  After dvp_prove_begin_partial(need_extend = 0) a rank extends only
+ * the vectors of `mask` (bit v = vector v of [a, b, c', i]), the ranks that need q2 / r2 exchange the extended vectors --
+ * dvp_prover_extended_ptr(v) is the device address of vector v (m canonical Fr) to send from / receive into -- and
+ * dvp_prove_quotient then forms r2 and q2 (src/proving.rs:492-508).  begin_partial(need_extend = 1) is exactly
+ * begin_partial(0) + dvp_prove_extend_vectors(all) + dvp_prove_quotient. */
+uint32_t dvp_prover_extend_count(const dvp_prover* p);
+int dvp_prove_extend_vectors(dvp_prover* p, uint32_t mask, void* stream);
+int dvp_prover_extended_ptr(dvp_prover* p, uint32_t v, void** d_ptr);
+int dvp_prove_quotient(dvp_prover* p, void* stream);
 size_t dvp_prover_msm_size(const dvp_prover* p, int which);
 /* window bits / window count chosen for MSM `which` (0,0 until its fixed-base tables exist) */
 int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows);

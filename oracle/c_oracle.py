@@ -26,6 +26,19 @@ def build(force=False):
     return LIB_PATH
 
 
+def host_threads(cap: int = 64) -> int:
+    """threads this process may really use: the affinity mask clipped by the cgroup CPU quota (a one-GPU box shows the
+    whole host in its mask but owns 16 CPUs of it)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 _lib = None
 
 
@@ -215,6 +228,8 @@ def _ecfft_lib():
         build()
         _ecfft = C.CDLL(ECFFT_PATH)
         vp = C.c_void_p
+        _ecfft.dvo_ecfft_set_threads.argtypes = [C.c_int]
+        _ecfft.dvo_ecfft_set_threads(host_threads())
         _ecfft.dvo_fftree_new.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp]
         _ecfft.dvo_fftree_new.restype = vp
         _ecfft.dvo_fftree_free.argtypes = [vp]

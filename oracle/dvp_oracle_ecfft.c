@@ -26,6 +26,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef uint64_t u64;
 typedef unsigned __int128 u128;
@@ -84,6 +87,15 @@ static inline fe fe_mul(fe a, fe b) {
   memcpy(r.v, t, 32);
   if (ge_p(r.v, t[4])) sub_p(r.v);
   return r;
+}
+/* OpenMP sizes its team by the affinity mask, which on a shared host is far larger than the CPU quota of the container:
+ * the caller passes the number of threads it may really use (oracle/c_oracle.py reads the cgroup quota) */
+void dvo_ecfft_set_threads(int n) {
+#ifdef _OPENMP
+  if (n >= 1) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
 }
 static void fe_init(void) {
   if (g_init) return;

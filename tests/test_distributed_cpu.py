@@ -74,6 +74,28 @@ def _worker(rank, world, port, q):
                 self.sc[1] = self.sc[1][:16] + [54321] * 16
             self.bases = [[co.k233_mulgen(k) for k in st["g_m"] + st["g_q"]], [co.k233_mulgen(k) for k in gk]]
 
+        # the extends by vector (distributed.prove_sharded, from three extender ranks up): this rank's own extended vectors
+        # are the oracle's, the others start as poison and must arrive by broadcast; the quotient recomputed from what
+        # arrived must be the oracle's q2 / r2
+        def extend_count(self):
+            return 3
+
+        def extend_vectors(self, vectors):
+            self.vector_sharded = sorted(vectors)
+            names = ("a2", "b2", "c2")
+            self.ext = [torch.from_numpy(to_limbs(self.pr[names[v]] if v in vectors else [777] * 8).view(np.int64).copy()) for v in range(3)]
+
+        def extended_tensor(self, v):
+            return self.ext[v]
+
+        def quotient(self):
+            a2, b2, c2 = ([int.from_bytes(row.numpy().view(np.uint64).tobytes(), "little") for row in t] for t in self.ext)
+            assert [a2, b2, c2] == [self.pr["a2"], self.pr["b2"], self.pr["c2"]], "an extended vector did not arrive"
+            r2 = [(a2[i] * b2[i] - self.pr["i2"][i]) % o.P for i in range(8)]
+            q2 = [(r2[i] - c2[i]) * st["tables"]["z_vals2inv"][i] % o.P for i in range(8)]
+            assert r2 == self.pr["r2"] and q2 == self.pr["q2"]
+            self.sc = [self.pr["w"] + q2, self.pr["s_k"]]  # un-poison: this rank now holds q2 and (through r2) k_r
+
         def _alpha(self, dl):
             return o.transcript_challenge(co.xsk233_encode(co.k233_mulgen(dl)), o.TOY_PUBLIC)
 
@@ -137,7 +159,7 @@ def _worker(rank, world, port, q):
     exp_commit = co.xsk233_encode(co.k233_mulgen(be.pr["dl_commit_p"]))
     exp_kzg = co.xsk233_encode(co.k233_mulgen(be.pr["dl_kzg"]))
     ok = proof[0] == exp_commit and proof[1] == exp_kzg and getattr(be, "sharded_challenge", False)
-    q.put((rank, ok, proof[0].hex()))
+    q.put((rank, ok, proof[0].hex(), getattr(be, "vector_sharded", None)))
     dist.destroy_process_group()
 
 
@@ -161,5 +183,11 @@ def test_prove_sharded_gloo(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _ in res), res
-    assert len({h for _, _, h in res}) == 1  # every rank holds the same commitment
+    assert all(r[1] for r in res), res
+    assert len({r[2] for r in res}) == 1  # every rank holds the same commitment
+    # from three extender ranks up the extends are split by vector: every vector has exactly one owner among the extenders
+    sys.path.insert(0, ROOT)
+    dist_mod = importlib.import_module("dv-pari_amd.distributed")
+    n_ext_ranks = sum(1 for pl in dist_mod.shard_plan(world, 8, 8) if pl[2])
+    owned = sorted(v for r in res if r[3] is not None for v in r[3])
+    assert owned == ([0, 1, 2] if n_ext_ranks >= 3 else []), (n_ext_ranks, res)

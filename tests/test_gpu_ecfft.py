@@ -85,8 +85,8 @@ def test_multiblock_extend_enter_exit_vs_oracle(dvp, log_n, shifted):
     t.close()
 
 
-def test_extend_2_20_and_enter_2_18_vs_oracle(dvp, big_tree):
-    """the prover's own extend (m = 2^20, batch 3: a, b, c'; src/proving.rs:410-422) and a 2^18-coefficient enter,
+def test_extend_2_20_and_enter_2_16_vs_oracle(dvp, big_tree):
+    """the prover's own extend (m = 2^20, batch 3: a, b, c'; src/proving.rs:410-422) and a 2^16-coefficient enter,
     every element against the oracle's FFTree"""
     m = 1 << 20
     ot = co.FFTree(21)
@@ -96,10 +96,10 @@ def test_extend_2_20_and_enter_2_18_vs_oracle(dvp, big_tree):
     for b in range(3):
         assert np.array_equal(out[b], ot.extend(ev[b])), b
     ot.close()
-    t = dvp.ec_fft.FFTree(1 << 18)
-    o18 = co.FFTree(18)
-    c = rand_fr_np(1 << 18, 1818)
-    assert np.array_equal(t.enter(c), o18.enter(c))
+    t = dvp.ec_fft.FFTree(1 << 16)
+    o16 = co.FFTree(16)
+    c = rand_fr_np(1 << 16, 1616)
+    assert np.array_equal(t.enter(c), o16.enter(c))
     t.close()
 
 

@@ -31,6 +31,10 @@ shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, f"{
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))
 shutil.copy(one("msm/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_msm_kernel_stats.csv"))
 shutil.copy(os.path.join(SRC, "msm_bench.log"), os.path.join(DST, f"{tag}_msm_bench.log"))
+try:
+    shutil.copy(one("msm16/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_msm_2p16_kernel_stats.csv"))
+except AssertionError:
+    pass
 
 
 def round0_dispatches(dirname):
@@ -79,20 +83,27 @@ traffic = {
 # into one figure -- read bytes = 32 B x (32-byte requests) + 64 B x (the others), unless the guide's 128-byte tally applies
 try:
     tcc = round0_dispatches("pmc_tcc")
-    rd, rd32 = avg(tcc, "TCC_EA0_RDREQ_sum"), avg(tcc, "TCC_EA0_RDREQ_32B_sum")
-    hit, miss = avg(tcc, "TCC_HIT_sum"), avg(tcc, "TCC_MISS_sum")
-    read_bytes = 32.0 * rd32 + 64.0 * (rd - rd32)
+    rd, rd32, rd64, rd128 = (avg(tcc, k) for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"))
+    read_bytes = 32.0 * rd32 + 64.0 * rd64 + 128.0 * rd128
     traffic["tcc_requests"] = {
-        "source": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace (one more separate pass of the same command)",
-        "TCC_EA0_RDREQ": rd, "TCC_EA0_RDREQ_32B": rd32, "TCC_HIT": hit, "TCC_MISS": miss,
-        "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
-        "read_bytes_32B_64B_split": read_bytes,
+        "source": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace, and a second pass with "
+                  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum (separate passes of the same command, counters + kernel trace only)",
+        "TCC_EA0_RDREQ": rd, "TCC_EA0_RDREQ_32B": rd32, "TCC_EA0_RDREQ_64B": rd64, "TCC_EA0_RDREQ_128B": rd128,
+        "read_bytes_by_request_size": read_bytes,
         "read_requests_per_addition": rd / b["roofline"]["work_model"]["additions_per_launch"],
         "avg_duration_ms_under_pmc": avg(tcc, "ms"),
     }
+    try:
+        t2 = round0_dispatches("pmc_tcc2")
+        hit, miss = avg(t2, "TCC_HIT_sum"), avg(t2, "TCC_MISS_sum")
+        traffic["tcc_requests"].update({"TCC_HIT": hit, "TCC_MISS": miss, "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
+                                        "TCC_EA0_RDREQ_DRAM": avg(t2, "TCC_EA0_RDREQ_DRAM_sum"), "TCC_REQ": avg(t2, "TCC_REQ_sum")})
+    except Exception as e2:
+        traffic["tcc_requests"]["second_pass_unavailable"] = str(e2)[:200]
     traffic["traffic_bytes_per_launch_best"] = read_bytes + w_kb * 1024.0
-    traffic["reading"] = ("FETCH_SIZE x 1024 = %.3g B against 32/64-byte request bytes %.3g B: ratio %.2f (1.0 = FETCH_SIZE already counts these requests at their "
-                          "size, i.e. the x2 correction for 128-byte streaming requests does not apply to this kernel's 64-byte gathers)" % (f_kb * 1024.0, read_bytes, read_bytes / (f_kb * 1024.0)))
+    traffic["reading"] = ("read bytes by request size (32 B x %.3g + 64 B x %.3g + 128 B x %.3g) = %.3g B against FETCH_SIZE x 1024 = %.3g B: ratio %.2f -- "
+                          "1.0 means FETCH_SIZE already counts this kernel's requests at their size, 2.0 that the guide's x2 correction applies"
+                          % (rd32, rd64, rd128, read_bytes, f_kb * 1024.0, read_bytes / (f_kb * 1024.0)))
 except Exception as e:  # counters missing on this build: keep the two-convention spread
     traffic["tcc_requests"] = {"unavailable": str(e)[:200]}
 json.dump(traffic, open(os.path.join(DST, f"{tag}_pmc_traffic_k_affine_round0.json"), "w"), indent=1)

@@ -21,9 +21,10 @@ timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_B
 echo "pmc sq done"
 # request-level view of the same launches (resolves FETCH_SIZE's request-size ambiguity): read requests of the L2's memory side, how many
 # of them are 32-byte ones, and the L2 hit / miss split.  Counter names differ between ROCm builds: the list is saved first.
-(rocprofv3 -L 2>/dev/null | grep -E "TCC_(EA0_RDREQ|HIT|MISS|BUBBLE|EA0_RD_UNCACHED|REQ|READ)" | sort -u | head -80) > $OUT/tcc_counters.txt || true
-timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace -d $OUT/pmc_tcc -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err || echo "pmc tcc pass failed (see pmc_tcc.err)"
+timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace -d $OUT/pmc_tcc -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err || echo "pmc tcc pass failed (see pmc_tcc.err)"
+timeout -k 10 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum --kernel-trace -d $OUT/pmc_tcc2 -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_tcc2.json 2> $OUT/pmc_tcc2.err || echo "pmc tcc2 pass failed (see pmc_tcc2.err)"
 echo "pmc tcc done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 20 22 > $OUT/msm_bench.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm16 -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 > $OUT/msm16_bench.log 2>&1
 echo "msm stats done"
 ls -R $OUT | head -40
