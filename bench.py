@@ -449,7 +449,8 @@ def main():
             "msm_pairs_per_proof": inst.n_wires + 5 * m,
             "sharding": ("in-library (dvp_set_devices): MSM index ranges per device, one host thread each, partial points added on device 0"
                          if n_dev_inproc > 1 else
-                         "MSM index ranges per rank, all-gather of partial points + local add; challenge "
+                         "MSM index ranges per rank, all-gather of partial points + local add; extends by vector among the ranks that need q2 / r2 "
+                         "(from three such ranks up: one broadcast per vector); challenge "
                          "phase (inversions, barycentric sums, K scalars) by index with one all-gather of 128-byte records" if world > 1 else "single GPU"),
             "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "sliding": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
                             "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "sliding": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},

@@ -163,11 +163,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_prove_sharded_gloo(world):
     """world 2: uniform slices; world 3: one rank skips the extends (distributed.shard_plan) and owns only [w], [k_a|k_b];
-    world 8 (the node size the bench is run at): half of the ranks skip the extends, one-element shards, eight records per
-    all-gather"""
+    world 4: three extender ranks, so the extends are split by vector (one each, three broadcasts in the extender group);
+    world 8 (the node size the bench is run at): three ranks skip the extends, five share them by vector, one-element
+    shards, eight records per all-gather"""
     import torch.multiprocessing as mp
 
     s = socket.socket()

@@ -80,21 +80,22 @@ def test_rccl_collectives_execute_on_one_gpu(dvp):
 
 def test_bench_self_launch_rehearsal(dvp):
     """`python bench.py --gpus N` with nothing around it must start its own ranks, and rank 0's line must say what ran.
-    Rehearsal knobs of a one-GPU box: every rank on cuda:0, gloo instead of RCCL; 3 ranks = a plan with a rank that skips
-    the extends; the in-library leg (ms_per_step_inproc, dvp_set_devices over a repeated id) runs in the child."""
+    Rehearsal knobs of a one-GPU box: every rank on cuda:0, gloo instead of RCCL; 4 ranks = a plan with one rank that skips
+    the extends and three that split them by vector (three broadcasts of device buffers in the extender group); the
+    in-library leg (ms_per_step_inproc, dvp_set_devices over a repeated id) runs in the child."""
     import json
     import subprocess
 
     env = dict(os.environ, DVP_BENCH_SHARE_GPU="1", DVP_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--log-m", "14"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--log-m", "14"],
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["backend"] == "gloo" and len(d["ms_per_step_ranks"]) == 3
+    assert d["n_gpus"] == 4 and d["rccl_ranks"] == 4 and d["backend"] == "gloo" and len(d["ms_per_step_ranks"]) == 4
     assert d["ms_per_step_inproc"] is not None and d["ms_per_step"] > 0, d.get("inproc_error")
 
 

@@ -262,6 +262,59 @@ def test_sharded_challenge_simulated_ranks(dvp, world):
     assert proof == ref and dvp.srs.verify(td, pub, proof)
 
 
+@pytest.mark.parametrize("horner_max_pub", [-1, 0])
+def test_extends_by_vector_simulated_ranks(dvp, horner_max_pub):
+    """The extends split by VECTOR over the ranks that need q2 / r2 (SURVEY 8e option A; distributed.prove_sharded from three
+    extender ranks up): every simulated rank -- its own prover, begin without extends -- extends only the vectors it owns,
+    the extended vectors are copied between the provers' own buffers through the zero-copy views the broadcast uses
+    (GpuBackend.extended_tensor), and the quotient of every rank must equal the single-GPU prover's a2 b2 c2 r2 q2.  Both
+    routes for i(X): Horner (3 vectors) and a fourth extend (DVP_HORNER_MAX_PUB = 0)."""
+    import torch
+
+    knobs = {} if horner_max_pub < 0 else {"DVP_HORNER_MAX_PUB": horner_max_pub}
+    with dvp.tune(**knobs):
+        inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(12)
+        rnd = random.Random(79)
+        td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+        pv = dvp.proving.Prover(inst)
+        srs = dvp.srs.verifier_runs_setup(pv, inst, td)
+        pv.set_srs(srs)
+        ref = pv.prove(pub, prv)
+        want = {n: pv.debug(n) for n in ("a2", "b2", "c2", "i2", "r2", "q2")}
+        dev = torch.device("cuda", 0)
+        assignment = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).to(dev)
+        n_ext = pv.extend_count()
+        assert n_ext == (3 if horner_max_pub < 0 else 4)
+        ranks = []
+        for r in range(3):
+            q = dvp.proving.Prover(inst)
+            q.set_srs(srs)
+            ranks.append(dvp.distributed.GpuBackend(q, dev))
+        ext_ranks = [0, 1, 2]
+        for r, be in enumerate(ranks):
+            be.begin(assignment, False)
+            be.extend_vectors([v for v in range(n_ext) if dvp.distributed.extend_owner(v, ext_ranks) == r])
+        for v in range(n_ext):  # the broadcast: the owner's vector into every other rank's buffer
+            src = ranks[dvp.distributed.extend_owner(v, ext_ranks)].extended_tensor(v)
+            for r, be in enumerate(ranks):
+                if r != dvp.distributed.extend_owner(v, ext_ranks):
+                    be.extended_tensor(v).copy_(src)
+        torch.cuda.synchronize()
+        for be in ranks:
+            be.quotient()
+            for n in want:
+                assert np.array_equal(be.prover.debug(n), want[n]), n
+        # and the rest of the proof from one of them
+        be = ranks[1]
+        commit = be.msm_partial(0, 0, be.msm_size(0)).clone()
+        be.challenge(commit)
+        proof = be.finish(be.msm_partial(1, 0, be.msm_size(1)).clone())
+        assert proof == ref
+        for be in ranks:
+            be.prover.close()
+        pv.close()
+
+
 def test_prove_2_20_full_size(dvp):
     """BASELINE config #4 at full size (2^20 constraints), oracle-backed (tests/fullsize.py): the domain and the SRS
     scalars are pinned on sampled indices by their definitions, commit_p / kzg_k by the discrete-log identity against

@@ -49,7 +49,18 @@ for world in [int(x) for x in os.environ.get("SHARD_WORLDS", "1,2,4,8").split(",
         acc = None
         for rep in range(4):
             ph = {}
-            _, ph["begin"] = timed(lambda: be.begin(assignment, need))
+            ext_ranks = [r for r in range(world) if plan[r][2]]
+            if need and len(ext_ranks) >= 3 and os.environ.get("SHARD_EXTENDS", "vector") != "replicated":
+                # extends by vector (prove_sharded from three extender ranks up): this rank's own vectors + the quotient; the
+                # broadcasts of the other vectors (2 x 32 MB in, <= 32 MB out per rank at 2^20) are NOT in a one-GPU projection
+                own = [v for v in range(pv.extend_count()) if dvp.distributed.extend_owner(v, ext_ranks) == rank]
+                def beg():
+                    be.begin(assignment, False)
+                    be.extend_vectors(own)
+                    be.quotient()
+                _, ph["begin"] = timed(beg)
+            else:
+                _, ph["begin"] = timed(lambda: be.begin(assignment, need))
             _, ph["msmA_part"] = timed(lambda: be.msm_partial(0, *range_a))
             if world > 1 and os.environ.get("SHARD_CHALLENGE", "sharded") != "full":  # the index-sharded challenge: own slice of the sums, (stand-in for the all-gather: the own record
                 # repeated -- the values do not matter for the timing), then the K scalars of the own range only
