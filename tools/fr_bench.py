@@ -1,11 +1,12 @@
 """Fr vector kernels alone: batch inversion of 2^21 elements (the [den | den2] inversion of a 2^20-constraint proof) -- python tools/fr_bench.py"""
 import importlib, os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, torch
 dvp = importlib.import_module("dv-pari_amd")
-from util import rand_fr_np
 n = 1 << 21
-a = rand_fr_np(n, 5)
+rng = np.random.default_rng(5)
+a = rng.integers(0, 2**62, size=(n, 4), dtype=np.uint64)
+a[:, 3] &= np.uint64((1 << 38) - 1)  # < 2^230 < p
 a[17] = 0
 d = torch.from_numpy(a.view(np.int64)).cuda()
 ref = d.clone()
