@@ -674,14 +674,18 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, 
   return lo;
 }
 
-template <bool INDIRECT>
+// QUAD: one task per quad of lanes (quad-cooperative products, gf233.cuh).  A small MSM -- config #2's 2^16 points, the shard
+// of one rank of an 8-way split -- has fewer reducer tasks than the chip has lanes and its fan-in-K chains are pure
+// latency: 2.2x shorter per addition this way (the same trade k_merge<true> makes for the deep merge levels).
+constexpr uint32_t ACCUM_QUAD_MAX = 49152;  // tasks: 4 lanes each = one chip-full of 3 blocks per CU
+template <bool INDIRECT, bool QUAD>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
                Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLdsK L = gf_ldsk_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (QUAD) tid >>= 2;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
   uint32_t j = tid - toff[key];
@@ -691,30 +695,51 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   // the affine rounds, where x == 0 marks infinity
   Aff first = INDIRECT ? bases[items[start]] : bases[start];
   Ld acc = (!INDIRECT && gf_is_zero(first.x)) ? ld_infinity() : ld_from_aff(first);
+  if (QUAD) {
+    GfLdsQ L = gf_ldsq_init(lds_raw);
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) {
-    Aff q = INDIRECT ? bases[items[start + t]] : bases[start + t];
-    if (!INDIRECT && gf_is_zero(q.x)) continue;
-    ld_madd_ip(acc, q, L);
+    for (uint32_t t = 1; t < len; ++t) {
+      Aff q = INDIRECT ? bases[items[start + t]] : bases[start + t];
+      if (!INDIRECT && gf_is_zero(q.x)) continue;
+      ld_madd_ip(acc, q, L);
+    }
+    if (L.r == 0) out[tid] = acc;
+  } else {
+    GfLdsK L = gf_ldsk_init(lds_raw);
+#pragma unroll 1
+    for (uint32_t t = 1; t < len; ++t) {
+      Aff q = INDIRECT ? bases[items[start + t]] : bases[start + t];
+      if (!INDIRECT && gf_is_zero(q.x)) continue;
+      ld_madd_ip(acc, q, L);
+    }
+    out[tid] = acc;
   }
-  out[tid] = acc;
 }
 
+template <bool QUAD>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
              const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K, Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
-  GfLdsK L = gf_ldsk_init(lds_raw);
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (QUAD) tid >>= 2;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
   uint32_t j = tid - toff[key];
   uint32_t start = off[key] + j * K;
   uint32_t len = min(K, cnt[key] - j * K);
   Ld acc = in[start];
+  if (QUAD) {
+    GfLdsQ L = gf_ldsq_init(lds_raw);
 #pragma unroll 1
-  for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
-  out[tid] = acc;
+    for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
+    if (L.r == 0) out[tid] = acc;
+  } else {
+    GfLdsK L = gf_ldsk_init(lds_raw);
+#pragma unroll 1
+    for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
+    out[tid] = acc;
+  }
 }
 
 // ---- multi-squaring tables for the fast inversion (gf233.cuh) ----------------------------------------
@@ -1258,7 +1283,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
         attr_err = hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE1_LDS);
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
-      const void* ec[] = {(const void*)k_accum_affine<true>, (const void*)k_accum_affine<false>, (const void*)k_accum_proj, (const void*)k_merge<false>, (const void*)k_merge<true>,
+      const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
+                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false>, (const void*)k_merge<true>,
                           (const void*)k_affine_round<true>, (const void*)k_affine_round<false>, (const void*)k_sum_points, (const void*)k_tail};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
@@ -1469,12 +1495,23 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     int nxt = (cur + 1) % 3;
     DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
+    // tmax is an upper bound on the tasks (the real count sits on the device); quads when even the bound fits one chip-full
+#define DVP_ACCUM_AFFINE(IND)                                                                                                                  \
+  do {                                                                                                                                         \
+    if (tmax <= ACCUM_QUAD_MAX)                                                                                                                \
+      hipLaunchKernelGGL((k_accum_affine<IND, true>), dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, pts_in, items, pc[cur], po[cur], \
+                         po[nxt], nk, p.K, bufA);                                                                                              \
+    else                                                                                                                                       \
+      hipLaunchKernelGGL((k_accum_affine<IND, false>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur],     \
+                         po[nxt], nk, p.K, bufA);                                                                                              \
+  } while (0)
     if (ra == 0) {
       ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // small inputs: no pair rounds, this is the dominant kernel
-      hipLaunchKernelGGL((k_accum_affine<true>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, p.K, bufA);
+      DVP_ACCUM_AFFINE(true);
       ps0.stop();
     } else
-      hipLaunchKernelGGL((k_accum_affine<false>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur], po[nxt], nk, p.K, bufA);
+      DVP_ACCUM_AFFINE(false);
+#undef DVP_ACCUM_AFFINE
     cur = nxt;
     cap = tmax;
     Ld *in = bufA, *outb = bufB;
@@ -1482,7 +1519,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       nxt = (cur + 1) % 3;
       DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
       tmax = cap / p.K + nk + 1;
-      hipLaunchKernelGGL(k_accum_proj, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
+      if (tmax <= ACCUM_QUAD_MAX)
+        hipLaunchKernelGGL(k_accum_proj<true>, dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
+      else
+        hipLaunchKernelGGL(k_accum_proj<false>, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
       cap = tmax;
       cur = nxt;
       Ld* t = in; in = outb; outb = t;
