@@ -1235,6 +1235,9 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   uint32_t K = (uint32_t)(p.e_max / 262144);
   if (K < 8) K = 8;
   if (K > 16) K = 16;
+  // small inputs (config #2's 2^16 points: ~1.5 M entries) are chain latency in the reducer as well: 2^16 .. 2^18 points run
+  // 5-10 % faster with three additions per task than with seven (tools/small_msm_sweep.py)
+  if (!fixed && n <= ((size_t)1 << 18)) K = 4;
   // fixed-base mode: the reducer only sees what the pair rounds leave (<= ~20 entries in the fullest buckets) and is pure
   // chain latency there: two levels of <= 7 additions beat one of <= 15 (2^20 prove: 24.26 against 24.58 ms)
   if (fixed) K = 8;
@@ -1495,10 +1498,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     int nxt = (cur + 1) % 3;
     DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
+    const size_t accum_quad_max = tn.msm_accum_quad_max > 0 ? (size_t)tn.msm_accum_quad_max : ACCUM_QUAD_MAX;
     // tmax is an upper bound on the tasks (the real count sits on the device); quads when even the bound fits one chip-full
 #define DVP_ACCUM_AFFINE(IND)                                                                                                                  \
   do {                                                                                                                                         \
-    if (tmax <= ACCUM_QUAD_MAX)                                                                                                                \
+    if (tmax <= accum_quad_max)                                                                                                                \
       hipLaunchKernelGGL((k_accum_affine<IND, true>), dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, pts_in, items, pc[cur], po[cur], \
                          po[nxt], nk, p.K, bufA);                                                                                              \
     else                                                                                                                                       \
@@ -1519,7 +1523,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       nxt = (cur + 1) % 3;
       DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
       tmax = cap / p.K + nk + 1;
-      if (tmax <= ACCUM_QUAD_MAX)
+      if (tmax <= accum_quad_max)
         hipLaunchKernelGGL(k_accum_proj<true>, dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
       else
         hipLaunchKernelGGL(k_accum_proj<false>, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
