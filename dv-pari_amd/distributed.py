@@ -33,11 +33,13 @@ def shard_plan(world: int, n_wires: int, m: int, extend_pairs: float = None):
     s minimises the larger load.  s == world (uniform slices, every rank extends) is what small worlds get."""
     ta, tb = n_wires + m, 4 * m
     cap_a, cap_b = n_wires, 2 * m
-    # measured on MI355X (round 2, tools/shard_profile.py): R1CS evaluation + three extends + quotient of 2^20 = 1.58 ms, the time
-    # the sharded MSMs take for ~0.42 * 2^20 (scalar, base) pairs
-    e = 0.42 * m if extend_pairs is None else extend_pairs
+    # measured on MI355X (tools/shard_profile.py): R1CS evaluation + three extends + quotient of 2^20 = 1.58 ms, the time the
+    # sharded MSMs take for ~0.42 * 2^20 (scalar, base) pairs.  From three extenders up the extends are split by vector
+    # (prove_sharded): an extender then spends 0.25 ms (quotient only) to 0.9 ms (one vector + quotient) plus the broadcasts
+    # of the vectors it does not own (64-96 MB in over xGMI, not measurable on a one-GPU box): charged as 0.30 * m pairs
     best = None
     for s in range(world, 0, -1):
+        e = (0.42 if s < 3 else 0.30) * m if extend_pairs is None else extend_pairs
         if s == world:
             x, load = 0.0, e + (ta + tb) / world
         else:
