@@ -28,7 +28,7 @@ outside the timed loop, and `bound` names the larger fraction:
 `traffic` / `issue` come from the committed rocprofv3 PMC passes of this same command (profiles/): counters cannot be
 collected inside an un-profiled run.
 cpu_baseline: the C restatement with the reference's algorithmic shape (oracle/dvp_oracle.c: one tau-adic scalar
-multiplication per point + add tree; the extend butterflies and the pointwise Fr stages in 4 x 64-bit Montgomery
+multiplication per point -- width-5 tau-NAF, PCLMULQDQ field arithmetic -- + add tree; the extend butterflies and the pointwise Fr stages in 4 x 64-bit Montgomery
 arithmetic) on this box's host cores on a bounded sample, and OpenSSL's EC_POINT_mul per point as a third-party datapoint.
 """
 import argparse
@@ -546,7 +546,7 @@ def main():
             "cpu_affinity_mask": mask,
             "cgroup_cpu_quota": quota,
             "kind": "port",
-            "sample": f"{n_s}-point reference-shaped MSM (one tau-adic scalar multiplication per point + add tree, oracle/dvp_oracle.c) in "
+            "sample": f"{n_s}-point reference-shaped MSM (one width-5 tau-NAF scalar multiplication per point + add tree, oracle/dvp_oracle.c) in "
                       f"{dt:.1f}s = {pts_per_s:.0f} points/s on {cores} threads = {us_core:.1f} us*core per point"
                       + (f" (~{us_core * mhz / 1e3:.0f} k cycles at {mhz:.0f} MHz; xs233's own xsk233_mul_frob is quoted at ~29.6 k cycles, so the "
                          f"reference's C library would be ~{us_core * mhz / 1e3 / 29.6:.1f}x faster than this port)" if mhz else "")

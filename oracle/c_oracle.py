@@ -112,11 +112,13 @@ def _pt_in(pt):
     return np.concatenate([_limbs(pt[0]), _limbs(pt[1])]), 0
 
 
-def k233_mul(k, pt, frob=True):
+def k233_mul(k, pt, frob=True, tnaf5=False):
+    """k * pt by one of three independent routes: integer double-and-add (frob=False), tau-adic 4-digit windows (default),
+    width-5 tau-NAF (tnaf5=True: what the timed reference-shaped MSM uses)"""
     a, inf = _pt_in(pt)
     o = np.zeros(8, dtype=np.uint64)
     oi = C.c_int(0)
-    lib().dvo_k233_mul(_p(_limbs(k)), _p(a), inf, 1 if frob else 0, _p(o), C.byref(oi))
+    lib().dvo_k233_mul(_p(_limbs(k)), _p(a), inf, 2 if tnaf5 else (1 if frob else 0), _p(o), C.byref(oi))
     return _pt_out(o, oi)
 
 

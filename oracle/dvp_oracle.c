@@ -3,7 +3,8 @@
  *
  * Plain-C CPU restatement of the DV-Pari curve hot path with the REFERENCE'S ALGORITHMIC SHAPE:
  * multi_scalar_mul = one independent Frobenius-based scalar multiplication per (scalar, point)
- * followed by an add tree (src/curve.rs:141-158: "For now we just compute individual point scalar
+ * (width-5 tau-NAF over a table of eight odd multiples, mixed Lopez-Dahab additions, PCLMULQDQ field arithmetic kept in
+ * XMM registers: the technique class of xs233's xsk233_mul_frob) followed by an add tree (src/curve.rs:141-158: "For now we just compute individual point scalar
  * multiplications and sum up the result").  The per-point arithmetic of the reference lives in
  * xs233-sys =0.2.0 (xsk233_mul_frob, src/curve.rs:118-123), which is not in the tree; it is restated
  * here from the mathematics (K-233 Lopez-Dahab formulas, tau-adic windowed multiplication,
@@ -24,29 +25,38 @@
 
 typedef uint64_t u64;
 typedef unsigned __int128 u128;
-typedef struct { u64 w[4]; } gf;
+/* one element = 4 x u64 little-endian; the arithmetic works on the two 128-bit halves so that values stay in XMM registers
+ * from one operation to the next (a result assembled in 64-bit registers and re-loaded as 128-bit operands by the next
+ * PCLMULQDQ defeats store forwarding: the first version spent more time there than in the multiplier itself) */
+typedef union { u64 w[4]; __m128i v[2]; } gf;
 
 /* ------------------------------------------------------------------------------------------- */
 /* GF(2^233) = GF(2)[z]/(z^233+z^74+1), 4 x u64 little-endian                                   */
 /* ------------------------------------------------------------------------------------------- */
-static inline gf gf_zero(void) { gf r = {{0, 0, 0, 0}}; return r; }
-static inline gf gf_one(void) { gf r = {{1, 0, 0, 0}}; return r; }
-static inline gf gf_add(gf a, gf b) { gf r; for (int i = 0; i < 4; ++i) r.w[i] = a.w[i] ^ b.w[i]; return r; }
-static inline int gf_is_zero(gf a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+static inline gf gf_zero(void) { gf r; r.v[0] = _mm_setzero_si128(); r.v[1] = _mm_setzero_si128(); return r; }
+static inline gf gf_one(void) { gf r; r.v[0] = _mm_set_epi64x(0, 1); r.v[1] = _mm_setzero_si128(); return r; }
+static inline gf gf_add(gf a, gf b) { gf r; r.v[0] = _mm_xor_si128(a.v[0], b.v[0]); r.v[1] = _mm_xor_si128(a.v[1], b.v[1]); return r; }
+static inline int gf_is_zero(gf a) { __m128i t = _mm_or_si128(a.v[0], a.v[1]); return _mm_testz_si128(t, t); }
 static inline int gf_eq(gf a, gf b) { return gf_is_zero(gf_add(a, b)); }
 
-static inline gf gf_reduce8(u64 c[8]) {
-  for (int j = 7; j >= 4; --j) {
-    u64 t = c[j];
-    c[j - 4] ^= t << 23;
-    c[j - 3] ^= (t >> 41) ^ (t << 33);
-    c[j - 2] ^= t >> 31;
-  }
-  u64 t = c[3] >> 41;
-  c[0] ^= t;
-  c[1] ^= t << 10;
-  c[3] &= ((u64)1 << 41) - 1;
-  gf r = {{c[0], c[1], c[2], c[3]}};
+/* 512-bit product c3:c2:c1:c0 (128 bits each) -> 233 bits.  A 64-bit word t at word position j >= 4 folds to
+ * t << 23 (word j-4), (t >> 41) ^ (t << 33) (word j-3) and t >> 31 (word j-2): z^233 = z^74 + 1, 256 - 233 = 23,
+ * 23 + 74 = 97 = 64 + 33.  Two words per step in the 64-bit lanes; the middle term straddles two registers. */
+static inline void gf_fold(__m128i t, __m128i* lo, __m128i* hi) {
+  __m128i u = _mm_xor_si128(_mm_srli_epi64(t, 41), _mm_slli_epi64(t, 33));
+  *lo = _mm_xor_si128(*lo, _mm_xor_si128(_mm_slli_epi64(t, 23), _mm_slli_si128(u, 8)));
+  *hi = _mm_xor_si128(*hi, _mm_xor_si128(_mm_srli_epi64(t, 31), _mm_srli_si128(u, 8)));
+}
+static inline gf gf_reduce(__m128i c0, __m128i c1, __m128i c2, __m128i c3) {
+  gf_fold(c3, &c1, &c2); /* words 6,7 -> words 2..5 */
+  gf_fold(c2, &c0, &c1); /* words 4,5 -> words 0..3 */
+  /* bits 233..255 of word 3: t = w3 >> 41 -> word 0, and t << 10 -> word 1 */
+  __m128i t = _mm_srli_si128(_mm_srli_epi64(c1, 41), 8);
+  c0 = _mm_xor_si128(c0, _mm_xor_si128(t, _mm_slli_si128(_mm_slli_epi64(t, 10), 8)));
+  c1 = _mm_and_si128(c1, _mm_set_epi64x((long long)(((u64)1 << 41) - 1), -1));
+  gf r;
+  r.v[0] = c0;
+  r.v[1] = c1;
   return r;
 }
 
@@ -60,31 +70,19 @@ static inline void clmul128(__m128i a, __m128i b, __m128i* lo, __m128i* hi) {
 }
 /* 256 x 256 -> 512 by one more Karatsuba level: 9 PCLMULQDQ instead of the 16 of the schoolbook form */
 static inline gf gf_mul(gf a, gf b) {
-  __m128i a0 = _mm_loadu_si128((const __m128i*)&a.w[0]), a1 = _mm_loadu_si128((const __m128i*)&a.w[2]);
-  __m128i b0 = _mm_loadu_si128((const __m128i*)&b.w[0]), b1 = _mm_loadu_si128((const __m128i*)&b.w[2]);
   __m128i l0, l1, h0, h1, m0, m1;
-  clmul128(a0, b0, &l0, &l1);
-  clmul128(a1, b1, &h0, &h1);
-  clmul128(_mm_xor_si128(a0, a1), _mm_xor_si128(b0, b1), &m0, &m1);
+  clmul128(a.v[0], b.v[0], &l0, &l1);
+  clmul128(a.v[1], b.v[1], &h0, &h1);
+  clmul128(_mm_xor_si128(a.v[0], a.v[1]), _mm_xor_si128(b.v[0], b.v[1]), &m0, &m1);
   m0 = _mm_xor_si128(m0, _mm_xor_si128(l0, h0));
   m1 = _mm_xor_si128(m1, _mm_xor_si128(l1, h1));
-  u64 c[8];
-  _mm_storeu_si128((__m128i*)&c[0], l0);
-  _mm_storeu_si128((__m128i*)&c[2], _mm_xor_si128(l1, m0));
-  _mm_storeu_si128((__m128i*)&c[4], _mm_xor_si128(h0, m1));
-  _mm_storeu_si128((__m128i*)&c[6], h1);
-  return gf_reduce8(c);
+  return gf_reduce(l0, _mm_xor_si128(l1, m0), _mm_xor_si128(h0, m1), h1);
 }
 
+/* squaring spreads the bits: each 64-bit word times itself */
 static inline gf gf_sqr(gf a) {
-  u64 c[8];
-  for (int i = 0; i < 4; ++i) {
-    __m128i ai = _mm_cvtsi64_si128((long long)a.w[i]);
-    __m128i r = _mm_clmulepi64_si128(ai, ai, 0);
-    c[2 * i] = (u64)_mm_cvtsi128_si64(r);
-    c[2 * i + 1] = (u64)_mm_extract_epi64(r, 1);
-  }
-  return gf_reduce8(c);
+  return gf_reduce(_mm_clmulepi64_si128(a.v[0], a.v[0], 0x00), _mm_clmulepi64_si128(a.v[0], a.v[0], 0x11),
+                   _mm_clmulepi64_si128(a.v[1], a.v[1], 0x00), _mm_clmulepi64_si128(a.v[1], a.v[1], 0x11));
 }
 
 static gf gf_sqr_n(gf a, int n) { while (n-- > 0) a = gf_sqr(a); return a; }
@@ -173,6 +171,13 @@ static aff ld_to_aff(ld p) {
   return r;
 }
 static ld ld_frob(ld p) { p.X = gf_sqr(p.X); p.Y = gf_sqr(p.Y); p.Z = gf_sqr(p.Z); return p; }
+static inline ld ld_frob_n(ld p, int k) {
+  gf x = p.X, y = p.Y, z = p.Z;
+  for (int i = 0; i < k; ++i) { x = gf_sqr(x); y = gf_sqr(y); z = gf_sqr(z); }
+  ld r;
+  r.X = x; r.Y = y; r.Z = z;
+  return r;
+}
 
 static const aff K233_G = {
     {{0x0a4c9d6eefad6126ull, 0x149563a419c26bf5ull, 0x7e731af129f22ff4ull, 0x0000017232ba853aull}},
@@ -311,26 +316,28 @@ static void mul_round_256(const u64 s[4], const u64 A[3], u64 q[2]) { /* round(s
   c += t[4]; q[0] = (u64)c; c >>= 64;
   c += t[5]; q[1] = (u64)c;
 }
-static int tau_digits_fast(const u64 s[4], unsigned char* dig) {
+/* the partially reduced scalar rho = r0 + r1 tau (|r0|, |r1| < 2^118: N(rho) < ~N(delta) = r) as signed 128-bit integers */
+typedef __int128 i128;
+static void tau_reduce_fast(const u64 s[4], i128* r0, i128* r1) {
   u64 Q0[2], Q1[2];
   mul_round_256(s, TAU_A0, Q0);
   mul_round_256(s, TAU_A1, Q1);
-  u64 a[4], b[4], c[4], d[4];
-  mp_mul(Q0, 2, TAU_D0, 2, a);
-  mp_mul(Q1, 2, TAU_D1, 2, b);
-  mp_mul(Q0, 2, TAU_D1, 2, c);
-  mp_mul(Q1, 2, TAU_C0M, 2, d);
-  i192 S = i192_from_mag(s, 3, 0), A = i192_from_mag(a, 3, 0), B = i192_from_mag(b, 3, 0);
-  i192 C = i192_from_mag(c, 3, 0), D = i192_from_mag(d, 3, 0);
-  i192 r0 = i192_sub(i192_add(S, A), i192_add(B, B));
-  i192 r1 = i192_sub(C, D);
+  /* rho0 = s + Q0*D0 - 2*Q1*D1 ; rho1 = Q0*D1 - Q1*(D1-D0): exact values are small, so arithmetic mod 2^128 is enough */
+  const u128 q0 = ((u128)Q0[1] << 64) | Q0[0], q1 = ((u128)Q1[1] << 64) | Q1[0];
+  const u128 d0 = ((u128)TAU_D0[1] << 64) | TAU_D0[0], d1 = ((u128)TAU_D1[1] << 64) | TAU_D1[0], c0 = ((u128)TAU_C0M[1] << 64) | TAU_C0M[0];
+  const u128 sl = ((u128)s[1] << 64) | s[0];
+  *r0 = (i128)(sl + q0 * d0 - 2 * (q1 * d1));
+  *r1 = (i128)(q0 * d1 - q1 * c0);
+}
+static int tau_digits_fast(const u64 s[4], unsigned char* dig) {
+  i128 r0, r1;
+  tau_reduce_fast(s, &r0, &r1);
   int n = 0;
-  while (!(i192_is_zero(r0) && i192_is_zero(r1)) && n < 256) {
-    unsigned u = (unsigned)(r0.w[0] & 1);
-    dig[n++] = (unsigned char)u;
-    i192 h = i192_sar1(r0);
-    r0 = i192_sub(r1, h);
-    r1 = i192_neg(h);
+  while ((r0 | r1) != 0 && n < 256) {
+    dig[n++] = (unsigned char)(r0 & 1);
+    i128 h = (r0 - (r0 & 1)) >> 1; /* (r0 - u) / 2, exact */
+    r0 = r1 - h;
+    r1 = -h;
   }
   return n;
 }
@@ -381,6 +388,113 @@ static ld k233_mul_frob(const u64 k[4], aff p) {
   return acc;
 }
 
+/* ---- (3) width-5 tau-NAF (Solinas): the multiplication the TIMED reference-shaped MSM uses ------------------------------
+ * Digits u in {0, +-1, +-3, .., +-15}, at most one nonzero in any 5 consecutive positions (density 1/6): 39 mixed additions
+ * for a 233-digit expansion instead of the 55 of the 4-digit windows above; negation is free (-(x, y) = (x, x + y)).
+ * A digit u stands for alpha_u = u mods tau^5 (the element of least norm congruent to u); the table holds alpha_u * P.
+ * t_w (tau = t_w mod tau^5 as residues mod 32) and the alpha_u = beta_u + gamma_u tau are derived at first use instead of
+ * being typed in: tau^2 = -tau - 2 (mu = -1 on K-233), N(a + b tau) = a^2 - a b + 2 b^2, conj(tau) = -1 - tau. */
+#define TNAF_W 5
+static int g_tnaf_ready = 0, g_tnaf_tw, g_tnaf_b[16], g_tnaf_g[16], g_tnaf_kmax;
+static void tnaf_init(void) {
+  if (g_tnaf_ready) return;
+  long a = 1, b = 0; /* tau^w = a + b tau */
+  for (int i = 0; i < TNAF_W; ++i) { long na = -2 * b, nb = a - b; a = na; b = nb; }
+  const long N = 1L << TNAF_W, ca = a - b, cb = -b; /* conj(tau^w) = ca + cb tau */
+  for (long t = 0; t < N; ++t) { /* the root of t^2 + t + 2 mod 2^w with tau^w | (t - tau) */
+    if ((t * t + t + 2) % N) continue;
+    long p0 = t * ca + 2 * cb, p1 = t * cb - ca + cb; /* (t - tau) * conj(tau^w) */
+    if (p0 % N == 0 && p1 % N == 0) g_tnaf_tw = (int)t;
+  }
+  int kmax = 1;
+  for (long u = 1; u < 16; u += 2) {
+    /* q = round(u * conj(tau^w) / N) coordinate-wise, then the neighbour of least norm */
+    long y0 = u * ca, y1 = u * cb, q0 = (y0 + N / 2) >> TNAF_W, q1 = (y1 + N / 2) >> TNAF_W;
+    long best = -1, bb = 0, bg = 0;
+    for (long e0 = -1; e0 <= 1; ++e0)
+      for (long e1 = -1; e1 <= 1; ++e1) {
+        long r0 = q0 + e0, r1 = q1 + e1;
+        long al = u - (r0 * a - 2 * r1 * b), ga = -(r0 * b + r1 * a - r1 * b); /* u - q tau^w */
+        long nm = al * al - al * ga + 2 * ga * ga;
+        if (best < 0 || nm < best) { best = nm; bb = al; bg = ga; }
+      }
+    g_tnaf_b[u] = (int)bb;
+    g_tnaf_g[u] = (int)bg;
+    if (labs(bb) > kmax) kmax = (int)labs(bb);
+    if (labs(bg) > kmax) kmax = (int)labs(bg);
+  }
+  g_tnaf_kmax = kmax;
+  g_tnaf_ready = 1;
+}
+/* signed digits, least significant first; returns their number */
+static int tnaf5_digits(const u64 s[4], signed char* dig) {
+  i128 r0, r1;
+  tau_reduce_fast(s, &r0, &r1);
+  int n = 0;
+  while ((r0 | r1) != 0 && n < 300) {
+    int d = 0;
+    if (r0 & 1) {
+      int u = (int)((r0 + r1 * g_tnaf_tw) & ((1 << TNAF_W) - 1));
+      if (u >= (1 << (TNAF_W - 1))) u -= 1 << TNAF_W;
+      d = u;
+      const int au = u > 0 ? u : -u, sg = u > 0 ? 1 : -1;
+      r0 -= sg * g_tnaf_b[au];
+      r1 -= sg * g_tnaf_g[au];
+    }
+    dig[n++] = (signed char)d;
+    i128 h = r0 >> 1; /* r0 is even here */
+    r0 = r1 - h;
+    r1 = -h;
+  }
+  return n;
+}
+static ld ld_neg(ld p) { p.Y = gf_add(p.Y, gf_mul(p.X, p.Z)); return p; } /* -(x, y) = (x, x + y), y = Y / Z^2 */
+static ld k233_mul_tnaf5(const u64 k[4], aff p) {
+  tnaf_init();
+  signed char dig[304];
+  const int n = tnaf5_digits(k, dig);
+  if (n == 0 || p.inf) return ld_inf();
+  /* small multiples j P (j <= kmax) and their Frobenius images; alpha_u P = beta_u P + gamma_u tau(P) */
+  ld mult[8];
+  mult[1] = ld_from_aff(p);
+  for (int j = 2; j <= g_tnaf_kmax && j < 8; ++j) mult[j] = (j & 1) ? ld_madd(mult[j - 1], p) : ld_dbl(mult[j / 2]);
+  ld tab[16];
+  for (int u = 1; u < 16; u += 2) {
+    const int b = g_tnaf_b[u], g = g_tnaf_g[u];
+    ld t = ld_inf();
+    if (b) { t = mult[b > 0 ? b : -b]; if (b < 0) t = ld_neg(t); }
+    if (g) { ld f = ld_frob(mult[g > 0 ? g : -g]); if (g < 0) f = ld_neg(f); t = b ? ld_add(t, f) : f; }
+    tab[u] = t;
+  }
+  /* one shared inversion brings the eight table points to affine form (alpha_u P is never the neutral element for P in E[r]) */
+  aff ta[16];
+  gf pre[16], run = gf_one();
+  for (int u = 1; u < 16; u += 2) { pre[u] = run; run = gf_mul(run, tab[u].Z); }
+  gf inv = gf_inv(run);
+  for (int u = 15; u >= 1; u -= 2) {
+    gf zi = gf_mul(inv, pre[u]);
+    inv = gf_mul(inv, tab[u].Z);
+    ta[u].x = gf_mul(tab[u].X, zi);
+    ta[u].y = gf_mul(tab[u].Y, gf_sqr(zi));
+    ta[u].inf = 0;
+  }
+  /* runs of zero digits become one tau^k: the three coordinates are squared k times in registers, three independent chains */
+  ld acc = ld_inf();
+  int pending = 0;
+  for (int i = n - 1; i >= 0; --i) {
+    ++pending;
+    const int d = dig[i];
+    if (d) {
+      acc = ld_frob_n(acc, pending);
+      pending = 0;
+      aff q = ta[d > 0 ? d : -d];
+      if (d < 0) q.y = gf_add(q.y, q.x);
+      acc = ld_madd(acc, q);
+    }
+  }
+  return ld_frob_n(acc, pending);
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* exported API (ctypes): points are x||y as 8 x u64 + an int/byte infinity flag               */
 /* ------------------------------------------------------------------------------------------- */
@@ -401,10 +515,10 @@ void dvo_gf_mul(const u64 a[4], const u64 b[4], u64 out[4]) { gf x, y; memcpy(x.
 void dvo_gf_sqr(const u64 a[4], u64 out[4]) { gf x; memcpy(x.w, a, 32); gf r = gf_sqr(x); memcpy(out, r.w, 32); }
 void dvo_gf_inv(const u64 a[4], u64 out[4]) { gf x; memcpy(x.w, a, 32); gf r = gf_inv(x); memcpy(out, r.w, 32); }
 
-/* which: 0 = integer double-and-add, 1 = tau-adic */
+/* which: 0 = integer double-and-add, 1 = tau-adic 4-digit windows, 2 = width-5 tau-NAF */
 void dvo_k233_mul(const u64 k[4], const u64 pxy[8], int pinf, int which, u64 out[8], int* out_inf) {
   aff p = aff_load(pxy, pinf);
-  ld r = which ? k233_mul_frob(k, p) : (p.inf ? ld_inf() : k233_mul_dbl(k, p));
+  ld r = which == 2 ? k233_mul_tnaf5(k, p) : which ? k233_mul_frob(k, p) : (p.inf ? ld_inf() : k233_mul_dbl(k, p));
   aff_store(ld_to_aff(r), out, out_inf);
 }
 void dvo_k233_mulgen(const u64 k[4], u64 out[8], int* out_inf) {
@@ -431,7 +545,7 @@ static void* msm_worker(void* arg) {
   ld acc = ld_inf();
   for (size_t i = j->lo; i < j->hi; ++i) {
     aff p = aff_load(j->bases + 8 * i, j->inf ? j->inf[i] : 0);
-    ld t = k233_mul_frob(j->scalars + 4 * i, p); /* point_scalar_mul, src/curve.rs:113-126 */
+    ld t = k233_mul_tnaf5(j->scalars + 4 * i, p); /* point_scalar_mul, src/curve.rs:113-126 */
     acc = ld_add(acc, t);                        /* reduce(xsk233_add), src/curve.rs:150-157 */
   }
   j->partial = acc;
@@ -439,6 +553,7 @@ static void* msm_worker(void* arg) {
 }
 
 int dvo_msm(const u64* scalars, const u64* bases, const unsigned char* inf, size_t n, int threads, u64 out[8], int* out_inf) {
+  tnaf_init(); /* before the workers start */
   if (threads < 1) threads = 1;
   if (threads > 256) threads = 256;
   msm_job jobs[256];

@@ -48,6 +48,13 @@ def test_k233_against_openssl():
         assert co.k233_mulgen(H(e["k"])) == exp
         assert co.k233_mul(H(e["k"]), o.G_STD, frob=False) == exp  # integer double-and-add
         assert co.k233_mul(H(e["k"]), o.G_STD, frob=True) == exp   # tau-adic (reference-shaped)
+        assert co.k233_mul(H(e["k"]), o.G_STD, tnaf5=True) == exp  # width-5 tau-NAF: what the timed CPU baseline runs
+    # the three routes agree on random points and on the edge scalars (0, 1, small, p - 1, short)
+    rnd = random.Random(55)
+    pt = co.k233_mulgen(rnd.randrange(1, o.P))
+    for k in [0, 1, 2, 3, 31, 32, 33, o.P - 1, o.P - 2] + [rnd.randrange(o.P) for _ in range(200)] + [rnd.randrange(1 << rnd.randrange(1, 232)) for _ in range(100)]:
+        assert co.k233_mul(k, pt, frob=False) == co.k233_mul(k, pt) == co.k233_mul(k, pt, tnaf5=True), hex(k)
+    assert co.k233_mul(12345, None, tnaf5=True) is None
 
 
 def test_msm_linearity_like_reference():
