@@ -519,10 +519,11 @@ def main():
         dt_ext = time.perf_counter() - t1
         ns_per_frmul = dt_ext / (passes * ext_n * 2) * 1e9 * cores
         ext_s_per_proof = 4 * (2 * log_m) * (m * 2) * ns_per_frmul * 1e-9 / cores
-        # the pointwise stages (src/proving.rs:492-654): ~26 Fr products per constraint (quotient, the K scalars, three
-        # batch inversions at 3 products per element, three barycentric sums) at the same measured cost per product; the
-        # reference's sparse mat-vec and barycentric loops are sequential, which this figure does not charge
-        pointwise_s_per_proof = 26.0 * m * ns_per_frmul * 1e-9 / cores
+        # the pointwise stages (src/proving.rs:492-654: quotient, three barycentric evaluations with their own batch inversions,
+        # denominators, K scalars) actually run on 2^18-element vectors and scaled linearly; the reference's sparse mat-vec
+        # and its barycentric loops are sequential, which this figure does not charge
+        pw_n = 1 << min(log_m, 18)
+        pointwise_s_per_proof = co.fr_pointwise_stages(pw_n, cores) * (m / pw_n)
         msm_s_per_proof = (inst.n_wires + 5 * m) / pts_per_s
         cpu_s = msm_s_per_proof + ext_s_per_proof + pointwise_s_per_proof
         # "best CPU" (BASELINE.md B3): a host-side bucket method on the same cores
@@ -552,8 +553,8 @@ def main():
                          f"reference's C library would be ~{us_core * mhz / 1e3 / 29.6:.1f}x faster than this port)" if mhz else "")
                       + f"; a proof needs {pts_per_constraint:.2f} point multiplications per constraint = {msm_s_per_proof:.2f}s; plus the four "
                       f"extends as {passes} butterfly passes over 2^{ext_n.bit_length() - 1} elements in 4x64-bit Montgomery arithmetic "
-                      f"({ns_per_frmul:.0f} ns*core per Fr product) scaled to 2^{log_m} = {ext_s_per_proof:.2f}s per proof; plus the pointwise stages as "
-                      f"26 Fr products per constraint at that cost = {pointwise_s_per_proof:.3f}s",
+                      f"({ns_per_frmul:.0f} ns*core per Fr product) scaled to 2^{log_m} = {ext_s_per_proof:.2f}s per proof; plus the pointwise stages (quotient, three barycentric "
+                      f"evaluations with their batch inversions, K scalars) run on 2^{pw_n.bit_length() - 1} elements and scaled = {pointwise_s_per_proof:.3f}s",
             "msm_points_per_s": pts_per_s,
             "msm_us_core_per_point": us_core,
             "extend_s_per_proof": ext_s_per_proof,

@@ -65,6 +65,8 @@ def lib():
         _lib.dvo_fr_mont_mul.argtypes = [vp, vp, vp]
         _lib.dvo_fr_butterfly_passes.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
         _lib.dvo_fr_butterfly_passes.restype = C.c_int
+        _lib.dvo_fr_pointwise_stages.argtypes = [vp, C.c_size_t, C.c_int]
+        _lib.dvo_fr_pointwise_stages.restype = C.c_int
         for f in ("dvo_gf_mul",):
             getattr(_lib, f).argtypes = [vp, vp, vp]
         for f in ("dvo_gf_sqr", "dvo_gf_inv"):
@@ -196,6 +198,19 @@ def fr_butterfly_passes(data: np.ndarray, mats: np.ndarray, passes: int, threads
     """in place: `passes` extend-shaped butterfly passes over data [n,4] with matrices mats [2, n/2, 4, 4] (Montgomery)"""
     assert data.flags["C_CONTIGUOUS"] and mats.flags["C_CONTIGUOUS"] and mats.shape[:2] == (2, data.shape[0] // 2)
     return lib().dvo_fr_butterfly_passes(_p(data), _p(mats), data.shape[0], passes, threads)
+
+
+def fr_pointwise_stages(m: int, threads: int = 1, seed: int = 3):
+    """runs the pointwise Fr stages of Proof::prove (src/proving.rs:492-654: quotient, three barycentric evaluations with
+    their own batch inversions, denominators, K scalars) on synthetic m-length vectors; returns the wall time in seconds"""
+    import time
+
+    rng = np.random.default_rng(seed)
+    buf = rng.integers(1, 2**62, size=(21 * m, 4), dtype=np.uint64)
+    buf[:, 3] &= np.uint64((1 << 38) - 1)
+    t0 = time.perf_counter()
+    lib().dvo_fr_pointwise_stages(_p(buf), m, threads)
+    return time.perf_counter() - t0
 
 
 _ossl = None

@@ -764,3 +764,99 @@ int dvo_fr_butterfly_passes(u64* data, const u64* mats, size_t n, int passes, in
   }
   return 0;
 }
+
+/* ---- the pointwise Fr stages of Proof::prove (src/proving.rs:492-654) on m-length vectors, for the timed CPU baseline ----
+ * r2 = a2 b2 - i2, q2 = (r2 - c2) zinv            (:492-508)
+ * three barycentric evaluations, each with its OWN batch inversion of (alpha - d_i) as the reference does (:571-591 ->
+ *   src/ec_fft.rs:455-491): sum_i y_i w_i / (alpha - d_i)
+ * denominators (d - alpha), (d' - alpha) and their batch inversions (:599-616)
+ * k_a = (a - a0) inv, k_b = (b - b0) inv, r = a b - i, k_r interleaved [(r - r0) inv, (r2 - r0) inv2]   (:619-654)
+ * Values are Montgomery residues of arbitrary data (the timing does not depend on them); ark's batch_inversion = 3 products
+ * per element + one inversion per chunk.  Threads split the index range. */
+static inline void fr_sub_mod(const u64 a[4], const u64 b[4], u64 out[4]) {
+  u128 br = 0;
+  u64 r[4];
+  for (int j = 0; j < 4; ++j) { u128 d = (u128)a[j] - b[j] - (u64)br; r[j] = (u64)d; br = (d >> 64) & 1; }
+  if (br) { u128 c = 0; for (int j = 0; j < 4; ++j) { c += (u128)r[j] + FR_P[j]; r[j] = (u64)c; c >>= 64; } }
+  memcpy(out, r, 32);
+}
+static void fr_inv_mont(const u64 a[4], u64 out[4]) { /* a^(p-2) */
+  u64 e[4], r[4], acc[4]; /* left-to-right square and multiply over the 232 bits of p - 2 (bit 231 is set) */
+  memcpy(e, FR_P, 32);
+  e[0] -= 2;
+  memcpy(r, a, 32);
+  memcpy(acc, a, 32);
+  for (int i = 230; i >= 0; --i) {
+    fr_mont_mul(acc, acc, acc);
+    if ((e[i >> 6] >> (i & 63)) & 1) fr_mont_mul(acc, r, acc);
+  }
+  memcpy(out, acc, 32);
+}
+static void fr_batch_inv(u64* v, size_t n, u64* scratch) { /* in place, n x 4; scratch n x 4 */
+  u64 run[4] = {1, 0, 0, 0}, inv[4], t[4];
+  for (size_t i = 0; i < n; ++i) { memcpy(scratch + 4 * i, run, 32); fr_mont_mul(run, v + 4 * i, run); }
+  fr_inv_mont(run, inv);
+  for (size_t i = n; i-- > 0;) { fr_mont_mul(inv, scratch + 4 * i, t); fr_mont_mul(inv, v + 4 * i, inv); memcpy(v + 4 * i, t, 32); }
+}
+typedef struct { u64* buf; size_t m, lo, hi; } pw_job;
+/* buf layout (each m x 4 words): a b c i a2 b2 c2 i2 zinv d d2 barw | den den2 tmp scratch | q2 ka kb kr(2m) */
+static void* pw_worker(void* arg) {
+  pw_job* j = (pw_job*)arg;
+  const size_t m = j->m, lo = j->lo, hi = j->hi, n = hi - lo;
+  if (!n) return NULL;
+  u64* B = j->buf;
+#define V(k) (B + (size_t)(k) * m * 4)
+  u64 *a = V(0), *b = V(1), *ci = V(2), *iv = V(3), *a2 = V(4), *b2 = V(5), *c2 = V(6), *i2 = V(7), *zinv = V(8), *d = V(9), *d2 = V(10), *bw = V(11);
+  u64 *den = V(12), *den2 = V(13), *tmp = V(14), *scr = V(15), *q2 = V(16), *ka = V(17), *kb = V(18), *kr = V(19);
+#undef V
+  (void)ci;
+  const u64 alpha[4] = {0x1234567, 0x89abcdef, 0x13579bdf, 0x7f}, a0[4] = {5, 6, 7, 8}, b0[4] = {9, 10, 11, 12}, r0[4] = {13, 14, 15, 16};
+  u64 t[4], u[4], sums[3][4] = {{0}};
+  for (size_t i = lo; i < hi; ++i) { /* quotient */
+    fr_mont_mul(a2 + 4 * i, b2 + 4 * i, t);
+    fr_sub_mod(t, i2 + 4 * i, t);
+    memcpy(tmp + 4 * i, t, 32); /* r2 */
+    fr_sub_mod(t, c2 + 4 * i, u);
+    fr_mont_mul(u, zinv + 4 * i, q2 + 4 * i);
+  }
+  const u64* ys[3] = {a, b, iv};
+  for (int k = 0; k < 3; ++k) { /* barycentric evaluation, inversions recomputed per call as in the reference */
+    for (size_t i = lo; i < hi; ++i) fr_sub_mod(alpha, d + 4 * i, den + 4 * i);
+    fr_batch_inv(den + 4 * lo, n, scr + 4 * lo);
+    for (size_t i = lo; i < hi; ++i) {
+      fr_mont_mul(ys[k] + 4 * i, bw + 4 * i, t);
+      fr_mont_mul(t, den + 4 * i, t);
+      fr_add_mod(sums[k], t, sums[k]);
+    }
+  }
+  for (size_t i = lo; i < hi; ++i) { fr_sub_mod(d + 4 * i, alpha, den + 4 * i); fr_sub_mod(d2 + 4 * i, alpha, den2 + 4 * i); }
+  fr_batch_inv(den + 4 * lo, n, scr + 4 * lo);
+  fr_batch_inv(den2 + 4 * lo, n, scr + 4 * lo);
+  for (size_t i = lo; i < hi; ++i) { /* K scalars */
+    fr_sub_mod(a + 4 * i, a0, t); fr_mont_mul(t, den + 4 * i, ka + 4 * i);
+    fr_sub_mod(b + 4 * i, b0, t); fr_mont_mul(t, den + 4 * i, kb + 4 * i);
+    fr_mont_mul(a + 4 * i, b + 4 * i, t); fr_sub_mod(t, iv + 4 * i, t); fr_sub_mod(t, r0, t);
+    fr_mont_mul(t, den + 4 * i, kr + 8 * i);
+    fr_sub_mod(tmp + 4 * i, r0, t);
+    fr_mont_mul(t, den2 + 4 * i, kr + 8 * i + 4);
+  }
+  memcpy(tmp + 4 * lo, sums[0], 32); /* keep the sums alive */
+  return NULL;
+}
+/* buf: 21 * m * 4 words, filled by the caller with values < p; returns 0 */
+int dvo_fr_pointwise_stages(u64* buf, size_t m, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pw_job jobs[256];
+  pthread_t th[256];
+  size_t per = (m + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].buf = buf; jobs[t].m = m;
+    jobs[t].lo = (size_t)t * per < m ? (size_t)t * per : m;
+    jobs[t].hi = (size_t)(t + 1) * per < m ? (size_t)(t + 1) * per : m;
+    pthread_create(&th[t], NULL, pw_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+  return 0;
+}
+
