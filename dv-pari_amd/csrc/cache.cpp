@@ -211,6 +211,8 @@ std::string join(const char* dir, const char* name) {
 struct OpenEntry {
   dvp_prover* p = nullptr;
   std::mutex mu;
+  bool opened = false;  // the files have been read (under mu); rc then holds the result
+  int rc = DVP_OK;
   ~OpenEntry() { if (p) dvp_prover_destroy(p); }
 };
 typedef std::tuple<std::string, uint32_t, int> OpenKey;
@@ -222,19 +224,32 @@ int current_device() {
   (void)hipGetDevice(&d);
   return d;
 }
+// The table lock only covers the lookup / insertion of a placeholder; reading the files, decoding the points and building
+// the tables (seconds at full size) happen under the ENTRY's mutex, so opening one cache_dir neither blocks proofs on
+// another one (or on another device) nor dvp_cache_dir_release.  A failed open leaves no entry behind.
 int open_entry(const char* cache_dir, uint32_t n_public, std::shared_ptr<OpenEntry>* out) {
-  std::lock_guard<std::mutex> g(g_open_mu);
   OpenKey key(std::string(cache_dir), n_public, current_device());
-  auto it = g_open.find(key);
-  if (it == g_open.end()) {
-    dvp_prover* p = nullptr;
-    int rc = dvp_prover_open_cache_dir(cache_dir, n_public, &p);
-    if (rc) return rc;
-    auto e = std::make_shared<OpenEntry>();
-    e->p = p;
-    it = g_open.emplace(key, e).first;
+  std::shared_ptr<OpenEntry> e;
+  {
+    std::lock_guard<std::mutex> g(g_open_mu);
+    auto it = g_open.find(key);
+    if (it == g_open.end()) it = g_open.emplace(key, std::make_shared<OpenEntry>()).first;
+    e = it->second;
   }
-  *out = it->second;
+  {
+    std::lock_guard<std::mutex> ge(e->mu);
+    if (!e->opened) {
+      e->rc = dvp_prover_open_cache_dir(cache_dir, n_public, &e->p);
+      e->opened = true;
+    }
+  }
+  if (e->rc != DVP_OK) {
+    std::lock_guard<std::mutex> g(g_open_mu);
+    auto it = g_open.find(key);
+    if (it != g_open.end() && it->second == e) g_open.erase(it);
+    return e->rc;
+  }
+  *out = e;
   return DVP_OK;
 }
 
