@@ -116,6 +116,12 @@ static int slide_slots(int c) {
   }
   return best;
 }
+// INTEGER: the windows are cut from the scalar's BINARY expansion instead (MsmFixedCtx::integer: table row j holds 2^j P, not
+// tau^j P).  With every multiple of every base precomputed, what a window multiplier is made of -- Frobenius or doublings -- no
+// longer matters to the bucket rounds, the entry count is the same (one window per c + 1 digits of a ~232-digit string either
+// way), and the recode loses its expensive half: no partial reduction modulo delta, no multi-limb tau-adic expansion (~3 000
+// instructions per scalar, 0.68 ms per 2^20-constraint proof) -- the digits are the scalar's own bits.
+template <bool INTEGER>
 __global__ void __launch_bounds__(256)
 k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, const uint8_t* __restrict__ width_tab,
                int slots, uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
@@ -134,30 +140,35 @@ k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__
     atomicMin(err, (unsigned long long)i);
     skip = true;
   }
-  uint32_t r0[5], r1[5];
-  tau_partial_reduce(s, r0, r1);
-  if (skip) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
-  }
-  // the digits, least significant first: 8 words of 2 x 16 digits pushed through a shift register (static indices, one
-  // copy of the expansion step in the code); digits >= TAU_DIGITS = 240 land in the top half of d[7] and must be zero
   uint32_t d[8];
+  if (INTEGER) {  // a canonical scalar is < r < 2^232: its bits are the digit string
 #pragma unroll
-  for (int k = 0; k < 8; ++k) d[k] = 0;
+    for (int k = 0; k < 8; ++k) d[k] = skip ? 0u : s[k];
+  } else {
+    uint32_t r0[5], r1[5];
+    tau_partial_reduce(s, r0, r1);
+    if (skip) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
+    }
+    // the digits, least significant first: 8 words of 2 x 16 digits pushed through a shift register (static indices, one
+    // copy of the expansion step in the code); digits >= TAU_DIGITS = 240 land in the top half of d[7] and must be zero
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = 0;
 #pragma unroll 1
-  for (int k = 0; k < 8; ++k) {
-    uint32_t wlo = tau_step16(r0, r1);
-    uint32_t whi = tau_step16(r0, r1);
+    for (int k = 0; k < 8; ++k) {
+      uint32_t wlo = tau_step16(r0, r1);
+      uint32_t whi = tau_step16(r0, r1);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) d[q] = d[q + 1];
-    d[7] = wlo | (whi << 16);
+      for (int q = 0; q < 7; ++q) d[q] = d[q + 1];
+      d[7] = wlo | (whi << 16);
+    }
+    uint32_t rest = d[7] >> (TAU_DIGITS - 224);
+    d[7] &= (1u << (TAU_DIGITS - 224)) - 1;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
+    if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than TAU_DIGITS (proven impossible, tau.cuh)
   }
-  uint32_t rest = d[7] >> (TAU_DIGITS - 224);
-  d[7] &= (1u << (TAU_DIGITS - 224)) - 1;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
-  if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than TAU_DIGITS (proven impossible, tau.cuh)
   int len = 0;  // number of significant digits
 #pragma unroll
   for (int k = 0; k < 8; ++k)
@@ -656,6 +667,28 @@ k_frob_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, Aff* __res
   }
 }
 
+// integer sliding-window mode: T[j][i] = 2^j P_i, j < rows, by affine doublings (lambda = x + y / x, x3 = lambda^2 + lambda,
+// y3 = x^2 + (lambda + 1) x3): one table-driven inversion + 2 products + 2 squarings per row and base -- setup, once per
+// context.  A base of odd prime order never doubles to infinity or to x = 0; bases flagged infinite get no entries.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_dbl_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, GfSqrTables T, Aff* __restrict__ table) {
+  extern __shared__ char lds_raw[];
+  GfLdsK L = gf_ldsk_init(lds_raw);
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff p = bases[i];
+  table[i] = p;
+  const Gf one = gf_one();
+#pragma unroll 1
+  for (int j = 1; j < rows; ++j) {
+    Gf lam = gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L));
+    Gf x3 = gf_add(gf_sqr(lam), lam);
+    p.y = gf_add(gf_sqr(p.x), gf_mul(gf_add(lam, one), x3, L));
+    p.x = x3;
+    table[(size_t)j * n + i] = p;
+  }
+}
+
 // EC kernels on the Karatsuba LDS multiplier: 256-thread blocks, 4 x 8 KB of half tables; the quad-cooperative
 // flavours (latency-bound stages) keep the 16 KB comb tables
 constexpr int EC_TPB = 256;
@@ -1032,14 +1065,26 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   const bool slide = n_narrow < 0;
   Ld* in = buf;
   Ld* out = buf + cnt0;
-  for (uint32_t tid = threadIdx.x; tid < cnt0; tid += EC_TPB) {
-    uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
-    int k = slide ? (int)tid : (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
-    Ld p = slide ? A[tid] : A[((size_t)w << c) + 1 + t];
-    p.X = gf_sqr_n_fast(p.X, k, T);
-    p.Y = gf_sqr_n_fast(p.Y, k, T);
-    p.Z = gf_sqr_n_fast(p.Z, k, T);
-    in[tid] = p;
+  if (n_narrow == -2) {
+    // integer sliding windows (MsmFixedCtx::integer): bucket key b stands for the odd integer 2b + 1, so the result is
+    // A[0] + sum_t 2^t A[t], t = 1 .. c-1: t doublings of A[t], one point per quad of lanes (a serial chain of <= c - 1
+    // doublings at 3 products + 5 squarings each)
+    for (uint32_t pt = threadIdx.x >> 2; pt < cnt0; pt += EC_TPB / 4) {
+      Ld p = A[pt];
+#pragma unroll 1
+      for (uint32_t k = 0; k < pt; ++k) p = ld_dbl(p, L);
+      if (L.r == 0) in[pt] = p;
+    }
+  } else {
+    for (uint32_t tid = threadIdx.x; tid < cnt0; tid += EC_TPB) {
+      uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
+      int k = slide ? (int)tid : (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
+      Ld p = slide ? A[tid] : A[((size_t)w << c) + 1 + t];
+      p.X = gf_sqr_n_fast(p.X, k, T);
+      p.Y = gf_sqr_n_fast(p.Y, k, T);
+      p.Z = gf_sqr_n_fast(p.Z, k, T);
+      in[tid] = p;
+    }
   }
   __syncthreads();
   uint32_t cnt = cnt0;
@@ -1188,6 +1233,7 @@ struct MsmFixedCtx {
   // sliding-window mode (k_recode_slide): the table holds all TAU_DIGITS rotations, W = entry slots per scalar, keys are
   // the odd c-digit patterns (c - 1 key bits)
   bool slide = false;
+  bool integer = false;          // sliding windows over the scalar's BINARY digits: table row j holds 2^j P (k_dbl_table_all)
   uint8_t* width_tab = nullptr;  // device, 256 entries: slide_window_width(R, c)
   void set_c_slide(int cc) {
     c = cc;
@@ -1195,7 +1241,7 @@ struct MsmFixedCtx {
     W = slide_slots(cc);
     slide = true;
   }
-  int rows() const { return slide ? TAU_DIGITS : W; }
+  int rows() const { return slide ? (integer ? 233 : TAU_DIGITS) : W; }  // a canonical scalar has <= 232 binary digits
   int key_bits() const { return slide ? c - 1 : c; }
   int hi_bits = -1;  // level-1 partition bits of the sort (set at creation)
   FxBits bits() const { FxBits b; b.hi = hi_bits; b.lo = key_bits() - b.hi; return b; }
@@ -1370,8 +1416,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
   const bool slide = fx && fx->slide;
-  if (slide)
-    hipLaunchKernelGGL(k_recode_slide, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
+  if (slide && fx->integer)
+    hipLaunchKernelGGL(k_recode_slide<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
+                       fx->width_tab, p.W, digits32, err);
+  else if (slide)
+    hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
                        fx->width_tab, p.W, digits32, err);
   else if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
@@ -1547,7 +1596,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
   (void)cntT;
-  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, slide ? -1 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, slide ? (fx->integer ? -2 : -1) : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
                      (uint32_t*)d_out_inf);
   ps_tail.stop();
   ps_total.stop();
@@ -1583,9 +1632,10 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 // range_hint = number of bases a typical call will cover (the per-GPU shard): the shared window size c
 // minimises an empirical cost in field multiplications (pair additions + a per-bucket term, see below)
 void msm_fixed_destroy(MsmFixedCtx* c);
-static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hint, bool slide, MsmFixedCtx** out, hipError_t* alloc_err) {
+static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hint, bool slide, bool integer, MsmFixedCtx** out, hipError_t* alloc_err) {
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
+  c->integer = slide && integer;
   double best = 1e300;
   int best_c = 8;
   const int c_max = FX_C_MAX + (slide ? 1 : 0);  // <= 20 key bits either way
@@ -1613,11 +1663,17 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
     if (e == hipSuccess) e = hipMemcpy(c->width_tab, wt, sizeof(wt), hipMemcpyHostToDevice);
   }
   if (e == hipSuccess) {
-    if (slide)
+    if (slide && c->integer) {
+      GfSqrTables Tsq;
+      int rc_t = gf_sqr_tables(&Tsq, 0);
+      if (rc_t != DVP_OK) { msm_fixed_destroy(c); return rc_t; }
+      e = hipFuncSetAttribute((const void*)k_dbl_table_all, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
+      if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table_all, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->rows(), Tsq, c->table);
+    } else if (slide)
       hipLaunchKernelGGL(k_frob_table_all, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->rows(), c->table);
     else
       hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
-    e = hipGetLastError();
+    if (e == hipSuccess) e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -1646,11 +1702,14 @@ int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, Ms
     else if (budget_gb >= 0) slide = slide_bytes <= (uint64_t)budget_gb * 1000000000ull;
     else slide = hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes + (uint64_t)total_b / 4 <= (uint64_t)free_b;
   }
+  // DVP_MSM_SLIDE: 1 = tau-adic sliding windows, 2 = sliding windows over the binary digits (integer multiples in the table);
+  // unset: the integer flavour when the table fits
+  const bool integer = mode == 2 || (mode < 0 && tune().msm_slide_integer != 0);
   hipError_t alloc_err = hipSuccess;
-  int rc = msm_fixed_build(d_bases, n_total, range_hint, slide, out, &alloc_err);
+  int rc = msm_fixed_build(d_bases, n_total, range_hint, slide, integer, out, &alloc_err);
   if (rc != DVP_OK && slide && mode < 0 && alloc_err == hipErrorOutOfMemory) {
     (void)hipGetLastError();  // the failed hipMalloc is not an error of this call
-    rc = msm_fixed_build(d_bases, n_total, range_hint, false, out, &alloc_err);
+    rc = msm_fixed_build(d_bases, n_total, range_hint, false, false, out, &alloc_err);
   }
   return rc;
 }
@@ -1807,7 +1866,7 @@ extern "C" int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c, 
   DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
   DVP_HIP(hipMemcpy(dt.p, wt, sizeof(wt), hipMemcpyHostToDevice));
   DVP_HIP(hipMemset(de.p, 0xff, 8));
-  hipLaunchKernelGGL(k_recode_slide, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
+  hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
                      *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*slots * n * 4, hipMemcpyDeviceToHost));

@@ -125,7 +125,7 @@ def test_msm_wire_format(dvp):
     assert out == co.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)))
 
 
-@pytest.mark.parametrize("slide", [0, 1])
+@pytest.mark.parametrize("slide", [0, 1, 2])  # aligned tau windows / tau sliding windows / sliding windows over the binary digits
 @pytest.mark.parametrize("hint", [0, 1 << 10, 1 << 24])
 def test_fixed_base_msm_context(dvp, hint, slide):
     """dvp_msm_ctx_*: pre-rotated bases, shared bucket set; full range, sub-ranges (the per-GPU shards) and a
@@ -239,7 +239,7 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     assert max(len(co.tau_digits(x)) for x in special) >= 236
     s[: len(special)] = to_limbs(special)
     ks, ss = from_limbs(k), from_limbs(s)
-    for c, slide in [(c, 0) for c in range(8, 21)] + [(c, 1) for c in range(8, 22)]:
+    for c, slide in [(c, 0) for c in range(8, 21)] + [(c, 1) for c in range(8, 22)] + [(c, 2) for c in range(8, 22)]:
         with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_SLIDE=slide, DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
                       DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
             fb = dvp.curve.FixedBaseMsm(bases)

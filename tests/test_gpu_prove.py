@@ -399,14 +399,14 @@ def test_in_library_multi_gpu_same_bytes(dvp, log_m, devices):
 
 
 def test_table_flavours_same_bytes(dvp):
-    """the two fixed-base table flavours (aligned windows over W rotations / sliding windows over all 240, DVP_MSM_SLIDE) and
-    the cost-model default produce the same proof; dvp_prover_msm_table_bytes reports flavour and size (rotations x bases x 64 B)"""
+    """the fixed-base table flavours (aligned windows over W rotations / sliding windows over all 240 rotations / sliding
+    windows over the 233 integer multiples 2^j P, DVP_MSM_SLIDE = 0 / 1 / 2) and the default produce the same proof; dvp_prover_msm_table_bytes reports flavour and size (rotations x bases x 64 B)"""
     log_m = 13
     inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
     rnd = random.Random(77)
     td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
     proofs = []
-    for slide in (0, 1, -1):
+    for slide in (0, 1, 2, -1):
         with dvp.tune(DVP_MSM_FIXED_MIN=1, DVP_MSM_SLIDE=slide):
             pv = dvp.proving.Prover(inst)
             pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
@@ -414,11 +414,12 @@ def test_table_flavours_same_bytes(dvp):
             proofs.append(pv.prove(pub, prv))
             for which in (0, 1):
                 nbytes, sliding = pv.msm_table(which)
-                rows = 240 if sliding else pv.msm_plan(which)[1]
+                # sliding tables: 240 Frobenius rotations (DVP_MSM_SLIDE = 1) or 233 integer multiples 2^j P (= 2, the default)
+                rows = (240 if slide == 1 else 233) if sliding else pv.msm_plan(which)[1]
                 assert nbytes == rows * pv.msm_size(which) * 64
                 assert sliding == (slide != 0)          # the default picks the sliding tables on an empty 288 GB device
             pv.close()
-    assert proofs[0] == proofs[1] == proofs[2] and dvp.srs.verify(td, pub, proofs[0])
+    assert proofs[0] == proofs[1] == proofs[2] == proofs[3] and dvp.srs.verify(td, pub, proofs[0])
 
 
 def test_points_sum_records(dvp):
