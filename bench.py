@@ -336,7 +336,7 @@ def main():
                         best = dt
                 msm_standalone[f"2^{lg}"] = {"ms": best * 1e3, "mpoints_per_s": n_pts / best / 1e6}
             del d_bases, d_sc
-        # footprint: the same proof with the aligned-window tables (W ~ 14 rotations per base instead of all 240)
+        # footprint: the same proof with the aligned-window tables (W ~ 14 rotations per base instead of a multiple for every digit position)
         if tables[0][1] or tables[1][1]:
             with dvp.tune(DVP_MSM_SLIDE=0):
                 pv2 = dvp.proving.Prover(inst)

@@ -133,10 +133,13 @@ void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
 /* window bits c and window count (aligned windows: all W windows share one set of 2^c buckets; sliding windows: entry
  * slots per scalar, 2^(c-1) buckets of odd patterns) the context settled on */
 int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
-/* HBM held by the context's pre-rotated table.  Two flavours: aligned windows keep W ~ 14 rotations of every base
- * (0.9 KB per base); sliding windows keep all 240 (15 KB per base: 64 GB for the 4m bases of a 2^20-constraint prover)
- * and need ~8 % fewer bucket additions.  The sliding table is chosen when it leaves a quarter of the device memory
- * free at the moment the context is built (DVP_MSM_SLIDE = 1 / 0 forces it on / off); *sliding reports which one this is. */
+/* HBM held by the context's precomputed table.  Two flavours: aligned windows keep W ~ 14 Frobenius rotations of every base
+ * (0.9 KB per base); sliding windows keep a multiple of the base for EVERY digit position -- by default the 233 integer
+ * multiples 2^j P (windows cut from the scalar's binary digits; 14.6 KB per base: 63 GB for the 4m bases of a 2^20-constraint
+ * prover), with DVP_MSM_SLIDE=1 the 240 Frobenius rotations tau^j P (windows over the tau-adic digits) -- and need ~8 % fewer
+ * bucket additions.  The sliding table is chosen when it leaves a quarter of the device memory free at the moment the context
+ * is built, or fits the byte budget DVP_MSM_TABLE_MAX_GB when that environment variable is set (DVP_MSM_SLIDE = 0 forces the
+ * aligned windows); *sliding reports which one this is.  Results do not depend on the flavour. */
 uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
