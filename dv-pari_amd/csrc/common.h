@@ -73,7 +73,6 @@ struct Tune {
   long long msm_proj = 0;       // DVP_MSM_MODE=proj: skip the batched-affine rounds
   long long msm_aff_min = 1ll << 19;   // DVP_MSM_AFF_MIN: pair rounds run while a round has this many additions
   long long msm_aff_bmax = 48;  // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns
-  long long msm_merge_fuse = 1;        // DVP_MSM_MERGE_FUSE: the first five merge levels in one launch (0 = one launch per level)
   long long msm_accum_quad_max = 0;    // DVP_MSM_ACCUM_QUAD_MAX: reducer launches with at most this many tasks (upper bound) use a quad of lanes per task (0 = default)
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables

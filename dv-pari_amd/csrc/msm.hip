@@ -1049,43 +1049,6 @@ __global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uin
   }
 }
 
-// The first F merge levels in ONE launch.  They only mix buckets inside aligned groups of 2^F, so a workgroup keeps 512
-// buckets (48 KB) in LDS next to its multiplier tables and walks the F levels with a barrier between them: a group of 2^F
-// buckets is served by 2^(F-1) threads (level j has (2^F >> (j+1)) * (j+1) additions per group, at most 2^(F-1)).  Per
-// level the separate launches cost a kernel boundary and a partly filled chip each (74 us on average for the wide levels
-// against 37 us of pure addition latency); fused, a thread's F additions run back to back.
-constexpr int MERGE_FUSE = 5;
-constexpr unsigned MERGE_FUSED_LDS = EC_LDS + 2 * EC_TPB * sizeof(Ld);
-template <int F>
-__global__ void __launch_bounds__(EC_TPB) k_merge_fused(Ld* __restrict__ A) {
-  extern __shared__ char lds_raw[];
-  GfLdsK L = gf_ldsk_init(lds_raw);
-  Ld* g = (Ld*)(lds_raw + EC_LDS);
-  constexpr int PER = 2 * EC_TPB;              // buckets per workgroup
-  constexpr int VEC = PER * (int)sizeof(Ld) / 16;
-  uint4* gv = (uint4*)g;
-  uint4* av = (uint4*)(A + (size_t)blockIdx.x * PER);
-  for (int k = threadIdx.x; k < VEC; k += EC_TPB) gv[k] = av[k];
-  __syncthreads();
-  constexpr int GT = 1 << (F - 1);             // threads per group of 2^F buckets
-  const int grp = threadIdx.x / GT, q = threadIdx.x % GT;
-  Ld* gb = g + (size_t)grp * (2 * GT);
-#pragma unroll 1
-  for (int j = 0; j < F; ++j) {
-    const int adds = ((2 * GT) >> (j + 1)) * (j + 1);
-    if (q < adds) {
-      const int blk = q / (j + 1), sl = q - blk * (j + 1);
-      Ld* bb = gb + ((size_t)blk << (j + 1));
-      Ld l = bb[sl], r = bb[(1 << j) + sl];
-      if (sl == 0 && j >= 2) bb[1 + j] = r;    // T_right: slot j + 1 is nobody's operand at this level
-      ld_add_ip(l, r, L);
-      bb[sl] = l;
-    }
-    __syncthreads();
-  }
-  for (int k = threadIdx.x; k < VEC; k += EC_TPB) av[k] = gv[k];
-}
-
 // The whole Frobenius tail of an MSM in ONE single-workgroup launch: E[w*c+t] = tau^k(A[w*2^c + 1 + t]) with k = the first
 // digit of window w plus t (window w starts at digit w*c - min(w, n_narrow): the first n_narrow windows are c-1 digits wide;
 // up to 239 squarings per coordinate, done by table passes, not a serial chain), then the pairwise add tree (in[count]
@@ -1374,8 +1337,6 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                           (const void*)k_affine_round<true>, (const void*)k_affine_round<false>, (const void*)k_sum_points, (const void*)k_tail};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
-      if (attr_err == hipSuccess)
-        attr_err = hipFuncSetAttribute((const void*)k_merge_fused<MERGE_FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_FUSED_LDS);
       DVP_HIP(attr_err);
       attr_done[cur_dev] = true;
     }
@@ -1623,12 +1584,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   ProfScope ps_tail(PROF_MSM_TAIL, st);  // merge tree, Frobenius tail, final add tree
   const int merge_levels = fx ? fx->key_bits() : p.c;
-  int j0 = 0;
-  if (merge_levels >= MERGE_FUSE && nk % (2 * EC_TPB) == 0 && tn.msm_merge_fuse != 0) {
-    hipLaunchKernelGGL(k_merge_fused<MERGE_FUSE>, dim3(nk / (2 * EC_TPB)), dim3(EC_TPB), MERGE_FUSED_LDS, st, bkt);
-    j0 = MERGE_FUSE;
-  }
-  for (int j = j0; j < merge_levels; ++j) {
+  for (int j = 0; j < merge_levels; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
     if (total <= quad_max)
