@@ -133,7 +133,7 @@ def run_inproc_child(args, share_gpu):
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--inproc", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--log-m", str(args.log_m), "--no-cpu-baseline"]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=float(os.environ.get("DVP_BENCH_INPROC_TIMEOUT", "300")))
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=float(os.environ.get("DVP_BENCH_INPROC_TIMEOUT", "150")))
     except subprocess.TimeoutExpired:
         return None, "timeout"
     d = last_json_line(r.stdout)
