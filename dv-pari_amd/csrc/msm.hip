@@ -884,22 +884,12 @@ __device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_
 // FIRST only names the launch: k_affine_round<true> is the first pair round of an MSM (random gathers out of the
 // pre-rotated table -- the dominant kernel bench.py's roofline block is about), <false> the later rounds (coalesced
 // inputs); the code is the same, the two symbols keep them apart in rocprofv3's per-kernel statistics.
-typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ Gf gf_load_nt(const Gf* p) {
-  const nt_u32x4* q = (const nt_u32x4*)p;
-  const nt_u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
-  Gf r;
-  r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w; r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
-  return r;
-}
 template <bool FIRST>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, const uint32_t* __restrict__ total_ptr /* ooff[nkeys] */,
-               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out, int nt) {
+               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
-  auto ldx = [&](uint32_t i) -> Gf { return (FIRST && nt) ? gf_load_nt(&pts[i].x) : pts[i].x; };
-  auto ldy = [&](uint32_t i) -> Gf { return (FIRST && nt) ? gf_load_nt(&pts[i].y) : pts[i].y; };
   const uint32_t total = *total_ptr;
   const int B = (int)aff_slots_per_thread(total, cap, bmax);
   const uint32_t nthr = (total + B - 1) / B;
@@ -917,17 +907,17 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
   {
     uint2 d0 = ld_desc(0), d1 = ld_desc(1);
     Gf xa = gf_zero(), xb = gf_zero();
-    if (d0.y != AFF_NONE) { xa = ldx(d0.x); xb = ldx(d0.y); }
+    if (d0.y != AFF_NONE) { xa = pts[d0.x].x; xb = pts[d0.y].x; }
 #pragma unroll 1
     for (int k = 0; k < B; ++k) {
       const uint2 d2 = ld_desc(k + 2);
       Gf nxa = gf_zero(), nxb = gf_zero();
-      if (d1.y != AFF_NONE) { nxa = ldx(d1.x); nxb = ldx(d1.y); }
+      if (d1.y != AFF_NONE) { nxa = pts[d1.x].x; nxb = pts[d1.y].x; }
       Gf den = one;
       if (d0.y != AFF_NONE && !gf_is_zero(xa) && !gf_is_zero(xb)) {
         Gf dd = gf_add(xa, xb);
         if (!gf_is_zero(dd)) den = dd;
-        else if (gf_eq(ldy(d0.x), ldy(d0.y))) den = xa;  // doubling: lambda = x + y/x
+        else if (gf_eq(pts[d0.x].y, pts[d0.y].y)) den = xa;  // doubling: lambda = x + y/x
       }
       prefix[(size_t)k * nthr + tid] = run;
       run = gf_mul(run, den, L);
@@ -939,19 +929,19 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
   {
     uint2 e0 = ld_desc(B - 1), e1 = ld_desc(B - 2);
     Gf px = gf_zero(), qx = gf_zero(), pre = one;
-    if (e0.x != AFF_NONE) px = ldx(e0.x);
-    if (e0.y != AFF_NONE) { qx = ldx(e0.y); pre = prefix[(size_t)(B - 1) * nthr + tid]; }
+    if (e0.x != AFF_NONE) px = pts[e0.x].x;
+    if (e0.y != AFF_NONE) { qx = pts[e0.y].x; pre = prefix[(size_t)(B - 1) * nthr + tid]; }
 #pragma unroll 1
     for (int k = B - 1; k >= 0; --k) {
       const uint2 e2 = ld_desc(k - 2);
       // this slot's y-coordinates (needed after the two products of the inverse recovery) ...
       Gf py = gf_zero(), qy = gf_zero();
-      if (e0.x != AFF_NONE) py = ldy(e0.x);
-      if (e0.y != AFF_NONE) qy = ldy(e0.y);
+      if (e0.x != AFF_NONE) py = pts[e0.x].y;
+      if (e0.y != AFF_NONE) qy = pts[e0.y].y;
       // ... and the next slot's x-coordinates and prefix product
       Gf npx = gf_zero(), nqx = gf_zero(), npre = one;
-      if (e1.x != AFF_NONE) npx = ldx(e1.x);
-      if (e1.y != AFF_NONE) { nqx = ldx(e1.y); npre = prefix[(size_t)(k - 1) * nthr + tid]; }
+      if (e1.x != AFF_NONE) npx = pts[e1.x].x;
+      if (e1.y != AFF_NONE) { nqx = pts[e1.y].x; npre = prefix[(size_t)(k - 1) * nthr + tid]; }
       if (e0.x != AFF_NONE) {
         const uint32_t sidx = (uint32_t)k * nthr + tid;
         Gf ox = px, oy = py;  // odd leftover, or q == infinity: pass p through
@@ -1511,9 +1501,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
       if (r == 0)
         hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, items_are_desc ? (const uint2*)items : (const uint2*)gdesc, d_total,
-                           aff_cap, aff_bmax, Tsq, prefix, outp, (int)tn.msm_nt_loads);
+                           aff_cap, aff_bmax, Tsq, prefix, outp);
       else
-        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0);
+        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
       ps0.stop();
     }
     pts_in = outp;
@@ -1653,8 +1643,7 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
   const int kb = c->key_bits();
   c->hi_bits = kb / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
   if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && kb - h <= 15 && kb - h >= 1) c->hi_bits = h;
-  hipError_t e = tune().msm_table_uncached ? hipExtMallocWithFlags((void**)&c->table, (size_t)c->rows() * n_total * sizeof(Aff), hipDeviceMallocUncached)
-                                           : hipMalloc((void**)&c->table, (size_t)c->rows() * n_total * sizeof(Aff));
+  hipError_t e = hipMalloc((void**)&c->table, (size_t)c->rows() * n_total * sizeof(Aff));
   *alloc_err = e;
   if (e == hipSuccess && slide) {
     uint8_t wt[256] = {0};
@@ -1794,16 +1783,14 @@ __device__ __forceinline__ uint64_t ubench_mix(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
   return x;
 }
-__global__ void __launch_bounds__(256) k_ubench_gather(const uint4* __restrict__ t, uint64_t nlines, int per, uint32_t seed, uint32_t* __restrict__ out, int nt) {
+__global__ void __launch_bounds__(256) k_ubench_gather(const uint4* __restrict__ t, uint64_t nlines, int per, uint32_t seed, uint32_t* __restrict__ out) {
   const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-  nt_u32x4 acc = {0, 0, 0, 0};
+  uint4 acc = make_uint4(0, 0, 0, 0);
 #pragma unroll 4
   for (int k = 0; k < per; ++k) {
     const uint64_t idx = ubench_mix(tid * (uint64_t)per + k + ((uint64_t)seed << 40)) % nlines;
-    const nt_u32x4* p = (const nt_u32x4*)(t + idx * 4);
-    nt_u32x4 a, b, c, d;
-    if (nt) { a = __builtin_nontemporal_load(p); b = __builtin_nontemporal_load(p + 1); c = __builtin_nontemporal_load(p + 2); d = __builtin_nontemporal_load(p + 3); }
-    else { a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
+    const uint4* p = t + idx * 4;
+    const uint4 a = p[0], b = p[1], c = p[2], d = p[3];
     acc.x ^= a.x ^ b.x ^ c.x ^ d.x; acc.y ^= a.y ^ b.y ^ c.y ^ d.y; acc.z ^= a.z ^ b.z ^ c.z ^ d.z; acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
   }
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;  // keeps the loads alive
@@ -1814,14 +1801,8 @@ extern "C" int dvp_ubench_gather(const void* d_table, size_t table_bytes, int re
   DVP_HIP(hipGetDevice(&dev));
   DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   DevBuf own, out;
-  const int nt = (int)tune().msm_nt_loads;
   if (!d_table) {  // contents do not matter for a read-rate figure, but untouched pages may not be backed: write them once
-    if (tune().msm_table_uncached) {
-      DVP_HIP(hipExtMallocWithFlags(&own.p, table_bytes, hipDeviceMallocUncached));
-      own.bytes = table_bytes;
-    } else {
-      DVP_TRY(own.alloc(table_bytes));
-    }
+    DVP_TRY(own.alloc(table_bytes));
     DVP_HIP(hipMemset(own.p, 0x5a, table_bytes));
     d_table = own.p;
   }
@@ -1832,10 +1813,10 @@ extern "C" int dvp_ubench_gather(const void* d_table, size_t table_bytes, int re
   hipEvent_t e0, e1;
   DVP_HIP(hipEventCreate(&e0));
   DVP_HIP(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, 0, (const uint4*)d_table, nlines, per, 1u, out.as<uint32_t>(), nt);
+  hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, 0, (const uint4*)d_table, nlines, per, 1u, out.as<uint32_t>());
   DVP_HIP(hipEventRecord(e0, 0));
   for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, 0, (const uint4*)d_table, nlines, per, 2u + (uint32_t)r, out.as<uint32_t>(), nt);
+    hipLaunchKernelGGL(k_ubench_gather, dim3(blocks), dim3(256), 0, 0, (const uint4*)d_table, nlines, per, 2u + (uint32_t)r, out.as<uint32_t>());
   DVP_HIP(hipEventRecord(e1, 0));
   DVP_HIP(hipEventSynchronize(e1));
   float ms = 0;
