@@ -1832,7 +1832,15 @@ extern "C" int dvp_ubench_gather(const void* d_table, size_t table_bytes, int re
 // words of n canonical scalars for window size c, out_words[slot * n + i] = 0 (empty) or
 // 0x80000000 | position << 20 | pattern >> 1; *slots = entry slots per scalar (out_words holds *slots * n words; pass
 // out_words = NULL to query *slots).
+static int debug_recode(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots, bool integer);
 extern "C" int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots) {
+  return debug_recode(scalars, n, c, out_words, slots, false);
+}
+// the same for the windows over the scalar's binary digits (k_recode_slide<true>, the default sliding flavour)
+extern "C" int dvp_debug_recode_binary(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots) {
+  return debug_recode(scalars, n, c, out_words, slots, true);
+}
+static int debug_recode(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots, bool integer) {
   if (!slots || c < 8 || c > FX_C_MAX + 1 || n > (1u << 24)) return DVP_EINVAL;
   *slots = slide_slots(c);
   if (!out_words) return DVP_OK;
@@ -1847,8 +1855,12 @@ extern "C" int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c, 
   DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
   DVP_HIP(hipMemcpy(dt.p, wt, sizeof(wt), hipMemcpyHostToDevice));
   DVP_HIP(hipMemset(de.p, 0xff, 8));
-  hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
-                     *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
+  if (integer)
+    hipLaunchKernelGGL(k_recode_slide<true>, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
+                       *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
+  else
+    hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
+                       *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*slots * n * 4, hipMemcpyDeviceToHost));
   unsigned long long e = 0;

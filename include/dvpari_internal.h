@@ -46,6 +46,8 @@ int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_tabl
  * out_words[slot * n + i] = 0 (empty slot) or 0x80000000 | first digit position << 20 | odd pattern >> 1;
  * *slots = entry slots per scalar (out_words must hold *slots * n words; out_words = NULL only queries *slots). */
 int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
+/* the same for the default sliding flavour, windows cut from the scalar's BINARY digits (position = bit position) */
+int dvp_debug_recode_binary(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
 
 /* intermediates of the last proof, for parity tests (names: see prove.hip) */
 int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);

@@ -331,3 +331,31 @@ def test_sliding_recode_words_vs_restatement(dvp, c):
         if i >= 7 + len(adv):
             assert same, (c, i, hex(x))
     assert same_as_oracle >= len(vals) - len(adv)
+
+
+@pytest.mark.parametrize("c", [8, 13, 19, 20, 21])
+def test_binary_recode_words_vs_restatement(dvp, c):
+    """k_recode_slide<true> (the default sliding flavour: windows over the scalar's BINARY digits, table rows = 2^j P) word for
+    word: the entries of a scalar are exactly what the window rule restated in tests/util.py (slide_windows) cuts out of its
+    bits -- odd patterns, positions, slot count, empty slots -- and they reassemble to the scalar as an integer."""
+    import ctypes as C
+    from util import slide_windows
+
+    rnd = random.Random(400 + c)
+    vals = [0, 1, 2, 3, o.P - 1, (1 << 231) - 1, 1 << 230, (1 << 231) + 1] + [rnd.randrange(o.P) for _ in range(1500)] \
+        + [rnd.randrange(1 << rnd.randrange(1, 232)) for _ in range(300)]
+    s = to_limbs(vals)
+    slots = C.c_int(0)
+    dvp.check(dvp.lib.dvp_debug_recode_binary(None, 0, c, None, C.byref(slots)), "slots")
+    assert slots.value == slide_slots(c)
+    words = np.zeros((slots.value, len(vals)), dtype=np.uint32)
+    dvp.check(dvp.lib.dvp_debug_recode_binary(s.ctypes.data, len(vals), c, words.ctypes.data, C.byref(slots)), "recode")
+    for i, x in enumerate(vals):
+        got = [(int(w >> 20) & 0xFF, 2 * int(w & 0xFFFFF) + 1) for w in words[:, i] if w]
+        assert all(int(w) >> 31 for w in words[: len(got), i]) and not words[len(got):, i].any()
+        assert sum(v << pos for pos, v in got) == x, (c, i, hex(x))
+        assert slide_windows([(x >> j) & 1 for j in range(233)], c) == got, (c, i, hex(x))
+    # a scalar >= r is refused with its index, as in every other entry of the boundary
+    bad = to_limbs([5, o.P])
+    w2 = np.zeros((slots.value, 2), dtype=np.uint32)
+    assert dvp.lib.dvp_debug_recode_binary(bad.ctypes.data, 2, c, w2.ctypes.data, C.byref(slots)) == -1 and dvp.lib.dvp_last_error_index() == 1
