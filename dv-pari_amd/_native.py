@@ -72,6 +72,7 @@ _SIGS = {
     "dvp_msm_ctx_table_bytes": (C.c_uint64, [vp, C.POINTER(C.c_int)]),
     "dvp_debug_recode_slide": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]),
     "dvp_debug_recode_binary": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]),
+    "dvp_debug_recode_signed": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run": (C.c_int, [vp, u64p, sz, sz, u64p, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run_dev": (C.c_int, [vp, vp, sz, sz, vp, vp, vp]),
     "dvp_msm_xsk233": (C.c_int, [u8p, u8p, sz, u8p]),

@@ -77,6 +77,7 @@ struct Tune {
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables
   long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)
+  long long msm_aligned_signed = 1;    // DVP_MSM_ALIGNED_SIGNED: the aligned-window tables hold 2^(c w) P and the windows are signed binary digits (0 = tau-adic aligned windows)
   long long msm_slide_integer = 1;     // DVP_MSM_SLIDE_INTEGER: when DVP_MSM_SLIDE is unset, 1 = the sliding tables hold integer multiples 2^j P (binary windows), 0 = tau^j P
   long long msm_table_max_gb = -1;     // DVP_MSM_TABLE_MAX_GB: byte budget (GB) of ONE sliding-window table; -1 = whatever leaves a quarter of the device free
 };

@@ -35,7 +35,9 @@ namespace dvp {
 
 // Entry word of the fixed-base mode (one u32 per (slot, scalar)): bit 31 = valid, bits 20..27 = row of the pre-rotated
 // table (the power of tau the base is taken at), bits 0..19 = bucket key.  0 = empty slot.
-constexpr uint32_t FXW_VALID = 0x80000000u, FXW_KEY_MASK = 0xfffffu;
+// Bit 28 = the entry SUBTRACTS its point (signed-digit flavours): carried into bit 31 of the sorted item (ITEM_NEG) and applied
+// where the point is loaded (-(x, y) = (x, x + y): free).
+constexpr uint32_t FXW_VALID = 0x80000000u, FXW_KEY_MASK = 0xfffffu, FXW_NEG = 0x10000000u, ITEM_NEG = 0x80000000u;
 constexpr int FXW_ROW_SHIFT = 20;
 __host__ __device__ __forceinline__ uint32_t fxw_key(uint32_t d) { return d & FXW_KEY_MASK; }
 __host__ __device__ __forceinline__ uint32_t fxw_row(uint32_t d) { return (d >> FXW_ROW_SHIFT) & 0xffu; }
@@ -199,6 +201,50 @@ k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__
     pos += width;
   }
   for (; slot < slots; ++slot) words[(size_t)slot * n + i] = 0;
+}
+
+// Signed aligned windows over the BINARY digits (MsmFixedCtx::integer without the sliding table; table row w = 2^(c w) P): the
+// textbook signed-digit bucket method.  Window w holds d_w = bits [c w, c w + c) plus the carry of the window below; a digit
+// above 2^(c-1) becomes d_w - 2^c with a carry of one, so |d_w| <= 2^(c-1): HALF the buckets per window bit of the unsigned
+// windows (key = |d_w|; |d_w| = 2^(c-1), probability 2^-c, shares key 0, whose bucket the tail weighs by 2^(c-1)), the sign
+// travels with the entry (FXW_NEG) and is applied when the point is loaded.  W = ceil(234 / c) windows take a canonical scalar
+// (< 2^232) including the last carry.  No tau-adic expansion: a few shifts per window.
+__global__ void __launch_bounds__(256)
+k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W,
+                uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[9];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
+  s[8] = 0;
+  bool skip = inf && inf[i];
+  if (!tau_scalar_is_canonical(s)) {
+    atomicMin(err, (unsigned long long)i);
+    skip = true;
+  }
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  uint32_t carry = 0;
+#pragma unroll 1
+  for (int w = 0; w < W; ++w) {
+    const int bit = w * c, wd = bit >> 5, sh = bit & 31;
+    uint32_t lo = wd < 8 ? s[wd] : 0u, hi = wd + 1 < 9 ? s[wd + 1] : 0u;
+    uint32_t d = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
+    d += carry;
+    carry = 0;
+    uint32_t word = 0;
+    if (d > mask) {  // all ones + carry: digit 0, carry on
+      carry = 1;
+    } else if (d > half) {  // d - 2^c < 0
+      carry = 1;
+      d = (1u << c) - d;  // |d| in [1, 2^(c-1))
+      word = FXW_VALID | FXW_NEG | ((uint32_t)w << FXW_ROW_SHIFT) | d;
+    } else if (d) {
+      word = FXW_VALID | ((uint32_t)w << FXW_ROW_SHIFT) | (d & (half - 1));  // d == 2^(c-1) -> key 0
+    }
+    words[(size_t)w * n + i] = skip ? 0u : word;
+  }
+  if (carry && !skip) atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: W c >= 234
 }
 
 // ---- exclusive scan of u32 (3 kernels; up to 4096*1024 elements) ---------------------------------
@@ -472,7 +518,7 @@ k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, ui
     const uint32_t i = (uint32_t)(e % n), key = fxw_key(d);
     uint32_t pos = atomicAdd(&cur[key >> FX_LO], 1u);
     plo[pos] = (uint16_t)(key & ((1u << FX_LO) - 1));
-    pid[pos] = fxw_row(d) * n_total + i0 + i;
+    pid[pos] = (fxw_row(d) * n_total + i0 + i) | ((d & FXW_NEG) ? ITEM_NEG : 0u);
   }
 }
 // the partition whose chunk range [cstart[k], cstart[k+1]) holds chunk g (empty partitions share their start with the
@@ -591,7 +637,7 @@ k_part_scatter_staged(const uint32_t* __restrict__ digits, size_t total, uint32_
     const uint32_t key = fxw_key(d);
     uint32_t pos = atomicAdd(&cur[key >> FX_LO], 1u);
     st_d[pos] = key;
-    st_id[pos] = fxw_row(d) * n_total + i0 + (uint32_t)i;
+    st_id[pos] = (fxw_row(d) * n_total + i0 + (uint32_t)i) | ((d & FXW_NEG) ? ITEM_NEG : 0u);
   }
   __syncthreads();
   const uint32_t mask = (1u << FX_LO) - 1;
@@ -689,6 +735,29 @@ k_dbl_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, GfSqrTables
   }
 }
 
+// signed aligned windows: T[w][i] = 2^(c w) P_i, w < W (c affine doublings between rows)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, GfSqrTables T, Aff* __restrict__ table) {
+  extern __shared__ char lds_raw[];
+  GfLdsK L = gf_ldsk_init(lds_raw);
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Aff p = bases[i];
+  table[i] = p;
+  const Gf one = gf_one();
+#pragma unroll 1
+  for (int w = 1; w < W; ++w) {
+#pragma unroll 1
+    for (int k = 0; k < c; ++k) {
+      Gf lam = gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L));
+      Gf x3 = gf_add(gf_sqr(lam), lam);
+      p.y = gf_add(gf_sqr(p.x), gf_mul(gf_add(lam, one), x3, L));
+      p.x = x3;
+    }
+    table[(size_t)w * n + i] = p;
+  }
+}
+
 // EC kernels on the Karatsuba LDS multiplier: 256-thread blocks, 4 x 8 KB of half tables; the quad-cooperative
 // flavours (latency-bound stages) keep the 16 KB comb tables
 constexpr int EC_TPB = 256;
@@ -715,7 +784,7 @@ template <bool INDIRECT, bool QUAD>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
                const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
-               Ld* __restrict__ out) {
+               Ld* __restrict__ out, uint32_t sign_mask) {
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (QUAD) tid >>= 2;
@@ -726,13 +795,18 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   uint32_t len = min(K, cnt[key] - j * K);
   // INDIRECT: bases gathered through the sorted index list; otherwise `bases` is the compacted output of
   // the affine rounds, where x == 0 marks infinity
-  Aff first = INDIRECT ? bases[items[start]] : bases[start];
+  auto item_point = [&](uint32_t v) -> Aff {  // table entry named by a sorted item; bit 31 (signed flavours) = subtract it
+    Aff q = bases[v & ~sign_mask];
+    if (v & sign_mask) q.y = gf_add(q.y, q.x);
+    return q;
+  };
+  Aff first = INDIRECT ? item_point(items[start]) : bases[start];
   Ld acc = (!INDIRECT && gf_is_zero(first.x)) ? ld_infinity() : ld_from_aff(first);
   if (QUAD) {
     GfLdsQ L = gf_ldsq_init(lds_raw);
 #pragma unroll 1
     for (uint32_t t = 1; t < len; ++t) {
-      Aff q = INDIRECT ? bases[items[start + t]] : bases[start + t];
+      Aff q = INDIRECT ? item_point(items[start + t]) : bases[start + t];
       if (!INDIRECT && gf_is_zero(q.x)) continue;
       ld_madd_ip(acc, q, L);
     }
@@ -741,7 +815,7 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
     GfLdsK L = gf_ldsk_init(lds_raw);
 #pragma unroll 1
     for (uint32_t t = 1; t < len; ++t) {
-      Aff q = INDIRECT ? bases[items[start + t]] : bases[start + t];
+      Aff q = INDIRECT ? item_point(items[start + t]) : bases[start + t];
       if (!INDIRECT && gf_is_zero(q.x)) continue;
       ld_madd_ip(acc, q, L);
     }
@@ -887,9 +961,18 @@ __device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_
 template <bool FIRST>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, const uint32_t* __restrict__ total_ptr /* ooff[nkeys] */,
-               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out) {
+               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out, uint32_t sign_mask) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
+  // signed-digit flavours (first round only: the operands are table entries named by sorted items): bit 31 of an item says
+  // "subtract"; -(x, y) = (x, x + y), applied as the y-coordinate is loaded
+  const uint32_t sm = FIRST ? sign_mask : 0u;
+  auto ldx = [&](uint32_t v) -> Gf { return pts[v & ~sm].x; };
+  auto ldy = [&](uint32_t v, const Gf& x) -> Gf {
+    Gf y = pts[v & ~sm].y;
+    if (v & sm) y = gf_add(y, x);
+    return y;
+  };
   const uint32_t total = *total_ptr;
   const int B = (int)aff_slots_per_thread(total, cap, bmax);
   const uint32_t nthr = (total + B - 1) / B;
@@ -907,17 +990,17 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
   {
     uint2 d0 = ld_desc(0), d1 = ld_desc(1);
     Gf xa = gf_zero(), xb = gf_zero();
-    if (d0.y != AFF_NONE) { xa = pts[d0.x].x; xb = pts[d0.y].x; }
+    if (d0.y != AFF_NONE) { xa = ldx(d0.x); xb = ldx(d0.y); }
 #pragma unroll 1
     for (int k = 0; k < B; ++k) {
       const uint2 d2 = ld_desc(k + 2);
       Gf nxa = gf_zero(), nxb = gf_zero();
-      if (d1.y != AFF_NONE) { nxa = pts[d1.x].x; nxb = pts[d1.y].x; }
+      if (d1.y != AFF_NONE) { nxa = ldx(d1.x); nxb = ldx(d1.y); }
       Gf den = one;
       if (d0.y != AFF_NONE && !gf_is_zero(xa) && !gf_is_zero(xb)) {
         Gf dd = gf_add(xa, xb);
         if (!gf_is_zero(dd)) den = dd;
-        else if (gf_eq(pts[d0.x].y, pts[d0.y].y)) den = xa;  // doubling: lambda = x + y/x
+        else if (gf_eq(ldy(d0.x, xa), ldy(d0.y, xb))) den = xa;  // doubling: lambda = x + y/x
       }
       prefix[(size_t)k * nthr + tid] = run;
       run = gf_mul(run, den, L);
@@ -929,19 +1012,19 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
   {
     uint2 e0 = ld_desc(B - 1), e1 = ld_desc(B - 2);
     Gf px = gf_zero(), qx = gf_zero(), pre = one;
-    if (e0.x != AFF_NONE) px = pts[e0.x].x;
-    if (e0.y != AFF_NONE) { qx = pts[e0.y].x; pre = prefix[(size_t)(B - 1) * nthr + tid]; }
+    if (e0.x != AFF_NONE) px = ldx(e0.x);
+    if (e0.y != AFF_NONE) { qx = ldx(e0.y); pre = prefix[(size_t)(B - 1) * nthr + tid]; }
 #pragma unroll 1
     for (int k = B - 1; k >= 0; --k) {
       const uint2 e2 = ld_desc(k - 2);
       // this slot's y-coordinates (needed after the two products of the inverse recovery) ...
       Gf py = gf_zero(), qy = gf_zero();
-      if (e0.x != AFF_NONE) py = pts[e0.x].y;
-      if (e0.y != AFF_NONE) qy = pts[e0.y].y;
+      if (e0.x != AFF_NONE) py = ldy(e0.x, px);
+      if (e0.y != AFF_NONE) qy = ldy(e0.y, qx);
       // ... and the next slot's x-coordinates and prefix product
       Gf npx = gf_zero(), nqx = gf_zero(), npre = one;
-      if (e1.x != AFF_NONE) npx = pts[e1.x].x;
-      if (e1.y != AFF_NONE) { nqx = pts[e1.y].x; npre = prefix[(size_t)(k - 1) * nthr + tid]; }
+      if (e1.x != AFF_NONE) npx = ldx(e1.x);
+      if (e1.y != AFF_NONE) { nqx = ldx(e1.y); npre = prefix[(size_t)(k - 1) * nthr + tid]; }
       if (e0.x != AFF_NONE) {
         const uint32_t sidx = (uint32_t)k * nthr + tid;
         Gf ox = px, oy = py;  // odd leftover, or q == infinity: pass p through
@@ -990,10 +1073,17 @@ k_bucket_gather_aff(const Aff* __restrict__ in, const uint32_t* __restrict__ cnt
 // same, straight from the sorted items (keys that never had more than one point)
 __global__ void __launch_bounds__(256)
 k_bucket_gather_items(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
-                      const uint32_t* __restrict__ off, uint32_t nkeys, Ld* __restrict__ A) {
+                      const uint32_t* __restrict__ off, uint32_t nkeys, Ld* __restrict__ A, uint32_t sign_mask) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nkeys) return;
-  A[k] = cnt[k] ? ld_from_aff(bases[items[off[k]]]) : ld_infinity();
+  Ld r = ld_infinity();
+  if (cnt[k]) {
+    const uint32_t v = items[off[k]];
+    Aff q = bases[v & ~sign_mask];
+    if (v & sign_mask) q.y = gf_add(q.y, q.x);
+    r = ld_from_aff(q);
+  }
+  A[k] = r;
 }
 __global__ void __launch_bounds__(256) k_max_u32(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
   uint32_t m = 0;
@@ -1055,12 +1145,14 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   const bool slide = n_narrow < 0;
   Ld* in = buf;
   Ld* out = buf + cnt0;
-  if (n_narrow == -2) {
-    // integer sliding windows (MsmFixedCtx::integer): bucket key b stands for the odd integer 2b + 1, so the result is
+  if (n_narrow <= -2) {
+    // integer sliding windows (MsmFixedCtx::integer, -2): bucket key b stands for the odd integer 2b + 1, so the result is
     // A[0] + sum_t 2^t A[t], t = 1 .. c-1: t doublings of A[t], one point per quad of lanes (a serial chain of <= c - 1
-    // doublings at 3 products + 5 squarings each)
+    // doublings at 3 products + 5 squarings each).  Signed aligned windows (-3): key = |digit|, so the result is
+    // sum_t 2^t A[1 + t], t < c - 1, plus 2^(c-1) x bucket 0 (the digits of magnitude 2^(c-1); saved at buf[2 cnt0] before the
+    // merge turned slot 0 into the total)
     for (uint32_t pt = threadIdx.x >> 2; pt < cnt0; pt += EC_TPB / 4) {
-      Ld p = A[pt];
+      Ld p = n_narrow == -2 ? A[pt] : (pt + 1 < cnt0 ? A[1 + pt] : buf[2 * cnt0]);
 #pragma unroll 1
       for (uint32_t k = 0; k < pt; ++k) p = ld_dbl(p, L);
       if (L.r == 0) in[pt] = p;
@@ -1223,7 +1315,15 @@ struct MsmFixedCtx {
   // sliding-window mode (k_recode_slide): the table holds all TAU_DIGITS rotations, W = entry slots per scalar, keys are
   // the odd c-digit patterns (c - 1 key bits)
   bool slide = false;
-  bool integer = false;          // sliding windows over the scalar's BINARY digits: table row j holds 2^j P (k_dbl_table_all)
+  bool integer = false;          // windows over the scalar's BINARY digits: table rows hold 2^j P (k_dbl_table_all / k_dbl_table)
+  bool signed_digits = false;    // aligned windows with digits in [-2^(c-1), 2^(c-1)] (k_recode_signed): 2^(c-1) buckets
+  void set_c_signed(int cc) {
+    c = cc;
+    n_narrow = 0;
+    W = (234 + cc - 1) / cc;  // a canonical scalar (< 2^232) and the last carry
+    integer = true;
+    signed_digits = true;
+  }
   uint8_t* width_tab = nullptr;  // device, 256 entries: slide_window_width(R, c)
   void set_c_slide(int cc) {
     c = cc;
@@ -1232,7 +1332,7 @@ struct MsmFixedCtx {
     slide = true;
   }
   int rows() const { return slide ? (integer ? 233 : TAU_DIGITS) : W; }  // a canonical scalar has <= 232 binary digits
-  int key_bits() const { return slide ? c - 1 : c; }
+  int key_bits() const { return (slide || signed_digits) ? c - 1 : c; }
   int hi_bits = -1;  // level-1 partition bits of the sort (set at creation)
   FxBits bits() const { FxBits b; b.hi = hi_bits; b.lo = key_bits() - b.hi; return b; }
 };
@@ -1298,10 +1398,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     return DVP_OK;
   }
   if (n > (1u << 27)) return DVP_EINVAL;
+  const uint32_t sign_mask = (fx && fx->signed_digits) ? ITEM_NEG : 0u;  // signed flavours keep the sign in bit 31 of an item
   {  // entry positions and pre-rotated table indices are 32-bit (0xffffffff = "no partner" in a slot descriptor)
     const MsmPlan pl = msm_plan(n, fx);
     const uint64_t tab = fx ? (uint64_t)fx->rows() * fx->n_total : (uint64_t)n;
-    if ((uint64_t)pl.e_max >= 0xfffffff0ull || tab >= 0xfffffff0ull) return DVP_EINVAL;
+    if ((uint64_t)pl.e_max >= 0xfffffff0ull || tab >= (sign_mask ? 0x7ffffff0ull : 0xfffffff0ull)) return DVP_EINVAL;
   }
   int cur_dev = 0;
   DVP_HIP(hipGetDevice(&cur_dev));
@@ -1369,7 +1470,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_prefix = carve(affine_mode ? (affA_n + 128) * sizeof(Gf) : 16);  // one prefix product per output slot
   size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
-  size_t o_tail = carve((size_t)2 * p.W * p.c * sizeof(Ld));
+  size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
   DVP_TRY(g_ws.ensure(o));
   char* base = (char*)g_ws.p;
   auto* err = (unsigned long long*)(base + o_err);
@@ -1412,6 +1513,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   else if (slide)
     hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
                        fx->width_tab, p.W, digits32, err);
+  else if (fx && fx->signed_digits)
+    hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
+                       p.c, p.W, digits32, err);
   else if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
                        (uint32_t)n, p.c, p.W, p.n_narrow, digits32, err);
@@ -1460,7 +1564,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
   const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
   // entries that really exist: the overflow windows are empty in practice; a sliding window spans c + 1 digits on average
-  const size_t e_est = slide ? (size_t)((double)n * (234.0 / (p.c + 1) + 0.6)) : (size_t)n * (size_t)((234 + p.c - 1) / p.c);
+  const size_t e_est = slide ? (size_t)((double)n * (234.0 / (p.c + 1) + 0.6))
+                             : (size_t)n * (size_t)((fx && fx->signed_digits) ? p.W : (234 + p.c - 1) / p.c);
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -1501,9 +1606,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
       if (r == 0)
         hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, items_are_desc ? (const uint2*)items : (const uint2*)gdesc, d_total,
-                           aff_cap, aff_bmax, Tsq, prefix, outp);
+                           aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask);
       else
-        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp);
+        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0u);
       ps0.stop();
     }
     pts_in = outp;
@@ -1529,7 +1634,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
   if (rem_max <= 1) {
     if (ra == 0)
-      hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, bases0, items, cnt, off, nk, bkt);
+      hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, bases0, items, cnt, off, nk, bkt, sign_mask);
     else
       hipLaunchKernelGGL(k_bucket_gather_aff, dim3(cdiv(nk, 256)), dim3(256), 0, st, pts_in, pc[cur], po[cur], nk, bkt);
   } else {
@@ -1543,10 +1648,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   do {                                                                                                                                         \
     if (tmax <= accum_quad_max)                                                                                                                \
       hipLaunchKernelGGL((k_accum_affine<IND, true>), dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, pts_in, items, pc[cur], po[cur], \
-                         po[nxt], nk, p.K, bufA);                                                                                              \
+                         po[nxt], nk, p.K, bufA, sign_mask);                                                                                   \
     else                                                                                                                                       \
       hipLaunchKernelGGL((k_accum_affine<IND, false>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur],     \
-                         po[nxt], nk, p.K, bufA);                                                                                              \
+                         po[nxt], nk, p.K, bufA, sign_mask);                                                                                   \
   } while (0)
     if (ra == 0) {
       ProfScope ps0(PROF_MSM_ACCUM_AFFINE, st);  // small inputs: no pair rounds, this is the dominant kernel
@@ -1574,6 +1679,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   ProfScope ps_tail(PROF_MSM_TAIL, st);  // merge tree, Frobenius tail, final add tree
   const int merge_levels = fx ? fx->key_bits() : p.c;
+  if (sign_mask)  // bucket 0 (digits of magnitude 2^(c-1)) before the merge turns slot 0 into the total: k_tail weighs it by 2^(c-1)
+    DVP_HIP(hipMemcpyAsync(tail + 2 * (size_t)p.c, bkt, sizeof(Ld), hipMemcpyDeviceToDevice, st));
   for (int j = 0; j < merge_levels; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
@@ -1586,7 +1693,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
   (void)cntT;
-  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, slide ? (fx->integer ? -2 : -1) : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, slide ? (fx->integer ? -2 : -1) : (sign_mask ? -3 : (fx ? 0 : p.n_narrow)), Tsq, ta, (uint32_t*)d_out_xy,
                      (uint32_t*)d_out_inf);
   ps_tail.stop();
   ps_total.stop();
@@ -1639,7 +1746,18 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
     if (cost < best) { best = cost; best_c = cc; }
   }
   if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= c_max) best_c = (int)tune().msm_fixed_c;
-  if (slide) c->set_c_slide(best_c); else c->set_c(best_c);
+  const bool signed_aligned = !slide && tune().msm_aligned_signed != 0;
+  if (signed_aligned) {  // same cost model over its own entry and bucket counts: ceil(234 / c) entries, 2^(c-1) buckets
+    best = 1e300;
+    for (int cc = 8; cc <= FX_C_MAX + 1; ++cc) {
+      const int kb = cc - 1;
+      const double per_scalar = (double)((234 + cc - 1) / cc);
+      double cost = per_scalar * (double)range_hint * 5.6 + 10.0 * (double)(1u << kb) + (kb > 18 ? 25.0 * (double)((1u << kb) - (1u << 18)) : 0.0);
+      if (cost < best) { best = cost; best_c = cc; }
+    }
+    if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= FX_C_MAX + 1) best_c = (int)tune().msm_fixed_c;
+    c->set_c_signed(best_c);
+  } else if (slide) c->set_c_slide(best_c); else c->set_c(best_c);
   const int kb = c->key_bits();
   c->hi_bits = kb / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
   if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && kb - h <= 15 && kb - h >= 1) c->hi_bits = h;
@@ -1660,7 +1778,13 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
       if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table_all, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->rows(), Tsq, c->table);
     } else if (slide)
       hipLaunchKernelGGL(k_frob_table_all, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->rows(), c->table);
-    else
+    else if (c->signed_digits) {
+      GfSqrTables Tsq;
+      int rc_t = gf_sqr_tables(&Tsq, 0);
+      if (rc_t != DVP_OK) { msm_fixed_destroy(c); return rc_t; }
+      e = hipFuncSetAttribute((const void*)k_dbl_table, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
+      if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->c, c->W, Tsq, c->table);
+    } else
       hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
     if (e == hipSuccess) e = hipGetLastError();
   }
@@ -1863,6 +1987,32 @@ static int debug_recode(const uint64_t* scalars, size_t n, int c, uint32_t* out_
                        *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*slots * n * 4, hipMemcpyDeviceToHost));
+  unsigned long long e = 0;
+  DVP_HIP(hipMemcpy(&e, de.p, 8, hipMemcpyDeviceToHost));
+  if (e != ~0ull) {
+    g_last_error_index = (int64_t)(e & 0xffffffffull);
+    return DVP_EINVAL;
+  }
+  return DVP_OK;
+}
+
+// the signed aligned windows (k_recode_signed): out_words[w * n + i] = 0 (digit 0) or 0x80000000 | 0x10000000 if the digit is
+// negative | w << 20 | |digit| (|digit| = 2^(c-1) stored as key 0); *windows = ceil(234 / c)
+extern "C" int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* windows) {
+  if (!windows || c < 8 || c > FX_C_MAX + 1 || n > (1u << 24)) return DVP_EINVAL;
+  *windows = (234 + c - 1) / c;
+  if (!out_words) return DVP_OK;
+  if (!scalars || !n) return DVP_EINVAL;
+  DevBuf ds, dw, de;
+  DVP_TRY(ds.alloc(n * 32));
+  DVP_TRY(dw.alloc((size_t)*windows * n * 4));
+  DVP_TRY(de.alloc(8));
+  DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+  DVP_HIP(hipMemset(de.p, 0xff, 8));
+  hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, c, *windows,
+                     dw.as<uint32_t>(), de.as<unsigned long long>());
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*windows * n * 4, hipMemcpyDeviceToHost));
   unsigned long long e = 0;
   DVP_HIP(hipMemcpy(&e, de.p, 8, hipMemcpyDeviceToHost));
   if (e != ~0ull) {

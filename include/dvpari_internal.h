@@ -48,6 +48,9 @@ int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_tabl
 int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
 /* the same for the default sliding flavour, windows cut from the scalar's BINARY digits (position = bit position) */
 int dvp_debug_recode_binary(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
+/* the signed aligned windows of the small-table flavour: out_words[w * n + i] = 0 (digit 0) or 0x80000000 | 0x10000000 when the
+ * digit is negative | w << 20 | |digit| (|digit| = 2^(c-1) is stored as key 0); *windows = ceil(234 / c_bits) */
+int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* windows);
 
 /* intermediates of the last proof, for parity tests (names: see prove.hip) */
 int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);

@@ -125,7 +125,7 @@ def test_msm_wire_format(dvp):
     assert out == co.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)))
 
 
-@pytest.mark.parametrize("slide", [0, 1, 2])  # aligned tau windows / tau sliding windows / sliding windows over the binary digits
+@pytest.mark.parametrize("slide", [0, 1, 2, 3])  # signed aligned binary windows / tau sliding / binary sliding / tau aligned windows
 @pytest.mark.parametrize("hint", [0, 1 << 10, 1 << 24])
 def test_fixed_base_msm_context(dvp, hint, slide):
     """dvp_msm_ctx_*: pre-rotated bases, shared bucket set; full range, sub-ranges (the per-GPU shards) and a
@@ -136,11 +136,12 @@ def test_fixed_base_msm_context(dvp, hint, slide):
     bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
     inf = np.zeros(n, dtype=np.uint8)
     inf[5] = 1
+    knobs = {"DVP_MSM_SLIDE": 0, "DVP_MSM_ALIGNED_SIGNED": 0} if slide == 3 else {"DVP_MSM_SLIDE": slide}
     if hint <= n:
-        with dvp.tune(DVP_MSM_SLIDE=slide):
+        with dvp.tune(**knobs):
             fb = dvp.curve.FixedBaseMsm(bases, inf, hint)
     else:
-        with dvp.tune(DVP_MSM_FIXED_C=20, DVP_MSM_SLIDE=slide):
+        with dvp.tune(DVP_MSM_FIXED_C=20, **knobs):
             fb = dvp.curve.FixedBaseMsm(bases, inf, 0)
     ks, ss = from_limbs(k), from_limbs(s)
 
@@ -239,11 +240,14 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     assert max(len(co.tau_digits(x)) for x in special) >= 236
     s[: len(special)] = to_limbs(special)
     ks, ss = from_limbs(k), from_limbs(s)
-    for c, slide in [(c, 0) for c in range(8, 21)] + [(c, 1) for c in range(8, 22)] + [(c, 2) for c in range(8, 22)]:
-        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_SLIDE=slide, DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
+    # slide: 0 = aligned windows (signed binary digits: the default small-table flavour), 3 = aligned tau-adic windows,
+    # 1 = tau-adic sliding windows, 2 = sliding windows over the binary digits
+    for c, slide in [(c, 0) for c in range(8, 22)] + [(c, 3) for c in range(8, 21)] + [(c, 1) for c in range(8, 22)] + [(c, 2) for c in range(8, 22)]:
+        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_SLIDE=0 if slide == 3 else slide, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1,
+                      DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
                       DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
             fb = dvp.curve.FixedBaseMsm(bases)
-            assert fb.plan() == (c, slide_slots(c) if slide else (234 + c - 1) // c + 1)
+            assert fb.plan() == (c, slide_slots(c) if slide in (1, 2) else (234 + c - 1) // c + (1 if slide == 3 else 0))
             for _ in range(3):
                 lo = rnd.randrange(0, n - 1)
                 hi = rnd.randrange(lo + 1, n + 1)
@@ -359,3 +363,38 @@ def test_binary_recode_words_vs_restatement(dvp, c):
     bad = to_limbs([5, o.P])
     w2 = np.zeros((slots.value, 2), dtype=np.uint32)
     assert dvp.lib.dvp_debug_recode_binary(bad.ctypes.data, 2, c, w2.ctypes.data, C.byref(slots)) == -1 and dvp.lib.dvp_last_error_index() == 1
+
+
+@pytest.mark.parametrize("c", [8, 13, 19, 20, 21])
+def test_signed_recode_words_vs_restatement(dvp, c):
+    """k_recode_signed (the small-table flavour: aligned windows of signed binary digits) word for word against the textbook
+    signed-digit decomposition restated here: window w holds bits [c w, c w + c) plus the carry from below, a digit above
+    2^(c-1) becomes digit - 2^c with a carry; sum_w d_w 2^(c w) is the scalar and |d_w| <= 2^(c-1)."""
+    import ctypes as C
+
+    rnd = random.Random(500 + c)
+    vals = [0, 1, 2, (1 << c) - 1, 1 << (c - 1), (1 << (c - 1)) + 1, o.P - 1, (1 << 231) - 1, 1 << 230, int("1" * 231, 2)] \
+        + [rnd.randrange(o.P) for _ in range(1500)] + [rnd.randrange(1 << rnd.randrange(1, 232)) for _ in range(300)]
+    s = to_limbs(vals)
+    W = C.c_int(0)
+    dvp.check(dvp.lib.dvp_debug_recode_signed(None, 0, c, None, C.byref(W)), "windows")
+    assert W.value == (234 + c - 1) // c
+    words = np.zeros((W.value, len(vals)), dtype=np.uint32)
+    dvp.check(dvp.lib.dvp_debug_recode_signed(s.ctypes.data, len(vals), c, words.ctypes.data, C.byref(W)), "recode")
+    half = 1 << (c - 1)
+    for i, x in enumerate(vals):
+        exp, carry = [], 0
+        for w in range(W.value):
+            d = ((x >> (c * w)) & ((1 << c) - 1)) + carry
+            carry = 0
+            if d > half:
+                d, carry = d - (1 << c), 1
+            exp.append(d)
+        assert carry == 0 and sum(d << (c * w) for w, d in enumerate(exp)) == x
+        for w, d in enumerate(exp):
+            word = int(words[w, i])
+            if d == 0:
+                assert word == 0, (c, i, w)
+            else:
+                assert word >> 31 == 1 and ((word >> 20) & 0xFF) == w and bool(word & 0x10000000) == (d < 0), (c, i, w, hex(word))
+                assert (word & 0xFFFFF) == (abs(d) & (half - 1)), (c, i, w, d, hex(word))

@@ -406,8 +406,8 @@ def test_table_flavours_same_bytes(dvp):
     rnd = random.Random(77)
     td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
     proofs = []
-    for slide in (0, 1, 2, -1):
-        with dvp.tune(DVP_MSM_FIXED_MIN=1, DVP_MSM_SLIDE=slide):
+    for slide in (0, 1, 2, -1, 3):  # 3 = aligned tau-adic windows (DVP_MSM_ALIGNED_SIGNED = 0); 0 = aligned signed binary windows
+        with dvp.tune(DVP_MSM_FIXED_MIN=1, DVP_MSM_SLIDE=0 if slide == 3 else slide, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1):
             pv = dvp.proving.Prover(inst)
             pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
             assert pv.msm_table(0) == (0, False)      # no table before the first proof
@@ -417,9 +417,9 @@ def test_table_flavours_same_bytes(dvp):
                 # sliding tables: 240 Frobenius rotations (DVP_MSM_SLIDE = 1) or 233 integer multiples 2^j P (= 2, the default)
                 rows = (240 if slide == 1 else 233) if sliding else pv.msm_plan(which)[1]
                 assert nbytes == rows * pv.msm_size(which) * 64
-                assert sliding == (slide != 0)          # the default picks the sliding tables on an empty 288 GB device
+                assert sliding == (slide not in (0, 3))  # the default picks the sliding tables on an empty 288 GB device
             pv.close()
-    assert proofs[0] == proofs[1] == proofs[2] == proofs[3] and dvp.srs.verify(td, pub, proofs[0])
+    assert proofs[0] == proofs[1] == proofs[2] == proofs[3] == proofs[4] and dvp.srs.verify(td, pub, proofs[0])
 
 
 def test_points_sum_records(dvp):
