@@ -61,7 +61,6 @@ static void tune_from_env(Tune& t) {
   t.msm_fixed_min = geti("DVP_MSM_FIXED_MIN", t.msm_fixed_min);
   t.horner_max_pub = geti("DVP_HORNER_MAX_PUB", t.horner_max_pub);
   t.msm_table_max_gb = geti("DVP_MSM_TABLE_MAX_GB", t.msm_table_max_gb);
-  t.msm_slide_integer = geti("DVP_MSM_SLIDE_INTEGER", t.msm_slide_integer);
   t.msm_aligned_signed = geti("DVP_MSM_ALIGNED_SIGNED", t.msm_aligned_signed);
 }
 static std::mutex g_dev_mu;
@@ -82,7 +81,7 @@ static long long* tune_slot(const char* name) {
       {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi}, {"DVP_MSM_SLIDE", &t.msm_slide},
       {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax},
       {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_ACCUM_QUAD_MAX", &t.msm_accum_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub},
-      {"DVP_MSM_TABLE_MAX_GB", &t.msm_table_max_gb}, {"DVP_MSM_SLIDE_INTEGER", &t.msm_slide_integer}, {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}};
+      {"DVP_MSM_TABLE_MAX_GB", &t.msm_table_max_gb}, {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}};
   for (auto& e : tab)
     if (!strcmp(name, e.n)) return e.v;
   return nullptr;

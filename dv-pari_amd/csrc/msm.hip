@@ -210,7 +210,7 @@ k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__
 // travels with the entry (FXW_NEG) and is applied when the point is loaded.  W = ceil(234 / c) windows take a canonical scalar
 // (< 2^232) including the last carry.  No tau-adic expansion: a few shifts per window.
 __global__ void __launch_bounds__(256)
-k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W,
+k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow,
                 uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -223,28 +223,33 @@ k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict_
     atomicMin(err, (unsigned long long)i);
     skip = true;
   }
-  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  // the n_narrow LOW windows are c - 1 bits wide, the rest c (widths evened out so that the 234 bits fill every window: a short
+  // top window would send every scalar into a handful of buckets)
   uint32_t carry = 0;
+  int bit = 0;
 #pragma unroll 1
   for (int w = 0; w < W; ++w) {
-    const int bit = w * c, wd = bit >> 5, sh = bit & 31;
+    const int width = w < n_narrow ? c - 1 : c;
+    const uint32_t half = 1u << (width - 1), mask = (1u << width) - 1;
+    const int wd = bit >> 5, sh = bit & 31;
     uint32_t lo = wd < 8 ? s[wd] : 0u, hi = wd + 1 < 9 ? s[wd + 1] : 0u;
     uint32_t d = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & mask;
+    bit += width;
     d += carry;
     carry = 0;
     uint32_t word = 0;
     if (d > mask) {  // all ones + carry: digit 0, carry on
       carry = 1;
-    } else if (d > half) {  // d - 2^c < 0
+    } else if (d > half) {  // d - 2^width < 0
       carry = 1;
-      d = (1u << c) - d;  // |d| in [1, 2^(c-1))
+      d = (1u << width) - d;  // |d| in [1, 2^(width-1))
       word = FXW_VALID | FXW_NEG | ((uint32_t)w << FXW_ROW_SHIFT) | d;
     } else if (d) {
-      word = FXW_VALID | ((uint32_t)w << FXW_ROW_SHIFT) | (d & (half - 1));  // d == 2^(c-1) -> key 0
+      word = FXW_VALID | ((uint32_t)w << FXW_ROW_SHIFT) | (d & ((1u << (c - 1)) - 1));  // a full-width d == 2^(c-1) -> key 0
     }
     words[(size_t)w * n + i] = skip ? 0u : word;
   }
-  if (carry && !skip) atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: W c >= 234
+  if (carry && !skip) atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: the widths add up to >= 234
 }
 
 // ---- exclusive scan of u32 (3 kernels; up to 4096*1024 elements) ---------------------------------
@@ -735,9 +740,9 @@ k_dbl_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, GfSqrTables
   }
 }
 
-// signed aligned windows: T[w][i] = 2^(c w) P_i, w < W (c affine doublings between rows)
+// signed aligned windows: T[w][i] = 2^(o_w) P_i, o_w = first bit of window w (the n_narrow low windows are c - 1 bits wide)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, GfSqrTables T, Aff* __restrict__ table) {
+k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, int n_narrow, GfSqrTables T, Aff* __restrict__ table) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -747,8 +752,9 @@ k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, GfSqrTables
   const Gf one = gf_one();
 #pragma unroll 1
   for (int w = 1; w < W; ++w) {
+    const int width = (w - 1) < n_narrow ? c - 1 : c;  // row w starts where window w - 1 ends
 #pragma unroll 1
-    for (int k = 0; k < c; ++k) {
+    for (int k = 0; k < width; ++k) {
       Gf lam = gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L));
       Gf x3 = gf_add(gf_sqr(lam), lam);
       p.y = gf_add(gf_sqr(p.x), gf_mul(gf_add(lam, one), x3, L));
@@ -1317,10 +1323,16 @@ struct MsmFixedCtx {
   bool slide = false;
   bool integer = false;          // windows over the scalar's BINARY digits: table rows hold 2^j P (k_dbl_table_all / k_dbl_table)
   bool signed_digits = false;    // aligned windows with digits in [-2^(c-1), 2^(c-1)] (k_recode_signed): 2^(c-1) buckets
+  // 234 bits (a canonical scalar < 2^232, the last carry, one spare so that the top digit stays positive) in W = ceil(234 / c)
+  // windows whose widths differ by at most one: the n_narrow LOW windows are c - 1 wide.  A request whose windows would all be
+  // narrow is the next smaller c.
   void set_c_signed(int cc) {
+    for (;; --cc) {
+      W = (234 + cc - 1) / cc;
+      n_narrow = W * cc - 234;
+      if (n_narrow < W || cc <= 2) break;
+    }
     c = cc;
-    n_narrow = 0;
-    W = (234 + cc - 1) / cc;  // a canonical scalar (< 2^232) and the last carry
     integer = true;
     signed_digits = true;
   }
@@ -1515,7 +1527,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                        fx->width_tab, p.W, digits32, err);
   else if (fx && fx->signed_digits)
     hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
-                       p.c, p.W, digits32, err);
+                       p.c, p.W, p.n_narrow, digits32, err);
   else if (fx)
     hipLaunchKernelGGL((k_recode<uint32_t>), dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf,
                        (uint32_t)n, p.c, p.W, p.n_narrow, digits32, err);
@@ -1750,8 +1762,11 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
   if (signed_aligned) {  // same cost model over its own entry and bucket counts: ceil(234 / c) entries, 2^(c-1) buckets
     best = 1e300;
     for (int cc = 8; cc <= FX_C_MAX + 1; ++cc) {
+      MsmFixedCtx probe;
+      probe.set_c_signed(cc);
+      if (probe.c != cc) continue;  // all windows narrow: the same plan as cc - 1
       const int kb = cc - 1;
-      const double per_scalar = (double)((234 + cc - 1) / cc);
+      const double per_scalar = (double)probe.W;
       double cost = per_scalar * (double)range_hint * 5.6 + 10.0 * (double)(1u << kb) + (kb > 18 ? 25.0 * (double)((1u << kb) - (1u << 18)) : 0.0);
       if (cost < best) { best = cost; best_c = cc; }
     }
@@ -1783,7 +1798,7 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
       int rc_t = gf_sqr_tables(&Tsq, 0);
       if (rc_t != DVP_OK) { msm_fixed_destroy(c); return rc_t; }
       e = hipFuncSetAttribute((const void*)k_dbl_table, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->c, c->W, Tsq, c->table);
+      if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->c, c->W, c->n_narrow, Tsq, c->table);
     } else
       hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
     if (e == hipSuccess) e = hipGetLastError();
@@ -1799,32 +1814,21 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
 }
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
   if ((uint64_t)n_total * 32 >= 0xfffffff0ull) return DVP_EINVAL;  // W <= 31 windows of pre-rotated copies, 32-bit indices
-  // Sliding windows need every rotation of every base: TAU_DIGITS x n_total x 64 B (15 KB per base; 64 GB for the 4m
-  // bases of a 2^20-constraint prover, 97 GB for both of its SRS vectors) and buy ~8 % fewer bucket additions.  MI355X
-  // has 288 GB, so by default (Tune::msm_slide < 0) the mode is on whenever the table leaves a reserve of a quarter of the
-  // device (72 GB: MSM workspaces, ECFFT trees, the prover's vectors) free on the device right now -- both SRS vectors
-  // up to 2^21 constraints, the first one at 2^22; a third prover on the same device or a larger circuit gets the aligned
-  // windows and their W-row table on its own -- and an allocation failure falls back to the aligned windows as well.
+  // Table flavour (Tune::msm_slide, DVP_MSM_SLIDE):
+  //   unset / 0  aligned windows of signed binary digits over W rows 2^(o_w) P (768 B per base at W = 12: 4.8 GB for both SRS
+  //              vectors of a 2^20-constraint prover) -- the default: it is as fast as the sliding flavours (round 3:
+  //              23.54 ms against 23.57 ms) at a twentieth of their memory;
+  //   2          sliding windows over the binary digits, all 233 multiples 2^j P of every base (14.9 KB per base, 94 GB);
+  //   1          sliding windows over the tau-adic digits, all 240 Frobenius rotations (15.4 KB per base, 97 GB).
+  // DVP_MSM_ALIGNED_SIGNED = 0 turns the aligned flavour back into round 2's tau-adic aligned windows.  A sliding table above
+  // the byte budget DVP_MSM_TABLE_MAX_GB (when set) is refused in favour of the aligned flavour.
   const uint64_t slide_bytes = (uint64_t)TAU_DIGITS * n_total * sizeof(Aff);
   const long long mode = tune().msm_slide;
-  bool slide = false;
-  if ((uint64_t)TAU_DIGITS * n_total < 0xfffffff0ull && mode != 0) {
-    size_t free_b = 0, total_b = 0;
-    const long long budget_gb = tune().msm_table_max_gb;  // DVP_MSM_TABLE_MAX_GB: explicit byte budget of one table
-    if (mode > 0) slide = true;
-    else if (budget_gb >= 0) slide = slide_bytes <= (uint64_t)budget_gb * 1000000000ull;
-    else slide = hipMemGetInfo(&free_b, &total_b) == hipSuccess && slide_bytes + (uint64_t)total_b / 4 <= (uint64_t)free_b;
-  }
-  // DVP_MSM_SLIDE: 1 = tau-adic sliding windows, 2 = sliding windows over the binary digits (integer multiples in the table);
-  // unset: the integer flavour when the table fits
-  const bool integer = mode == 2 || (mode < 0 && tune().msm_slide_integer != 0);
+  bool slide = mode > 0 && (uint64_t)TAU_DIGITS * n_total < 0xfffffff0ull;
+  const long long budget_gb = tune().msm_table_max_gb;
+  if (slide && budget_gb >= 0 && slide_bytes > (uint64_t)budget_gb * 1000000000ull) slide = false;
   hipError_t alloc_err = hipSuccess;
-  int rc = msm_fixed_build(d_bases, n_total, range_hint, slide, integer, out, &alloc_err);
-  if (rc != DVP_OK && slide && mode < 0 && alloc_err == hipErrorOutOfMemory) {
-    (void)hipGetLastError();  // the failed hipMalloc is not an error of this call
-    rc = msm_fixed_build(d_bases, n_total, range_hint, false, false, out, &alloc_err);
-  }
-  return rc;
+  return msm_fixed_build(d_bases, n_total, range_hint, slide, mode == 2, out, &alloc_err);
 }
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows) {
   if (!c) return DVP_EINVAL;
@@ -2000,7 +2004,10 @@ static int debug_recode(const uint64_t* scalars, size_t n, int c, uint32_t* out_
 // negative | w << 20 | |digit| (|digit| = 2^(c-1) stored as key 0); *windows = ceil(234 / c)
 extern "C" int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* windows) {
   if (!windows || c < 8 || c > FX_C_MAX + 1 || n > (1u << 24)) return DVP_EINVAL;
-  *windows = (234 + c - 1) / c;
+  MsmFixedCtx plan;
+  plan.set_c_signed(c);
+  if (plan.c != c) return DVP_EINVAL;  // a window size whose windows would all be one bit narrower: ask for c - 1
+  *windows = plan.W;
   if (!out_words) return DVP_OK;
   if (!scalars || !n) return DVP_EINVAL;
   DevBuf ds, dw, de;
@@ -2009,7 +2016,7 @@ extern "C" int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c,
   DVP_TRY(de.alloc(8));
   DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
   DVP_HIP(hipMemset(de.p, 0xff, 8));
-  hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, c, *windows,
+  hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, c, *windows, plan.n_narrow,
                      dw.as<uint32_t>(), de.as<unsigned long long>());
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*windows * n * 4, hipMemcpyDeviceToHost));

@@ -247,7 +247,13 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
                       DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
                       DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
             fb = dvp.curve.FixedBaseMsm(bases)
-            assert fb.plan() == (c, slide_slots(c) if slide in (1, 2) else (234 + c - 1) // c + (1 if slide == 3 else 0))
+            if slide == 0:  # 234 bits in ceil(234 / c) windows evened out; all windows narrow = the plan of c - 1 (19 -> 18, 21 -> 20)
+                ce = c
+                while (234 + ce - 1) // ce * ce - 234 >= (234 + ce - 1) // ce:
+                    ce -= 1
+                assert fb.plan() == (ce, (234 + ce - 1) // ce)
+            else:
+                assert fb.plan() == (c, slide_slots(c) if slide in (1, 2) else (234 + c - 1) // c + 1)
             for _ in range(3):
                 lo = rnd.randrange(0, n - 1)
                 hi = rnd.randrange(lo + 1, n + 1)
@@ -365,36 +371,52 @@ def test_binary_recode_words_vs_restatement(dvp, c):
     assert dvp.lib.dvp_debug_recode_binary(bad.ctypes.data, 2, c, w2.ctypes.data, C.byref(slots)) == -1 and dvp.lib.dvp_last_error_index() == 1
 
 
-@pytest.mark.parametrize("c", [8, 13, 19, 20, 21])
+@pytest.mark.parametrize("c", [8, 13, 18, 19, 20, 21])
 def test_signed_recode_words_vs_restatement(dvp, c):
     """k_recode_signed (the small-table flavour: aligned windows of signed binary digits) word for word against the textbook
-    signed-digit decomposition restated here: window w holds bits [c w, c w + c) plus the carry from below, a digit above
-    2^(c-1) becomes digit - 2^c with a carry; sum_w d_w 2^(c w) is the scalar and |d_w| <= 2^(c-1)."""
+    signed-digit decomposition restated here: 234 bits in W = ceil(234 / c) windows, the W c - 234 LOW windows one bit
+    narrower (so no window is short: a short top window would pile every scalar into a handful of buckets); window w holds
+    its bits plus the carry from below, a digit above half its range becomes digit - 2^width with a carry;
+    sum_w d_w 2^(o_w) is the scalar and |d_w| <= 2^(width_w - 1).  A c whose windows would all be narrow is refused
+    (it is the plan of c - 1)."""
     import ctypes as C
 
     rnd = random.Random(500 + c)
-    vals = [0, 1, 2, (1 << c) - 1, 1 << (c - 1), (1 << (c - 1)) + 1, o.P - 1, (1 << 231) - 1, 1 << 230, int("1" * 231, 2)] \
-        + [rnd.randrange(o.P) for _ in range(1500)] + [rnd.randrange(1 << rnd.randrange(1, 232)) for _ in range(300)]
-    s = to_limbs(vals)
     W = C.c_int(0)
-    dvp.check(dvp.lib.dvp_debug_recode_signed(None, 0, c, None, C.byref(W)), "windows")
-    assert W.value == (234 + c - 1) // c
+    n_win = (234 + c - 1) // c
+    n_narrow = n_win * c - 234
+    rc = dvp.lib.dvp_debug_recode_signed(None, 0, c, None, C.byref(W))
+    if n_narrow >= n_win:
+        assert rc == -1
+        return
+    dvp.check(rc, "windows")
+    assert W.value == n_win
+    widths = [c - 1 if w < n_narrow else c for w in range(n_win)]
+    assert sum(widths) == 234
+    vals = [0, 1, 2, (1 << c) - 1, 1 << (c - 1), (1 << (c - 1)) + 1, (1 << (c - 2)), (1 << (c - 2)) + 1, o.P - 1, (1 << 231) - 1, 1 << 230,
+            int("1" * 231, 2)] + [rnd.randrange(o.P) for _ in range(1500)] + [rnd.randrange(1 << rnd.randrange(1, 232)) for _ in range(300)]
+    # every window at exactly half its range, and one past it (the wrap / carry boundary of each width)
+    off = 0
+    for wd in widths[:-1]:
+        vals += [1 << (off + wd - 1), (1 << (off + wd - 1)) + (1 << off), ((1 << wd) - 1) << off]
+        off += wd
+    s = to_limbs(vals)
     words = np.zeros((W.value, len(vals)), dtype=np.uint32)
     dvp.check(dvp.lib.dvp_debug_recode_signed(s.ctypes.data, len(vals), c, words.ctypes.data, C.byref(W)), "recode")
-    half = 1 << (c - 1)
     for i, x in enumerate(vals):
-        exp, carry = [], 0
-        for w in range(W.value):
-            d = ((x >> (c * w)) & ((1 << c) - 1)) + carry
+        exp, carry, off = [], 0, 0
+        for wd in widths:
+            d = ((x >> off) & ((1 << wd) - 1)) + carry
             carry = 0
-            if d > half:
-                d, carry = d - (1 << c), 1
-            exp.append(d)
-        assert carry == 0 and sum(d << (c * w) for w, d in enumerate(exp)) == x
-        for w, d in enumerate(exp):
+            if d > (1 << (wd - 1)):
+                d, carry = d - (1 << wd), 1
+            exp.append((off, d))
+            off += wd
+        assert carry == 0 and sum(d << o_w for o_w, d in exp) == x
+        for w, (_, d) in enumerate(exp):
             word = int(words[w, i])
             if d == 0:
                 assert word == 0, (c, i, w)
             else:
                 assert word >> 31 == 1 and ((word >> 20) & 0xFF) == w and bool(word & 0x10000000) == (d < 0), (c, i, w, hex(word))
-                assert (word & 0xFFFFF) == (abs(d) & (half - 1)), (c, i, w, d, hex(word))
+                assert (word & 0xFFFFF) == (abs(d) & ((1 << (c - 1)) - 1)), (c, i, w, d, hex(word))  # bucket key; 2^(c-1) -> bucket 0

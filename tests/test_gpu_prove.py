@@ -399,8 +399,10 @@ def test_in_library_multi_gpu_same_bytes(dvp, log_m, devices):
 
 
 def test_table_flavours_same_bytes(dvp):
-    """the fixed-base table flavours (aligned windows over W rotations / sliding windows over all 240 rotations / sliding
-    windows over the 233 integer multiples 2^j P, DVP_MSM_SLIDE = 0 / 1 / 2) and the default produce the same proof; dvp_prover_msm_table_bytes reports flavour and size (rotations x bases x 64 B)"""
+    """the fixed-base table flavours (aligned windows over W rows / sliding windows over all 240 Frobenius rotations / sliding
+    windows over the 233 integer multiples 2^j P, DVP_MSM_SLIDE = 0 / 1 / 2), the default (unset: the aligned signed windows)
+    and round 2's aligned tau-adic windows produce the same proof; dvp_prover_msm_table_bytes reports flavour and size
+    (rows x bases x 64 B)"""
     log_m = 13
     inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
     rnd = random.Random(77)
@@ -414,10 +416,10 @@ def test_table_flavours_same_bytes(dvp):
             proofs.append(pv.prove(pub, prv))
             for which in (0, 1):
                 nbytes, sliding = pv.msm_table(which)
-                # sliding tables: 240 Frobenius rotations (DVP_MSM_SLIDE = 1) or 233 integer multiples 2^j P (= 2, the default)
+                # sliding tables: 240 Frobenius rotations (DVP_MSM_SLIDE = 1) or 233 integer multiples 2^j P (= 2)
                 rows = (240 if slide == 1 else 233) if sliding else pv.msm_plan(which)[1]
                 assert nbytes == rows * pv.msm_size(which) * 64
-                assert sliding == (slide not in (0, 3))  # the default picks the sliding tables on an empty 288 GB device
+                assert sliding == (slide in (1, 2))  # the default (-1) is the aligned signed-window table
             pv.close()
     assert proofs[0] == proofs[1] == proofs[2] == proofs[3] == proofs[4] and dvp.srs.verify(td, pub, proofs[0])
 

@@ -9,8 +9,8 @@ td = dvp.srs.Trapdoor(0x1234567 + (1 << 200), 0x7654321 + (1 << 190), 0xABCDEF +
 w = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).cuda()
 srs, ref = None, None
 FL = [("sliding, binary digits (default)", {}), ("sliding, tau-adic", {"DVP_MSM_SLIDE": 1}),
-      ("aligned, signed binary digits", {"DVP_MSM_SLIDE": 0}), ("aligned, signed, c=19", {"DVP_MSM_SLIDE": 0, "DVP_MSM_FIXED_C": 19}),
-      ("aligned, signed, c=21", {"DVP_MSM_SLIDE": 0, "DVP_MSM_FIXED_C": 21}),
+      ("aligned, signed binary digits", {"DVP_MSM_SLIDE": 0}), ("aligned, signed, c=18", {"DVP_MSM_SLIDE": 0, "DVP_MSM_FIXED_C": 18}),
+      ("aligned, signed, c=17", {"DVP_MSM_SLIDE": 0, "DVP_MSM_FIXED_C": 17}),
       ("aligned, tau-adic", {"DVP_MSM_SLIDE": 0, "DVP_MSM_ALIGNED_SIGNED": 0})]
 for name, knobs in FL:
     with dvp.tune(**knobs):
