@@ -384,17 +384,23 @@ def main():
     mul_frac = (mul_eq / launch_s) / mul_rate if (acc_n and mul_rate) else None
     gathers = 4.0 * adds_per_launch  # 64-byte lines: both operands of an addition, once per pass
     gather_frac = (gathers / launch_s) / gather_rate if (acc_n and gather_rate) else None
+    # "bound" names the peak the contract's achieved / peak / frac triple is quoted against (algorithmic bytes against HBM streaming
+    # bandwidth); "limiter" is what the two models measured in this run say actually binds the kernel
+    bound = "hbm"
     if gather_frac is not None and mul_frac is not None:
-        bound = "hbm" if gather_frac >= mul_frac else "valu"
+        limiter = "gather_rate" if gather_frac >= mul_frac else "valu_lds"
     else:
-        bound = "hbm"
+        limiter = None
     roof = {
         "kernel": "dvp::k_affine_round<true> (first pair round of each MSM; the later rounds are k_affine_round<false>)",
         "bound": bound,
-        "bound_note": "the limit is the RATE of random 64-byte line reads out of the pre-rotated base table (a memory-system limit that sits far below "
-                      "streaming bandwidth), with the GF(2^233) product rate of the integer VALU + LDS close behind: see gather_model.frac and "
-                      "work_model.frac, both against ceilings measured in this run; achieved / peak / frac is the algorithmic-bytes figure against the "
-                      "HBM streaming peak that the metric contract asks for",
+        "limiter": limiter,
+        "bound_note": "achieved / peak / frac is the algorithmic-bytes figure against the HBM streaming peak that the metric contract asks for "
+                      "(tiny by construction: 96 B per pair); what binds the kernel is `limiter`, the larger of work_model.frac (GF(2^233) "
+                      "products on the integer VALU + LDS against the multiplier microbenchmark) and gather_model.frac (random 64-byte "
+                      "point reads against the gather microbenchmark on the same table), both ceilings measured in this run.  With the "
+                      "default 3-5 GB tables the gathers sit at about a third of their ceiling and the kernel is product-bound at the "
+                      "clock the chip holds under this load (issue.effective_clock_ghz against the microbenchmark's)",
         "achieved": achieved,
         "peak": 8000.0,
         "unit": "GB/s",

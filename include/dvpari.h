@@ -130,16 +130,15 @@ int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void
 typedef struct dvp_msm_ctx dvp_msm_ctx;
 int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out);
 void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
-/* window bits c and window count (aligned windows: all W windows share one set of 2^c buckets; sliding windows: entry
- * slots per scalar, 2^(c-1) buckets of odd patterns) the context settled on */
+/* window bits c and window count (aligned windows: all W windows share one set of 2^(c-1) buckets of |digit|; sliding windows:
+ * entry slots per scalar, 2^(c-1) buckets of odd patterns) the context settled on */
 int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
-/* HBM held by the context's precomputed table.  Two flavours: aligned windows keep W ~ 14 Frobenius rotations of every base
- * (0.9 KB per base); sliding windows keep a multiple of the base for EVERY digit position -- by default the 233 integer
- * multiples 2^j P (windows cut from the scalar's binary digits; 14.6 KB per base: 63 GB for the 4m bases of a 2^20-constraint
- * prover), with DVP_MSM_SLIDE=1 the 240 Frobenius rotations tau^j P (windows over the tau-adic digits) -- and need ~8 % fewer
- * bucket additions.  The sliding table is chosen when it leaves a quarter of the device memory free at the moment the context
- * is built, or fits the byte budget DVP_MSM_TABLE_MAX_GB when that environment variable is set (DVP_MSM_SLIDE = 0 forces the
- * aligned windows); *sliding reports which one this is.  Results do not depend on the flavour. */
+/* HBM held by the context's precomputed table.  Default flavour: aligned windows of signed binary digits over W ~ 12 multiples
+ * 2^(o_w) P of every base (0.77 KB per base: 3.2 GB for the 4m bases of a 2^20-constraint prover).  DVP_MSM_SLIDE = 2 / 1 (environment,
+ * read once) asks for sliding windows over a multiple of the base for EVERY digit position instead -- the 233 integer multiples 2^j P
+ * (14.9 KB per base: 63 GB for the same bases) / the 240 Frobenius rotations tau^j P -- which measured no faster;
+ * DVP_MSM_TABLE_MAX_GB = <n> refuses a sliding table above n GB in favour of the default.  *sliding reports which one this is.
+ * Results do not depend on the flavour. */
 uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
