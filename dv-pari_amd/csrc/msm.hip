@@ -956,10 +956,14 @@ k_round_desc(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
 // B = ceil(total / (cap * R)) slots each: B is 25..48 in the big rounds and shrinks to 1..8 in the last ones, where a
 // round is pure latency and short threads are what is wanted.
 constexpr uint32_t AFF_BMAX = 48;  // default (Tune::msm_aff_bmax)
-__device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_t cap, uint32_t bmax) {
+// bmax_bmin: bits 0..7 = most slots per thread, bits 8..15 = fewest (a small round then runs on fewer threads, each sharing its
+// inversion among more additions: Tune::msm_aff_bmin)
+__device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_t cap, uint32_t bmax_bmin) {
+  const uint32_t bmax = bmax_bmin & 0xffu, bmin = (bmax_bmin >> 8) & 0xffu;
   const uint32_t units = (total + cap - 1) / cap;  // slots per resident thread if the round were one chip-full
   const uint32_t R = (units + bmax - 1) / bmax;
-  return R ? (units + R - 1) / R : 1;
+  const uint32_t B = R ? (units + R - 1) / R : 1;
+  return B < bmin ? bmin : B;
 }
 // FIRST only names the launch: k_affine_round<true> is the first pair round of an MSM (random gathers out of the
 // pre-rotated table -- the dominant kernel bench.py's roofline block is about), <false> the later rounds (coalesced
@@ -1592,7 +1596,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round<false>, EC_TPB, EC_LDS));
   if (blk_per_cu < 1) blk_per_cu = 1;
   const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
-  const uint32_t aff_bmax = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
+  const uint32_t aff_bmax_only = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
+  const uint32_t aff_bmin = tn.msm_aff_bmin >= 1 && (uint32_t)tn.msm_aff_bmin <= aff_bmax_only ? (uint32_t)tn.msm_aff_bmin : 1u;
+  const uint32_t aff_bmax = aff_bmax_only | (aff_bmin << 8);
   auto launch_round = [&](int r) -> int {
     int nxt = (cur + 1) % 3;
     const bool items_are_desc = r == 0;  // even-aligned buckets: the sorted item list is the descriptor array
@@ -1611,7 +1617,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     }
 #undef DVP_DESC_LAUNCH
     // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
-    const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax);
+    const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax_only);
     const uint32_t grid = r_max * (aff_cap / EC_TPB) + 1;
     const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
     {
