@@ -212,7 +212,9 @@ def _extender_group(ext_ranks, group):
 
     key = (id(group) if group is not None else 0, tuple(ext_ranks))
     if key not in _EXT_GROUPS:
-        _EXT_GROUPS[key] = dist.new_group(ranks=list(ext_ranks)) if len(ext_ranks) < dist.get_world_size(group) else group
+        # new_group takes GLOBAL ranks; ext_ranks are ranks of `group`
+        glob = [dist.get_global_rank(group, r) for r in ext_ranks] if group is not None else list(ext_ranks)
+        _EXT_GROUPS[key] = dist.new_group(ranks=glob) if len(ext_ranks) < dist.get_world_size(group) else group
     return _EXT_GROUPS[key]
 
 
