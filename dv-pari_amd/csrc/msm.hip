@@ -1269,11 +1269,13 @@ struct MsmWorkspace {
   // overtakes the first pair round that is already enqueued on the caller's stream
   hipStream_t aux = nullptr;
   hipEvent_t ev = nullptr;
+  hipEvent_t ev_heavy = nullptr;  // end of this workspace's last run of pair rounds (HeavyGate)
   uint32_t* pinned = nullptr;
   int ensure_aux() {
     if (aux) return DVP_OK;
     DVP_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
     DVP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    DVP_HIP(hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming));
     DVP_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
     return DVP_OK;
   }
@@ -1293,10 +1295,23 @@ struct MsmWorkspace {
     return DVP_OK;
   }
 };
-// one grow-only workspace PER DEVICE: MSMs on different GPUs (in-library multi-GPU: one host thread per device,
-// prove.hip) run concurrently, MSMs on the same GPU take turns
+// grow-only workspaces, MSM_WS_SLOTS PER DEVICE: MSMs on different GPUs (in-library multi-GPU: one host thread per device,
+// prove.hip) run concurrently, and so do up to MSM_WS_SLOTS MSMs on the SAME GPU (two provers on two host threads and two
+// streams: the latency-bound stretches of one proof -- merge levels, tail, small rounds, host round trips -- are filled by the
+// other's kernels); a further caller waits for slot 0.  The second slot allocates only when two calls do overlap.
 constexpr int MSM_MAX_DEVICES = 16;
-static MsmWorkspace g_ws_dev[MSM_MAX_DEVICES];
+constexpr int MSM_WS_SLOTS = 2;
+static MsmWorkspace g_ws_dev[MSM_MAX_DEVICES][MSM_WS_SLOTS];
+// Two MSMs on one device overlap everything EXCEPT their pair rounds: those fill the chip on their own (two of them side by side
+// only contend: measured 4 % slower than taking turns), while everything around them -- sort, reducer, merge levels, tail, the
+// prover's Fr stages and host round trips -- leaves lanes idle.  So the pair rounds of the second MSM wait ON THE GPU
+// (hipStreamWaitEvent, no host block beyond the enqueue) for the end of the first one's, which staggers two provers that
+// started in lockstep by themselves.
+struct HeavyGate {
+  std::mutex mu;
+  hipEvent_t last = nullptr;
+};
+static HeavyGate g_heavy[MSM_MAX_DEVICES];
 
 struct MsmPlan {
   uint32_t n;
@@ -1451,8 +1466,15 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   MsmPlan p = msm_plan(n, fx);
   const FxBits fb = fx ? fx->bits() : FxBits{0, 0};
   const uint32_t FX_NP = fb.np();
-  MsmWorkspace& g_ws = g_ws_dev[cur_dev];
-  std::lock_guard<std::mutex> g(g_ws.mu);
+  std::unique_lock<std::mutex> g;
+  int ws_slot = 0;
+  const int ws_slots = tune().msm_ws_slots >= 1 && tune().msm_ws_slots <= MSM_WS_SLOTS ? (int)tune().msm_ws_slots : 1;
+  for (int sl = 0; sl < ws_slots && !g.owns_lock(); ++sl) {
+    g = std::unique_lock<std::mutex>(g_ws_dev[cur_dev][sl].mu, std::try_to_lock);
+    if (g.owns_lock()) ws_slot = sl;
+  }
+  if (!g.owns_lock()) g = std::unique_lock<std::mutex>(g_ws_dev[cur_dev][0].mu);
+  MsmWorkspace& g_ws = g_ws_dev[cur_dev][ws_slot];
   // carve the workspace
   size_t o = 0;
   auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
@@ -1638,6 +1660,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   // holds >= 4 entries the first round is certain to be needed, so it is enqueued BEFORE the host waits for that number:
   // the round trip (and the launch ramp after it) hides behind ~5 ms of round 0 instead of idling the GPU mid-MSM.
   int launched = 0;
+  std::unique_lock<std::mutex> heavy;  // held from the first pair round's enqueue to the last one's (released on every return)
+  if (ws_slots > 1 && affine_mode) {
+    heavy = std::unique_lock<std::mutex>(g_heavy[cur_dev].mu);
+    if (g_heavy[cur_dev].last && g_heavy[cur_dev].last != g_ws.ev_heavy) DVP_HIP(hipStreamWaitEvent(st, g_heavy[cur_dev].last, 0));
+  }
   if (affine_mode && (e_est >> 1) >= aff_min && e_est >= 4 * (size_t)nk) {
     DVP_TRY(launch_round(0));
     launched = 1;
@@ -1649,6 +1676,13 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     while (((uint64_t)1 << ra) < max_cnt && (e_est >> (ra + 1)) >= aff_min) ++ra;
   if (ra < launched) ra = launched;  // a first round over single-entry buckets only passes them through
   for (int r = launched; r < ra; ++r) DVP_TRY(launch_round(r));
+  if (heavy.owns_lock()) {
+    if (ra > 0) {
+      DVP_HIP(hipEventRecord(g_ws.ev_heavy, st));
+      g_heavy[cur_dev].last = g_ws.ev_heavy;
+    }
+    heavy.unlock();
+  }
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
   if (rem_max <= 1) {
     if (ra == 0)

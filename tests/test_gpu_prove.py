@@ -15,7 +15,7 @@ import pytest
 
 import pyref as o
 import c_oracle as co
-from util import to_limbs, from_limbs
+from util import to_limbs, from_limbs, np_to_pt
 
 pytestmark = pytest.mark.gpu
 VEC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
@@ -448,3 +448,53 @@ def test_points_sum_records(dvp):
     d2 = torch.from_numpy(rec[[2, 3]].copy().view(np.int64)).to(dev)
     dvp.check(dvp.lib.dvp_points_sum_dev(d2.data_ptr(), 2, out.data_ptr(), out.data_ptr() + 64, st))
     assert int(out.cpu().numpy().view(np.uint64)[8]) & 0xFFFFFFFF == 1
+
+
+@pytest.mark.parametrize("slots", [2, 1])
+def test_two_provers_in_flight_same_bytes(dvp, slots):
+    """two and three provers on their own host threads and streams of ONE GPU (msm.hip: two MSM workspaces per device, the pair
+    rounds of concurrent MSMs chained on the GPU by events -- HeavyGate; slots = 1: MSMs take turns): every proof of
+    every thread equals the bytes a prover computes alone, for two circuit sizes at once (different plans, different
+    workspace sizes, so a buffer shared by mistake would show) and with a stand-alone one-shot MSM running beside them"""
+    import threading
+
+    import torch
+
+    rnd = random.Random(4040)
+    jobs = []
+    for log_m in (13, 15, 13):
+        inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
+        td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+        pv = dvp.proving.Prover(inst)
+        pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+        w = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).cuda()
+        jobs.append((pv, w, pv.prove_dev(w.data_ptr(), 0), torch.cuda.Stream()))
+    # a one-shot MSM on a fourth thread: it takes whichever workspace is free (or waits for one)
+    n = 5000
+    k, s = to_limbs([rnd.randrange(o.P) for _ in range(n)]), to_limbs([rnd.randrange(o.P) for _ in range(n)])
+    bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
+    exp_msm = co.k233_mulgen(sum(a * b for a, b in zip(from_limbs(k), from_limbs(s))) % o.P)
+    bad = []
+
+    def prove_loop(i):
+        pv, w, ref, st = jobs[i]
+        for _ in range(6):
+            if pv.prove_dev(w.data_ptr(), st.cuda_stream) != ref:
+                bad.append(("proof", i))
+
+    def msm_loop():
+        for _ in range(6):
+            xy, is_inf = dvp.curve.multi_scalar_mul(s, bases)
+            if np_to_pt(xy, is_inf) != exp_msm:
+                bad.append(("msm",))
+
+    with dvp.tune(DVP_MSM_WS_SLOTS=slots, DVP_MSM_FIXED_MIN=1, DVP_MSM_AFF_MIN=256):
+        th = [threading.Thread(target=prove_loop, args=(i,)) for i in range(3)] + [threading.Thread(target=msm_loop)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+    torch.cuda.synchronize()
+    assert not bad, bad
+    for pv, *_ in jobs:
+        pv.close()
