@@ -10,7 +10,12 @@ bench.py -- DV-Pari prover hot path on MI355X.
 
 One "step" = one full Proof::prove (src/proving.rs:426-688) of a synthetic dense R1CS with 2^20 constraints (BASELINE
 config #4, the configuration the metric "R1CS constraints/sec (prove) at 2^20" is quoted on), witness already resident
-in HBM.  With N > 1 the two MSMs of the proof are sharded by index range over the ranks and combined by all-gather +
+in HBM.  On one GPU the K steps are timed twice: one proof at a time (`value_one_at_a_time`, `ms_per_step_one_at_a_time`;
+the stage breakdown and the roofline block describe this loop) and with `--in-flight` (default 2) proofs on the GPU at a
+time -- that many provers, each on its own host thread and stream -- which is `value` / `ms_per_step`: the metric is a
+throughput and a proof alone leaves the chip partly idle for ~3 of its ~23.5 ms.  Every step of both loops is a complete
+proof, byte-compared with the first one.  --in-flight 1 makes the one-at-a-time loop the headline (the profiled runs
+under profiles/ use it, so that per-kernel averages are those of undisturbed launches).  With N > 1 the two MSMs of the proof are sharded by index range over the ranks and combined by all-gather +
 local add (strong scaling: the proof size is fixed); the line then also carries what ran (`rccl_ranks`, `backend`, every
 rank's own ms per step) and, beside it, the in-library figure for the same device count (`ms_per_step_inproc`,
 dvp_set_devices: one process, one host thread per device, peer copies -- measured by a child process after the ranks
@@ -152,6 +157,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs after the timed loop (microbenchmarks, stand-alone MSMs, second table flavour)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inproc", action="store_true", help="one process, in-library multi-GPU over devices 0..gpus-1 (dvp_set_devices)")
+    ap.add_argument("--in-flight", type=int, default=2, help="proofs in flight on the GPU in the timed loop that gives `value` (single-GPU runs only): "
+                    "that many provers, each on its own host thread and stream, share the K steps; 1 = one proof at a time (that loop is "
+                    "always run as well: ms_per_step_one_at_a_time, stages, roofline)")
     args = ap.parse_args()
 
     if args.gpus > 1 and not args.inproc and "WORLD_SIZE" not in os.environ:
@@ -283,6 +291,50 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = m * args.steps / elapsed
     single = world == 1 and n_dev_inproc == 1
+    seq_ms, seq_value = ms_per_step, value  # one proof at a time: what stages_ms_per_step and the roofline block describe
+    n_in_flight = 1
+    if single and args.in_flight > 1 and args.steps >= args.in_flight:
+        # The headline loop: the same K steps with `--in-flight` proofs on the GPU at a time -- that many provers (own tables, own
+        # stream, own host thread) over the same circuit and witness.  A proof alone leaves the chip partly idle for ~3 ms of its
+        # ~23.5 (merge levels, the single-workgroup tail, late pair rounds, host round trips); a second one in flight fills them
+        # (msm.hip: two MSM workspaces per device, HeavyGate).  Every proof is compared with the one-at-a-time bytes.
+        import threading
+        n_in_flight = args.in_flight
+        provers = [pv]
+        for _ in range(n_in_flight - 1):
+            q = dvp.proving.Prover(inst)
+            q.set_srs(srs)
+            provers.append(q)
+        tstreams = [torch.cuda.Stream() for _ in provers]
+        bad = []
+
+        def _loop(i, k):
+            for _ in range(k):
+                if provers[i].prove_dev(assignment.data_ptr(), tstreams[i].cuda_stream) != proof:
+                    bad.append(i)
+
+        def _run(counts):
+            th = [threading.Thread(target=_loop, args=(i, k)) for i, k in enumerate(counts)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+        _run([max(2, args.warmup)] * n_in_flight)  # concurrent warm-up: the second MSM workspace is allocated on first overlap
+        counts = [args.steps // n_in_flight + (1 if i < args.steps % n_in_flight else 0) for i in range(n_in_flight)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _run(counts)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        assert not bad, "a proof computed with several in flight differs from the one-at-a-time bytes"
+        ms_per_step = elapsed / args.steps * 1e3
+        value = m * args.steps / elapsed
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        hbm_resident_gb = (total_b - free_b) / 1e9
+        for q in provers[1:]:
+            q.close()
+        del provers, tstreams
     extras = single and not args.no_extras
 
     # ---- outside the timed region ---------------------------------------------------------------------------------------
@@ -341,6 +393,8 @@ def main():
         # circuit; the library lets the two MSMs overlap everything but their pair rounds (msm.hip: HeavyGate).  Every proof is
         # compared with the timed loop's bytes.  Not the headline: `value` stays one proof at a time.
         try:
+            if n_in_flight > 1:
+                raise StopIteration  # already the headline loop
             import threading
             pv_b = dvp.proving.Prover(inst)
             pv_b.set_srs(srs)
@@ -369,6 +423,8 @@ def main():
                          "note": "two provers on two host threads and two streams of this GPU, started together; aggregate over both; "
                                  "each proof's own latency is about twice ms_per_proof"}
             pv_b.close()
+        except StopIteration:
+            in_flight = None
         except Exception as e:  # an extra: report, do not lose the line
             in_flight = {"error": repr(e)}
 
@@ -489,6 +545,14 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "in_flight": n_in_flight,
+        "value_one_at_a_time": seq_value,
+        "ms_per_step_one_at_a_time": seq_ms,
+        "in_flight_note": ("`value` / `ms_per_step`: the K steps run with `in_flight` proofs on the GPU at a time (that many provers, own host thread "
+                           "and stream each, every proof compared with the one-at-a-time bytes): sustained throughput; a proof's own latency is "
+                           "then about in_flight x ms_per_step.  `*_one_at_a_time`: the same K steps one after the other (the loop timed first; "
+                           "stages_ms_per_step, roofline and the profiles describe that loop).  --in-flight 1 makes it the headline."
+                           if n_in_flight > 1 else "one proof at a time"),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -507,10 +571,11 @@ def main():
             "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "sliding": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
                             "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "sliding": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
             "witness": "resident in HBM",
+            "proofs_in_flight": n_in_flight,
         },
         "hbm_resident_gb": hbm_resident_gb,
-        "hbm_resident_note": "device memory in use on this rank's GPU after the timed loop (tables, bases, workspaces, trees, the torch context)",
-        "ms_per_step_aligned_tables": aligned_ms if aligned_ms is not None else (None if (tables[0][1] or tables[1][1]) else ms_per_step),
+        "hbm_resident_note": "device memory in use on this rank's GPU after the timed loops (every prover in flight: tables, bases, MSM workspaces, trees; the torch context)",
+        "ms_per_step_aligned_tables": aligned_ms if aligned_ms is not None else (None if (tables[0][1] or tables[1][1]) else seq_ms),
         "aligned_tables_gb": aligned_gb if aligned_gb is not None else (None if (tables[0][1] or tables[1][1]) else round((tables[0][0] + tables[1][0]) / 1e9, 2)),
         "ms_per_step_sliding_tables": sliding_ms,
         "sliding_tables_gb": sliding_gb,

@@ -11,18 +11,18 @@ cd $ROOT
 timeout -k 10 600 python3 bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "pmc fetch done"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write done"
-timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o q --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o q --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --in-flight 1 > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
 echo "pmc sq done"
 # request-level view of the same launches (resolves FETCH_SIZE's request-size ambiguity): read requests of the L2's memory side, how many
 # of them are 32-byte ones, and the L2 hit / miss split.  Counter names differ between ROCm builds: the list is saved first.
-timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace -d $OUT/pmc_tcc -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err || echo "pmc tcc pass failed (see pmc_tcc.err)"
-timeout -k 10 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum --kernel-trace -d $OUT/pmc_tcc2 -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_tcc2.json 2> $OUT/pmc_tcc2.err || echo "pmc tcc2 pass failed (see pmc_tcc2.err)"
+timeout -k 10 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace -d $OUT/pmc_tcc -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err || echo "pmc tcc pass failed (see pmc_tcc.err)"
+timeout -k 10 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum --kernel-trace -d $OUT/pmc_tcc2 -o t --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_tcc2.json 2> $OUT/pmc_tcc2.err || echo "pmc tcc2 pass failed (see pmc_tcc2.err)"
 echo "pmc tcc done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 20 22 > $OUT/msm_bench.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm16 -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 > $OUT/msm16_bench.log 2>&1
