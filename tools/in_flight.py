@@ -23,7 +23,7 @@ for pv, st in zip(provers, streams):
     assert pv.prove_dev(w.data_ptr(), st.cuda_stream) == ref
 torch.cuda.synchronize()
 import itertools
-for slots, P in itertools.product((1, 2), Ps):
+for slots, P in itertools.product([int(x) for x in os.environ.get("SLOTS", "1,2").split(",")], Ps):
     dvp.lib.dvp_tune_set(b"DVP_MSM_WS_SLOTS", slots)
     bad = []
     def loop(i):
