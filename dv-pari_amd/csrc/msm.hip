@@ -24,6 +24,7 @@
 // gfx950 has no carry-less multiplier -- see gf233.cuh).
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -1279,7 +1280,13 @@ struct MsmWorkspace {
     DVP_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
     return DVP_OK;
   }
-  int ensure(size_t need) {
+  // `need` is raised to the largest size any workspace of this device was ever asked for: which of the two slots a call gets
+  // depends on timing, and a slot that had only seen the smaller MSM of a prover would otherwise be freed and re-allocated
+  // (a device-wide synchronisation plus a multi-GB hipMalloc) in the middle of a later proof
+  int ensure(size_t need, std::atomic<size_t>& dev_max) {
+    size_t seen = dev_max.load();
+    while (seen < need && !dev_max.compare_exchange_weak(seen, need)) {}
+    if (seen > need) need = seen;
     int dev;
     DVP_HIP(hipGetDevice(&dev));
     if (p && (dev != device || bytes < need)) {
@@ -1302,6 +1309,7 @@ struct MsmWorkspace {
 constexpr int MSM_MAX_DEVICES = 16;
 constexpr int MSM_WS_SLOTS = 2;
 static MsmWorkspace g_ws_dev[MSM_MAX_DEVICES][MSM_WS_SLOTS];
+static std::atomic<size_t> g_ws_need[MSM_MAX_DEVICES];
 // Two MSMs on one device overlap everything EXCEPT their pair rounds: those fill the chip on their own (two of them side by side
 // only contend: measured 4 % slower than taking turns), while everything around them -- sort, reducer, merge levels, tail, the
 // prover's Fr stages and host round trips -- leaves lanes idle.  So the pair rounds of the second MSM wait ON THE GPU
@@ -1509,7 +1517,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
-  DVP_TRY(g_ws.ensure(o));
+  DVP_TRY(g_ws.ensure(o, g_ws_need[cur_dev]));
   char* base = (char*)g_ws.p;
   auto* err = (unsigned long long*)(base + o_err);
   auto* digits = (uint16_t*)(base + o_digits);
