@@ -293,7 +293,8 @@ def main():
     single = world == 1 and n_dev_inproc == 1
     seq_ms, seq_value = ms_per_step, value  # one proof at a time: what stages_ms_per_step and the roofline block describe
     n_in_flight = 1
-    if single and args.in_flight > 1 and args.steps >= args.in_flight:
+    # (needs room for one more prover per extra proof in flight: tables, bases, vectors, a second MSM workspace)
+    if single and args.in_flight > 1 and args.steps >= args.in_flight and free_b > 1.15 * (args.in_flight - 1) * (total_b - free_b):
         # The headline loop: the same K steps with `--in-flight` proofs on the GPU at a time -- that many provers (own tables, own
         # stream, own host thread) over the same circuit and witness.  A proof alone leaves the chip partly idle for ~3 ms of its
         # ~23.5 (merge levels, the single-workgroup tail, late pair rounds, host round trips); a second one in flight fills them
