@@ -309,10 +309,15 @@ def main():
         tstreams = [torch.cuda.Stream() for _ in provers]
         bad = []
 
+        errs = []
+
         def _loop(i, k):
-            for _ in range(k):
-                if provers[i].prove_dev(assignment.data_ptr(), tstreams[i].cuda_stream) != proof:
-                    bad.append(i)
+            try:
+                for _ in range(k):
+                    if provers[i].prove_dev(assignment.data_ptr(), tstreams[i].cuda_stream) != proof:
+                        bad.append(i)
+            except Exception as e:  # an exception in a thread would otherwise vanish and leave a short, wrong timing
+                errs.append(repr(e))
 
         def _run(counts):
             th = [threading.Thread(target=_loop, args=(i, k)) for i, k in enumerate(counts)]
@@ -320,6 +325,8 @@ def main():
                 t.start()
             for t in th:
                 t.join()
+            if errs:
+                raise RuntimeError("in-flight loop: " + "; ".join(errs))
 
         _run([max(2, args.warmup)] * n_in_flight)  # concurrent warm-up: the second MSM workspace is allocated on first overlap
         counts = [args.steps // n_in_flight + (1 if i < args.steps % n_in_flight else 0) for i in range(n_in_flight)]
