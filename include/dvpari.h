@@ -124,7 +124,7 @@ int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out_xy, void* 
 int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void* d_bases_inf, size_t n,
                        void* d_out_xy /*8 x u64*/, void* d_out_inf /*u32*/, void* stream);
 /* Fixed-base flavour of the same seam: the reference calls multi_scalar_mul with the SAME bases (the SRS
- * vectors g_m, g_q, g_k_*) in every proof, so the bases can be pre-rotated by powers of the Frobenius once
+ * vectors g_m, g_q, g_k_*) in every proof, so a multiple 2^(o_w) P of every base is computed once for every window w
  * (W x the storage) and all windows then share one bucket set.  range_hint = bases a typical call covers
  * (the per-GPU shard; 0 = n).  run: sum over i in [lo, hi) of scalars[i - lo] * base[i]. */
 typedef struct dvp_msm_ctx dvp_msm_ctx;
