@@ -1626,7 +1626,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round<false>, EC_TPB, EC_LDS));
   if (blk_per_cu < 1) blk_per_cu = 1;
   const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
-  const uint32_t aff_bmax_only = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 64 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
+  const uint32_t aff_bmax_only = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 255 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
   const uint32_t aff_bmin = tn.msm_aff_bmin >= 1 && (uint32_t)tn.msm_aff_bmin <= aff_bmax_only ? (uint32_t)tn.msm_aff_bmin : 1u;
   const uint32_t aff_bmax = aff_bmax_only | (aff_bmin << 8);
   auto launch_round = [&](int r) -> int {
