@@ -1623,9 +1623,13 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   // resident threads of k_affine_round on this device (3 blocks of 256 per CU on MI355X: 196 608)
   int n_cu = 256, blk_per_cu = 3;
   DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, cur_dev));
-  DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round<false>, EC_TPB, EC_LDS));
+  // workgroup size of the pair rounds (Tune::msm_aff_tpb): the kernel has no block-level synchronisation (LDS tables are per wave),
+  // so smaller workgroups only change how soon a finished wave's slot is handed to the next workgroup
+  const uint32_t aff_tpb = (tn.msm_aff_tpb == 64 || tn.msm_aff_tpb == 128 || tn.msm_aff_tpb == 256) ? (uint32_t)tn.msm_aff_tpb : (uint32_t)EC_TPB;
+  const uint32_t aff_lds = (aff_tpb / 64) * GF_LDSK_BYTES_PER_WAVE;
+  DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round<false>, (int)aff_tpb, aff_lds));
   if (blk_per_cu < 1) blk_per_cu = 1;
-  const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * EC_TPB;
+  const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * aff_tpb;
   const uint32_t aff_bmax_only = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 255 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
   const uint32_t aff_bmin = tn.msm_aff_bmin >= 1 && (uint32_t)tn.msm_aff_bmin <= aff_bmax_only ? (uint32_t)tn.msm_aff_bmin : 1u;
   const uint32_t aff_bmax = aff_bmax_only | (aff_bmin << 8);
@@ -1648,15 +1652,15 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
 #undef DVP_DESC_LAUNCH
     // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
     const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax_only);
-    const uint32_t grid = r_max * (aff_cap / EC_TPB) + 1;
+    const uint32_t grid = r_max * (aff_cap / aff_tpb) + 1;
     const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
     {
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
       if (r == 0)
-        hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, items_are_desc ? (const uint2*)items : (const uint2*)gdesc, d_total,
+        hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, items_are_desc ? (const uint2*)items : (const uint2*)gdesc, d_total,
                            aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask);
       else
-        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(EC_TPB), EC_LDS, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0u);
+        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0u);
       ps0.stop();
     }
     pts_in = outp;
