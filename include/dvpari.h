@@ -270,8 +270,10 @@ int dvp_fftr_write(const char* path, uint32_t n_sections, const uint8_t* ids, co
 int dvp_prover_open_cache_dir(const char* cache_dir, uint32_t n_public, dvp_prover** out);
 /* Proof::prove(cache_dir, public_inputs, private_inputs) itself: opens cache_dir on first use and keeps the prover in
  * a process-wide table keyed by (cache_dir, n_public, current HIP device); dvp_cache_dir_release(NULL) drops every entry.
- * Thread safety: concurrent calls are allowed; proofs on the SAME entry are serialised (one prover = one set of device
- * buffers), a release during a prove takes effect when that prove returns.  Files that change on disk after the first
+ * Thread safety: concurrent calls are allowed; one prover = one set of device buffers, so an entry opens a SECOND prover
+ * from the same files the first time two calls on it overlap (two proofs in flight on the GPU; DVP_CACHE_REPLICAS=1 in the
+ * environment turns that off) and further callers wait for one of the two; a release during a prove takes effect when that
+ * prove returns.  Files that change on disk after the first
  * call are not re-read: release the entry first.  Only SRS files whose 30-byte encodings follow this library's codec
  * rule are supported until that rule is pinned against xs233 (tools/pin_xsk233.py). */
 int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,

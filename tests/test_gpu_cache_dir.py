@@ -179,6 +179,47 @@ def test_sparse_cache_dir_with_witness_file(dvp, tmp_path):
     pv.close()
 
 
+@pytest.mark.parametrize("replicas", [2, 1])
+def test_cache_dir_two_callers_at_once(dvp, tmp_path, replicas):
+    """Proof::prove(cache_dir, ..) from three host threads at once on ONE cache_dir (cache.cpp: the second caller proves on
+    a second prover opened from the same files, a third waits; DVP_CACHE_REPLICAS = 1: all take turns on one prover):
+    every proof equals the bytes a single caller gets"""
+    import threading
+
+    A, g = dvp.artifacts, dvp.gnark_r1cs
+    inst0, pub, prv = g.synthetic_sparse(13)
+    cache = tmp_path / "twice"
+    cache.mkdir()
+    inst0.write_dump_file(cache / A.R1CS_CONSTRAINTS_FILE)
+    rnd = random.Random(55)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    inst, pv = dvp.srs.verifier_runs_setup_cache_dir(td, cache, len(pub), write_precomputes=False)
+    n_wires = struct.unpack("<Q", (cache / A.SRS_G_M).read_bytes()[:8])[0]
+    w = dvp.fr.vec([1] + pub + prv)
+    wpub, wprv = w[1:1 + len(pub)], w[1 + len(pub):n_wires]
+    with dvp.tune(DVP_CACHE_REPLICAS=replicas):
+        ref = dvp.proving.Proof.prove(cache, wpub, wprv)
+        assert dvp.srs.verify(td, pub, ref)
+        bad = []
+
+        def loop():
+            try:
+                for _ in range(5):
+                    if dvp.proving.Proof.prove(cache, wpub, wprv) != ref:
+                        bad.append("bytes")
+            except Exception as e:  # noqa: BLE001 -- report from the main thread
+                bad.append(repr(e))
+
+        th = [threading.Thread(target=loop) for _ in range(3)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad
+    dvp.proving.release_cache_dir()
+    pv.close()
+
+
 def test_cpp_host_over_the_c_abi(dvp, tmp_path):
     """examples/dvp_prove_cli.cpp -- a compiled host that sees only include/dvpari.h -- proves from a cache_dir written
     by the Python setup and prints the same 118 bytes as the Python host"""
