@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -212,7 +213,7 @@ std::string join(const char* dir, const char* name) {
 struct OpenEntry {
   dvp_prover* p = nullptr;
   std::mutex mu;
-  bool opened = false;  // the files have been read (under mu); rc then holds the result
+  std::atomic<bool> opened{false};  // the files have been read (under mu); rc then holds the result
   int rc = DVP_OK;
   // A second prover over the same files, opened the first time a proof arrives while the first prover is busy: two host
   // threads calling dvp_prove_cache_dir on one cache_dir then have two proofs in flight on the GPU (+11 % constraints/s at
@@ -247,11 +248,11 @@ int open_entry(const char* cache_dir, uint32_t n_public, std::shared_ptr<OpenEnt
     if (it == g_open.end()) it = g_open.emplace(key, std::make_shared<OpenEntry>()).first;
     e = it->second;
   }
-  {
+  if (!e->opened.load(std::memory_order_acquire)) {  // (an opened entry is not locked here: its mutex is held for whole proofs)
     std::lock_guard<std::mutex> ge(e->mu);
-    if (!e->opened) {
+    if (!e->opened.load(std::memory_order_relaxed)) {
       e->rc = dvp_prover_open_cache_dir(cache_dir, n_public, &e->p);
-      e->opened = true;
+      e->opened.store(true, std::memory_order_release);
     }
   }
   if (e->rc != DVP_OK) {

@@ -361,6 +361,9 @@ struct dvp_prover {
   Aff* bases_k = nullptr;      // [g_k0 | g_k1 | g_k2] 4m
   uint8_t* inf_k = nullptr;
   bool have_srs[5] = {false, false, false, false, false};
+  // stream of the host-pointer seam (dvp_prove / dvp_prove_cache_dir, which carry no stream argument): one per prover, so that
+  // two provers driven from two host threads overlap on the GPU instead of meeting on the default stream
+  hipStream_t own_stream = nullptr;
   // fixed-base MSM contexts over [g_m | g_q] and [g_k_0 | g_k_1 | g_k_2]: bases pre-rotated by tau^(20 w), built
   // lazily once the SRS is complete (12 x the base storage: 4.8 GB at m = 2^20 -- HBM is not the scarce resource)
   MsmFixedCtx* fx[2] = {nullptr, nullptr};
@@ -490,6 +493,7 @@ extern "C" void dvp_prover_destroy(dvp_prover* p) {
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   if (p->fin_host) (void)hipHostFree(p->fin_host);
+  if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
   for (auto& mt : p->mat) {
     if (mt.row_ptr) (void)hipFree(mt.row_ptr);
     if (mt.wire) (void)hipFree(mt.wire);
@@ -1109,11 +1113,13 @@ extern "C" int dvp_prove(dvp_prover* p, const uint64_t* public_inputs, uint32_t 
   if ((n_public && !public_inputs) || (n_private && !private_inputs)) return DVP_EINVAL;
   if (!prover_ready(p)) return DVP_EINVAL;
   // assignment = [1, public, private]  (src/proving.rs:449-452)
+  if (!p->own_stream) DVP_HIP(hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking));
   Fr one = fr_one_canon();
-  DVP_HIP(hipMemcpy(p->w, &one, sizeof(Fr), hipMemcpyHostToDevice));
-  if (n_public) DVP_HIP(hipMemcpy(p->w + 1, public_inputs, (size_t)n_public * 32, hipMemcpyHostToDevice));
-  if (n_private) DVP_HIP(hipMemcpy(p->w + 1 + n_public, private_inputs, (size_t)n_private * 32, hipMemcpyHostToDevice));
-  return dvp_prove_dev(p, p->w, proof, nullptr);
+  DVP_HIP(hipMemcpyAsync(p->w, &one, sizeof(Fr), hipMemcpyHostToDevice, p->own_stream));
+  if (n_public) DVP_HIP(hipMemcpyAsync(p->w + 1, public_inputs, (size_t)n_public * 32, hipMemcpyHostToDevice, p->own_stream));
+  if (n_private) DVP_HIP(hipMemcpyAsync(p->w + 1 + n_public, private_inputs, (size_t)n_private * 32, hipMemcpyHostToDevice, p->own_stream));
+  DVP_HIP(hipStreamSynchronize(p->own_stream));  // `one` lives on this stack frame, and the caller's buffers are free again on return anyway
+  return dvp_prove_dev(p, p->w, proof, p->own_stream);
 }
 
 // Parity-test access to the intermediates of the last dvp_prove call.  name in:

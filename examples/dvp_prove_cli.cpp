@@ -14,13 +14,18 @@
 // build:  g++ -O2 -std=c++17 -Iinclude examples/dvp_prove_cli.cpp -Ldv-pari_amd -ldvpari_hip -Wl,-rpath,$PWD/dv-pari_amd -o dvp_prove_cli
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dvpari.h"
 
 int main(int argc, char** argv) {
   std::vector<int> devices;
+  int repeat = 0, threads = 1;  // --repeat N --threads T: N more proofs through dvp_prove_cache_dir from T host threads
   std::vector<char*> pos;
   for (int i = 1; i < argc; ++i) {
     if (std::string(argv[i]) == "--devices" && i + 1 < argc) {
@@ -34,12 +39,21 @@ int main(int argc, char** argv) {
         devices.push_back((int)id);
         tok = *end == ',' ? end + 1 : end;
       }
+    } else if ((std::string(argv[i]) == "--repeat" || std::string(argv[i]) == "--threads") && i + 1 < argc) {
+      const bool rep = std::string(argv[i]) == "--repeat";
+      char* end = nullptr;
+      const long v = strtol(argv[++i], &end, 10);
+      if (end == argv[i] || *end != 0 || v < 1 || v > 1000000) {
+        fprintf(stderr, "%s: expected a positive number, got '%s'\n", rep ? "--repeat" : "--threads", argv[i]);
+        return 2;
+      }
+      (rep ? repeat : threads) = (int)v;
     } else {
       pos.push_back(argv[i]);
     }
   }
   if (pos.size() < 2) {
-    fprintf(stderr, "usage: %s <cache_dir> <n_public> [<proof_out>] [--devices 0,1,..]\n", argv[0]);
+    fprintf(stderr, "usage: %s <cache_dir> <n_public> [<proof_out>] [--devices 0,1,..] [--repeat N --threads T]\n", argv[0]);
     return 2;
   }
   argc = (int)pos.size() + 1;
@@ -99,6 +113,46 @@ int main(int argc, char** argv) {
   }
   for (int i = 0; i < 118; ++i) printf("%02x", proof[i]);
   printf("\n");
+  if (repeat > 0) {
+    // Throughput through the reference's own signature (Proof::prove(cache_dir, public, private) = dvp_prove_cache_dir): `threads`
+    // host threads share `repeat` proofs; with two or more, the library keeps two proofs in flight on the GPU.  Every proof must
+    // equal the first one.
+    const uint64_t* pub = w.data() + 4;
+    const uint64_t* prv = w.data() + 4 * (1 + (size_t)n_public);
+    const uint32_t n_prv = (uint32_t)(n_wires - 1 - n_public);
+    uint8_t warm[118];
+    for (int t = 0; t < 2; ++t) {  // opens the cache_dir entry (and, below, its second prover) outside the timed part
+      rc = dvp_prove_cache_dir(dir.c_str(), pub, n_public, prv, n_prv, warm);
+      if (rc != DVP_OK || memcmp(warm, proof, 118)) {
+        fprintf(stderr, "dvp_prove_cache_dir: %s\n", rc ? dvp_strerror(rc) : "bytes differ from dvp_prove");
+        return 1;
+      }
+    }
+    std::atomic<int> next(0), bad(0);
+    auto worker = [&](int limit) {
+      uint8_t out[118];
+      while (next.fetch_add(1) < limit) {
+        const int r = dvp_prove_cache_dir(dir.c_str(), pub, n_public, prv, n_prv, out);
+        if (r != DVP_OK || memcmp(out, proof, 118)) bad.fetch_add(1);
+      }
+    };
+    auto run = [&](int limit) {
+      next = 0;
+      std::vector<std::thread> th;
+      for (int t = 0; t < threads; ++t) th.emplace_back(worker, limit);
+      for (auto& t : th) t.join();
+    };
+    run(2 * threads);  // concurrent warm-up: the second prover of the entry is opened when two calls first overlap
+    const auto t0 = std::chrono::steady_clock::now();
+    run(repeat);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (bad.load()) {
+      fprintf(stderr, "%d of the repeated proofs failed or differ\n", bad.load());
+      return 1;
+    }
+    fprintf(stderr, "%d proofs from %d host thread(s): %.2f ms per proof (witness in host memory, dvp_prove_cache_dir)\n", repeat, threads, ms / repeat);
+    dvp_cache_dir_release(nullptr);
+  }
   if (argc > 3) {
     FILE* f = fopen(argv[3], "wb");
     if (!f || fwrite(proof, 1, 118, f) != 118) {

@@ -233,7 +233,7 @@ def test_cpp_host_over_the_c_abi(dvp, tmp_path):
     exe = tmp_path / "dvp_prove_cli"
     libdir = os.path.join(root, "dv-pari_amd")
     subprocess.check_call([gxx, "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "dvp_prove_cli.cpp"),
-                           "-L" + libdir, "-ldvpari_hip", "-Wl,-rpath," + libdir, "-o", str(exe)])
+                           "-L" + libdir, "-ldvpari_hip", "-Wl,-rpath," + libdir, "-pthread", "-o", str(exe)])
     A, g = dvp.artifacts, dvp.gnark_r1cs
     inst0, pub, prv = g.synthetic_sparse(10)
     cache = tmp_path / "cache"
@@ -255,6 +255,10 @@ def test_cpp_host_over_the_c_abi(dvp, tmp_path):
     out = subprocess.run([str(exe), str(cache), str(len(pub)), "--devices", "0,0,0,0"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr
     assert bytes.fromhex(out.stdout.strip()) == ref.to_bytes()
+    # the reference's own signature from two host threads of the compiled host: 12 more proofs, all the same bytes
+    out = subprocess.run([str(exe), str(cache), str(len(pub)), "--repeat", "12", "--threads", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert bytes.fromhex(out.stdout.strip()) == ref.to_bytes() and "12 proofs from 2 host thread(s)" in out.stderr
     # a different public-input count is a different statement (Vandermonde fold, transcript): other bytes
     out = subprocess.run([str(exe), str(cache), "0"], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and bytes.fromhex(out.stdout.strip()) != ref.to_bytes()
