@@ -450,12 +450,14 @@ def test_points_sum_records(dvp):
     assert int(out.cpu().numpy().view(np.uint64)[8]) & 0xFFFFFFFF == 1
 
 
-@pytest.mark.parametrize("slots", [2, 1])
-def test_two_provers_in_flight_same_bytes(dvp, slots):
+@pytest.mark.parametrize("slots,devices", [(2, []), (1, []), (2, [0, 0])])
+def test_two_provers_in_flight_same_bytes(dvp, slots, devices):
     """two and three provers on their own host threads and streams of ONE GPU (msm.hip: two MSM workspaces per device, the pair
     rounds of concurrent MSMs chained on the GPU by events -- HeavyGate; slots = 1: MSMs take turns): every proof of
     every thread equals the bytes a prover computes alone, for two circuit sizes at once (different plans, different
-    workspace sizes, so a buffer shared by mistake would show) and with a stand-alone one-shot MSM running beside them"""
+    workspace sizes, so a buffer shared by mistake would show) and with a stand-alone one-shot MSM running beside them.
+    devices = [0, 0]: every prover additionally shards its MSMs over two in-library device entries (one host thread each), so
+    up to six MSM shards contend for the two workspaces of device 0"""
     import threading
 
     import torch
@@ -489,11 +491,15 @@ def test_two_provers_in_flight_same_bytes(dvp, slots):
                 bad.append(("msm",))
 
     with dvp.tune(DVP_MSM_WS_SLOTS=slots, DVP_MSM_FIXED_MIN=1, DVP_MSM_AFF_MIN=256):
-        th = [threading.Thread(target=prove_loop, args=(i,)) for i in range(3)] + [threading.Thread(target=msm_loop)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
+        dvp.set_devices(devices)
+        try:
+            th = [threading.Thread(target=prove_loop, args=(i,)) for i in range(3)] + [threading.Thread(target=msm_loop)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        finally:
+            dvp.set_devices([])
     torch.cuda.synchronize()
     assert not bad, bad
     for pv, *_ in jobs:

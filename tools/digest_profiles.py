@@ -29,6 +29,11 @@ def last_json_line(path):
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench_prove2p20.json"))
 shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_prove2p20_under_rocprof.json"))
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))
+try:
+    shutil.copy(one("stats_default/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_prove2p20_default_cmd_kernel_stats.csv"))
+    shutil.copy(os.path.join(SRC, "bench_default_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_prove2p20_default_cmd_under_rocprof.json"))
+except Exception as e:  # older refresh runs have no such pass
+    print("no default-command stats pass:", e)
 shutil.copy(one("msm/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_msm_kernel_stats.csv"))
 shutil.copy(os.path.join(SRC, "msm_bench.log"), os.path.join(DST, f"{tag}_msm_bench.log"))
 try:

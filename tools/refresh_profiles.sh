@@ -13,6 +13,9 @@ echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
+# the default command (both timed loops: one proof at a time, then two in flight) under the same tracer: what the driver's bench run executes
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o d --output-format csv -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_default_under_rocprof.json 2> $OUT/stats_default.err
+echo "stats (default command) done"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 echo "pmc fetch done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
