@@ -72,6 +72,7 @@ struct Tune {
   long long msm_slide = -1;     // DVP_MSM_SLIDE: fixed-base table flavour: unset / 0 = aligned windows (W rows per base), 1 = tau-adic sliding windows (240 rows), 2 = binary sliding windows (233 rows)
   long long msm_proj = 0;       // DVP_MSM_MODE=proj: skip the batched-affine rounds
   long long msm_aff_min = 1ll << 19;   // DVP_MSM_AFF_MIN: pair rounds run while a round has this many additions
+  long long msm_gate_min = 1;   // DVP_MSM_GATE_MIN: pair rounds with at least this many additions take turns between concurrent MSMs (HeavyGate); smaller ones overlap
   long long msm_ws_slots = 2;   // DVP_MSM_WS_SLOTS: MSMs that may run at the same time on one device (1 or 2 workspaces; their pair rounds still take turns, HeavyGate)
   long long cache_replicas = 2;  // DVP_CACHE_REPLICAS: provers dvp_prove_cache_dir may hold per cache_dir (2: a second one is opened when two callers overlap)
   long long msm_aff_tpb = 256;  // DVP_MSM_AFF_TPB: workgroup size of the pair rounds (64, 128 or 256)

@@ -1687,14 +1687,25 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   if (affine_mode)
     while (((uint64_t)1 << ra) < max_cnt && (e_est >> (ra + 1)) >= aff_min) ++ra;
   if (ra < launched) ra = launched;  // a first round over single-entry buckets only passes them through
-  for (int r = launched; r < ra; ++r) DVP_TRY(launch_round(r));
-  if (heavy.owns_lock()) {
-    if (ra > 0) {
-      DVP_HIP(hipEventRecord(g_ws.ev_heavy, st));
-      g_heavy[cur_dev].last = g_ws.ev_heavy;
-    }
-    heavy.unlock();
+  // the gate's event goes after the last round that still fills the chip several times over (>= Tune::msm_gate_min additions):
+  // the late rounds are latency-bound and are exactly what the next MSM's first round should overlap
+  int r_evt = -1;
+  if (heavy.owns_lock() && ra > 0) {
+    const size_t gate_min = tn.msm_gate_min > 0 ? (size_t)tn.msm_gate_min : 1;
+    r_evt = 0;
+    while (r_evt + 1 < ra && (e_est >> (r_evt + 2)) >= gate_min) ++r_evt;
   }
+  auto gate_event = [&]() -> int {
+    DVP_HIP(hipEventRecord(g_ws.ev_heavy, st));
+    g_heavy[cur_dev].last = g_ws.ev_heavy;
+    return DVP_OK;
+  };
+  if (r_evt >= 0 && r_evt < launched) DVP_TRY(gate_event());
+  for (int r = launched; r < ra; ++r) {
+    DVP_TRY(launch_round(r));
+    if (r == r_evt) DVP_TRY(gate_event());
+  }
+  if (heavy.owns_lock()) heavy.unlock();
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds
   if (rem_max <= 1) {
     if (ra == 0)
