@@ -586,6 +586,9 @@ extern "C" int dvp_prover_set_srs_encoded(dvp_prover* p, int which, const uint8_
   DVP_TRY(decode_dev(de.as<uint8_t>(), n, base, inf, 0));
   p->have_srs[which] = true;
   srs_changed(p, which < 2 ? 0 : 1);
+  // the copies / fills above ran on the default stream; proofs run on other (non-blocking) streams, which do not order themselves
+  // behind it: nothing of this setter may still be in flight when it returns
+  DVP_HIP(hipStreamSynchronize(nullptr));
   return DVP_OK;
 }
 extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_t* xy, const uint8_t* inf_in, size_t n) {
@@ -598,6 +601,9 @@ extern "C" int dvp_prover_set_srs_affine(dvp_prover* p, int which, const uint64_
   else DVP_HIP(hipMemset(inf, 0, n));
   p->have_srs[which] = true;
   srs_changed(p, which < 2 ? 0 : 1);
+  // the copies / fills above ran on the default stream; proofs run on other (non-blocking) streams, which do not order themselves
+  // behind it: nothing of this setter may still be in flight when it returns
+  DVP_HIP(hipStreamSynchronize(nullptr));
   return DVP_OK;
 }
 // device-to-device flavour (bases produced on the GPU, e.g. by dvp_mulgen on the same device)
@@ -611,6 +617,9 @@ extern "C" int dvp_prover_set_srs_affine_dev(dvp_prover* p, int which, const voi
   else DVP_HIP(hipMemset(inf, 0, n));
   p->have_srs[which] = true;
   srs_changed(p, which < 2 ? 0 : 1);
+  // the copies / fills above ran on the default stream; proofs run on other (non-blocking) streams, which do not order themselves
+  // behind it: nothing of this setter may still be in flight when it returns
+  DVP_HIP(hipStreamSynchronize(nullptr));
   return DVP_OK;
 }
 
