@@ -490,10 +490,27 @@ def test_two_provers_in_flight_same_bytes(dvp, slots, devices):
             if np_to_pt(xy, is_inf) != exp_msm:
                 bad.append(("msm",))
 
+    # a fifth thread keeps failing: an unsatisfied witness on a prover of its own must come back as DVP_EUNSAT with ITS row
+    # index (the error index is thread-local) while the other threads' proofs stay right
+    inst_u, pub_u, prv_u = dvp.gnark_r1cs.synthetic_dense(12)
+    pv_u = dvp.proving.Prover(inst_u)
+    pv_u.set_srs(dvp.srs.verifier_runs_setup(pv_u, inst_u, dvp.srs.Trapdoor(5, 6, 7)))
+    prv_bad = list(prv_u)
+    prv_bad[-1] = (prv_bad[-1] + 1) % o.P
+
+    def unsat_loop():
+        for _ in range(6):
+            try:
+                pv_u.prove(pub_u, prv_bad)
+                bad.append(("unsat accepted",))
+            except dvp.DvpError as e:
+                if e.status != -3 or not (0 <= e.index < inst_u.n_rows):
+                    bad.append(("unsat", e.status, e.index))
+
     with dvp.tune(DVP_MSM_WS_SLOTS=slots, DVP_MSM_FIXED_MIN=1, DVP_MSM_AFF_MIN=256):
         dvp.set_devices(devices)
         try:
-            th = [threading.Thread(target=prove_loop, args=(i,)) for i in range(3)] + [threading.Thread(target=msm_loop)]
+            th = [threading.Thread(target=prove_loop, args=(i,)) for i in range(3)] + [threading.Thread(target=msm_loop), threading.Thread(target=unsat_loop)]
             for t in th:
                 t.start()
             for t in th:
@@ -504,3 +521,4 @@ def test_two_provers_in_flight_same_bytes(dvp, slots, devices):
     assert not bad, bad
     for pv, *_ in jobs:
         pv.close()
+    pv_u.close()
