@@ -41,6 +41,7 @@ _SIGS = {
     "dvp_debug_ecfft_matrices": (C.c_int, [vp, C.c_int, C.c_int, u64p]),
     "dvp_debug_ecfft_layer": (C.c_int, [vp, u32, u64p]),
     "dvp_ubench_gf_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "dvp_debug_wave_trace": (C.c_int, [vp, u32]),
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),
     "dvp_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -22,6 +22,7 @@
 //
 // All of it runs on the VALU (no MFMA: there is no dense contraction in this algorithm, and
 // gfx950 has no carry-less multiplier -- see gf233.cuh).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -956,6 +957,25 @@ k_round_desc(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
 // 12 waves per CU).  With `cap` = resident threads of the chip, R = ceil(total / (cap * AFF_BMAX)) chip-fulls of
 // B = ceil(total / (cap * R)) slots each: B is 25..48 in the big rounds and shrinks to 1..8 in the last ones, where a
 // round is pure latency and short threads are what is wanted.
+// Round 4 (tools/wave_trace.py, profiles/r04_wave_trace_*): the instruction arbiter of a SIMD serves its OLDEST wave first.  Of
+// three resident waves with identical work the first finished after 1.32 ms, the second after 1.55, the third after 1.93; every
+// later chip-full inherited the stagger and the end of each launch drained through SIMDs with two and then one wave left --
+// that, not gaps between workgroups (a freed slot was refilled in 10-15 us) nor the launch ramp, was the whole of the missing
+// resident-wave fraction (0.83-0.88).  Rotating the user priority with the slot index hands the issue slots round: the three
+// waves of a SIMD now finish within 2 % of each other, a one-chip-full round ends 10 % sooner (1.58 -> 1.41 ms).
+#ifndef AFF_PRIO
+#define AFF_PRIO 1
+#endif
+#ifndef AFF_XY
+#define AFF_XY 1
+#endif
+__device__ __forceinline__ void aff_set_prio(uint32_t v) {
+  switch (v % 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(2); break;
+  }
+}
 constexpr uint32_t AFF_BMAX = 48;  // default (Tune::msm_aff_bmax)
 // bmax_bmin: bits 0..7 = most slots per thread, bits 8..15 = fewest (a small round then runs on fewer threads, each sharing its
 // inversion among more additions: Tune::msm_aff_bmin)
@@ -969,12 +989,25 @@ __device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_
 // FIRST only names the launch: k_affine_round<true> is the first pair round of an MSM (random gathers out of the
 // pre-rotated table -- the dominant kernel bench.py's roofline block is about), <false> the later rounds (coalesced
 // inputs); the code is the same, the two symbols keep them apart in rocprofv3's per-kernel statistics.
-template <bool FIRST>
+// Wave-level trace of a pair round (diagnostics only: dvp_debug_wave_trace, tools/wave_trace.py).  TRACE instantiations stamp
+// s_memrealtime (100 MHz, constant) and s_memtime (shader clock) at the start of a wave, after its first pass, after the shared
+// inversion and at its end, with the hardware slot the wave ran in (HW_ID: wave, SIMD, CU, SH, SE; XCC_ID): one 64-byte record
+// per wave behind a 64-byte header whose first word is the record counter.  The production launches use TRACE = false.
+struct WaveTrace {
+  unsigned long long* buf;  // [0] = records written, records from word 8
+  uint32_t cap, tag;
+};
+template <bool FIRST, bool TRACE = false>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, const uint32_t* __restrict__ total_ptr /* ooff[nkeys] */,
-               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out, uint32_t sign_mask) {
+               uint32_t cap, uint32_t bmax, GfSqrTables T, Gf* __restrict__ prefix, Aff* __restrict__ out, uint32_t sign_mask, WaveTrace wt) {
   extern __shared__ char lds_raw[];
+  unsigned long long tr_t0 = 0, tr_c0 = 0, tr_t1 = 0, tr_t2 = 0;
+  if (TRACE) { tr_t0 = wall_clock64(); tr_c0 = clock64(); }
   GfLdsK L = gf_ldsk_init(lds_raw);
+#if AFF_PRIO
+  const uint32_t wslot = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4);  // HW_ID.wave_id: this wave's slot in its SIMD
+#endif
   // signed-digit flavours (first round only: the operands are table entries named by sorted items): bit 31 of an item says
   // "subtract"; -(x, y) = (x, x + y), applied as the y-coordinate is loaded
   const uint32_t sm = FIRST ? sign_mask : 0u;
@@ -1004,6 +1037,9 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
     if (d0.y != AFF_NONE) { xa = ldx(d0.x); xb = ldx(d0.y); }
 #pragma unroll 1
     for (int k = 0; k < B; ++k) {
+#if AFF_PRIO
+      aff_set_prio(wslot + (uint32_t)k);
+#endif
       const uint2 d2 = ld_desc(k + 2);
       Gf nxa = gf_zero(), nxb = gf_zero();
       if (d1.y != AFF_NONE) { nxa = ldx(d1.x); nxb = ldx(d1.y); }
@@ -1018,16 +1054,33 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
       d0 = d1; d1 = d2; xa = nxa; xb = nxb;
     }
   }
+  if (TRACE) tr_t1 = wall_clock64();
   Gf inv = gf_inv_fast(run, T, L);
+  if (TRACE) tr_t2 = wall_clock64();
   // pass 2 (backwards): recover each inverse and finish the addition
   {
     uint2 e0 = ld_desc(B - 1), e1 = ld_desc(B - 2);
     Gf px = gf_zero(), qx = gf_zero(), pre = one;
     if (e0.x != AFF_NONE) px = ldx(e0.x);
     if (e0.y != AFF_NONE) { qx = ldx(e0.y); pre = prefix[(size_t)(B - 1) * nthr + tid]; }
+#if AFF_XY
+    Gf py = gf_zero(), qy = gf_zero();
+    if (e0.x != AFF_NONE) py = ldy(e0.x, px);
+    if (e0.y != AFF_NONE) qy = ldy(e0.y, qx);
+#endif
 #pragma unroll 1
     for (int k = B - 1; k >= 0; --k) {
+#if AFF_PRIO
+      aff_set_prio(wslot + (uint32_t)k);
+#endif
       const uint2 e2 = ld_desc(k - 2);
+#if AFF_XY
+      // the next slot's WHOLE points and prefix product: x and y of a point share a 128-byte line, and a y fetched one slot
+      // after its x (the round-3 pipeline) found the line evicted from the L2 again: 6.3 line requests per addition, 4.3 now
+      Gf npx = gf_zero(), nqx = gf_zero(), npy = gf_zero(), nqy = gf_zero(), npre = one;
+      if (e1.x != AFF_NONE) { npx = ldx(e1.x); npy = ldy(e1.x, npx); }
+      if (e1.y != AFF_NONE) { nqx = ldx(e1.y); nqy = ldy(e1.y, nqx); npre = prefix[(size_t)(k - 1) * nthr + tid]; }
+#else
       // this slot's y-coordinates (needed after the two products of the inverse recovery) ...
       Gf py = gf_zero(), qy = gf_zero();
       if (e0.x != AFF_NONE) py = ldy(e0.x, px);
@@ -1036,6 +1089,7 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
       Gf npx = gf_zero(), nqx = gf_zero(), npre = one;
       if (e1.x != AFF_NONE) npx = ldx(e1.x);
       if (e1.y != AFF_NONE) { nqx = ldx(e1.y); npre = prefix[(size_t)(k - 1) * nthr + tid]; }
+#endif
       if (e0.x != AFF_NONE) {
         const uint32_t sidx = (uint32_t)k * nthr + tid;
         Gf ox = px, oy = py;  // odd leftover, or q == infinity: pass p through
@@ -1064,6 +1118,25 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
         out[sidx].x = ox; out[sidx].y = oy;
       }
       e0 = e1; e1 = e2; px = npx; qx = nqx; pre = npre;
+#if AFF_XY
+      py = npy; qy = nqy;
+#endif
+    }
+  }
+#if AFF_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  if (TRACE) {
+    const unsigned long long t3 = wall_clock64(), c3 = clock64();
+    if ((threadIdx.x & 63u) == 0) {
+      const unsigned long long i = atomicAdd(wt.buf, 1ull);
+      if (i < wt.cap) {
+        unsigned long long* r = wt.buf + 8 + 8 * i;
+        r[0] = tr_t0; r[1] = tr_t1; r[2] = tr_t2; r[3] = t3;
+        r[4] = tr_c0; r[5] = c3;
+        r[6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);  // HW_ID | XCC_ID
+        r[7] = (unsigned long long)blockIdx.x | ((unsigned long long)wt.tag << 32) | ((unsigned long long)(uint32_t)B << 48);
+      }
     }
   }
 }
@@ -1259,6 +1332,11 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 
   for (int r = 0; r < reps; ++r) { x = gf_mul(x, y, L); y.w[0] ^= x.w[3]; }
   out[t] = x;
 }
+
+// wave trace of the pair rounds (dvp_debug_wave_trace): device buffer, record capacity, launch tag (counts traced launches)
+static std::atomic<unsigned long long*> g_wave_trace{nullptr};
+static uint32_t g_wave_trace_cap = 0;
+static std::atomic<uint32_t> g_wave_trace_tag{0};
 
 // ---- workspace -----------------------------------------------------------------------------------
 struct MsmWorkspace {
@@ -1464,7 +1542,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
                           (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false>, (const void*)k_merge<true>,
-                          (const void*)k_affine_round<true>, (const void*)k_affine_round<false>, (const void*)k_sum_points, (const void*)k_tail};
+                          (const void*)k_affine_round<true, false>, (const void*)k_affine_round<false, false>, (const void*)k_affine_round<true, true>,
+                          (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
       DVP_HIP(attr_err);
@@ -1513,7 +1592,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const size_t affA_n = p.e_max / 2 + p.nkeys + 1, affB_n = p.e_max / 4 + p.nkeys + 1;
   size_t o_affA = carve(affine_mode ? affA_n * sizeof(Aff) : 16);
   size_t o_affB = carve(affine_mode ? affB_n * sizeof(Aff) : 16);
-  size_t o_prefix = carve(affine_mode ? (affA_n + 128) * sizeof(Gf) : 16);  // one prefix product per output slot
+  size_t o_prefix = carve(affine_mode ? (affA_n + 256) * sizeof(Gf) : 16);  // one prefix product per output slot (+ the B - 1 <= 254 slots the last thread's rows may overhang)
   size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
@@ -1627,12 +1706,13 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   // so smaller workgroups only change how soon a finished wave's slot is handed to the next workgroup
   const uint32_t aff_tpb = (tn.msm_aff_tpb == 64 || tn.msm_aff_tpb == 128 || tn.msm_aff_tpb == 256) ? (uint32_t)tn.msm_aff_tpb : (uint32_t)EC_TPB;
   const uint32_t aff_lds = (aff_tpb / 64) * GF_LDSK_BYTES_PER_WAVE;
-  DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round<false>, (int)aff_tpb, aff_lds));
+  DVP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk_per_cu, (const void*)k_affine_round<false, false>, (int)aff_tpb, aff_lds));
   if (blk_per_cu < 1) blk_per_cu = 1;
   const uint32_t aff_cap = (uint32_t)n_cu * (uint32_t)blk_per_cu * aff_tpb;
   const uint32_t aff_bmax_only = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 255 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
   const uint32_t aff_bmin = tn.msm_aff_bmin >= 1 && (uint32_t)tn.msm_aff_bmin <= aff_bmax_only ? (uint32_t)tn.msm_aff_bmin : 1u;
   const uint32_t aff_bmax = aff_bmax_only | (aff_bmin << 8);
+  const bool wt_on = g_wave_trace.load() != nullptr;
   auto launch_round = [&](int r) -> int {
     int nxt = (cur + 1) % 3;
     const bool items_are_desc = r == 0;  // even-aligned buckets: the sorted item list is the descriptor array
@@ -1656,11 +1736,16 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
     {
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
-      if (r == 0)
-        hipLaunchKernelGGL(k_affine_round<true>, dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, items_are_desc ? (const uint2*)items : (const uint2*)gdesc, d_total,
-                           aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask);
+      WaveTrace wt{g_wave_trace.load(), g_wave_trace_cap, g_wave_trace_tag.fetch_add(wt_on ? 1u : 0u)};
+      const uint2* dsc = items_are_desc ? (const uint2*)items : (const uint2*)gdesc;
+      if (r == 0 && wt.buf)
+        hipLaunchKernelGGL((k_affine_round<true, true>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask, wt);
+      else if (r == 0)
+        hipLaunchKernelGGL((k_affine_round<true, false>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask, wt);
+      else if (wt.buf)
+        hipLaunchKernelGGL((k_affine_round<false, true>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0u, wt);
       else
-        hipLaunchKernelGGL(k_affine_round<false>, dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, (const uint2*)gdesc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0u);
+        hipLaunchKernelGGL((k_affine_round<false, false>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, 0u, wt);
       ps0.stop();
     }
     pts_in = outp;
@@ -1938,6 +2023,15 @@ extern "C" int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out
 
 // GF(2^233) products per second of the hot kernels' multiplier alone (every CU busy, k_affine_round's occupancy): the
 // ceiling bench.py's work model divides by, measured in the same process instead of quoted
+// d_buf: device buffer of 64 + 64 * n_records bytes, zeroed by the caller (word 0 counts the records); NULL switches the trace off.
+// While set, every pair round runs its TRACE instantiation and appends one record per wave (layout: WaveTrace above).
+extern "C" int dvp_debug_wave_trace(void* d_buf, uint32_t n_records) {
+  g_wave_trace_cap = d_buf ? n_records : 0;
+  g_wave_trace_tag.store(0);
+  g_wave_trace.store((unsigned long long*)d_buf);
+  return DVP_OK;
+}
+
 extern "C" int dvp_ubench_gf_mul(int reps, double* products_per_s) {
   if (reps < 1 || !products_per_s) return DVP_EINVAL;
   int dev = 0, n_cu = 256;

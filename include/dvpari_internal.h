@@ -34,6 +34,11 @@ int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
 /* microbenchmark of the MSM kernels' GF(2^233) multiplier alone (products per second, whole chip, the pair rounds'
  * occupancy): the ceiling of bench.py's work model, measured in the same run */
 int dvp_ubench_gf_mul(int reps, double* products_per_s);
+/* Wave-level trace of the batched-affine pair rounds (dvp::k_affine_round, tools/wave_trace.py).  d_buf = device buffer of
+ * 64 + 64 * n_records bytes zeroed by the caller, NULL = off.  While set, every pair round appends one 64-byte record per
+ * wave (8 u64: s_memrealtime at wave start / after pass 1 / after the shared inversion / at the end; s_memtime at start / end;
+ * HW_ID | XCC_ID << 32; blockIdx | launch tag << 32 | slots per thread << 48); word 0 of the buffer counts them. */
+int dvp_debug_wave_trace(void* d_buf, uint32_t n_records);
 /* random 64-byte gathers per second (whole chip, two independent lines in flight per lane and step, as the first pair
  * round issues them) out of a device table of `table_bytes` bytes starting at d_table; d_table = NULL allocates a scratch
  * table of that size.  The ceiling of bench.py's gather model for dvp::k_affine_round<true>. */
