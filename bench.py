@@ -10,12 +10,11 @@ bench.py -- DV-Pari prover hot path on MI355X.
 
 One "step" = one full Proof::prove (src/proving.rs:426-688) of a synthetic dense R1CS with 2^20 constraints (BASELINE
 config #4, the configuration the metric "R1CS constraints/sec (prove) at 2^20" is quoted on), witness already resident
-in HBM.  On one GPU the K steps are timed twice: one proof at a time (`value_one_at_a_time`, `ms_per_step_one_at_a_time`;
-the stage breakdown and the roofline block describe this loop) and with `--in-flight` (default 2) proofs on the GPU at a
-time -- that many provers, each on its own host thread and stream -- which is `value` / `ms_per_step`: the metric is a
-throughput and a proof alone leaves the chip partly idle for ~3 of its ~23.5 ms.  Every step of both loops is a complete
-proof, byte-compared with the first one.  --in-flight 1 makes the one-at-a-time loop the headline (the profiled runs
-under profiles/ use it, so that per-kernel averages are those of undisturbed launches).  With N > 1 the two MSMs of the proof are sharded by index range over the ranks and combined by all-gather +
+in HBM.  The K steps run ONE PROOF AT A TIME and that is `value` / `ms_per_step` (= the latency of a proof): the quantity
+the reference's prove() defines, and the loop the stage breakdown, the roofline block and the committed profiles describe.
+After the timed loop, outside it, the same proof is also run with two provers in flight on the GPU (own host thread and
+stream each, every proof byte-compared): `throughput_two_in_flight` -- a proving service's sustained rate, never `value`
+(--in-flight 1 skips that leg).  With N > 1 the two MSMs of the proof are sharded by index range over the ranks and combined by all-gather +
 local add (strong scaling: the proof size is fixed); the line then also carries what ran (`rccl_ranks`, `backend`, every
 rank's own ms per step) and, beside it, the in-library figure for the same device count (`ms_per_step_inproc`,
 dvp_set_devices: one process, one host thread per device, peer copies -- measured by a child process after the ranks
@@ -46,7 +45,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
                  "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
                  "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE", "OMP_NUM_THREADS")
@@ -82,7 +81,7 @@ def cpu_mhz() -> float:
 
 
 def load_profile(name):
-    for tag in (PROFILE_TAG, "r02"):
+    for tag in (PROFILE_TAG, "r03"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json")))
             d["_profile_tag"] = tag
@@ -157,9 +156,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs after the timed loop (microbenchmarks, stand-alone MSMs, second table flavour)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--inproc", action="store_true", help="one process, in-library multi-GPU over devices 0..gpus-1 (dvp_set_devices)")
-    ap.add_argument("--in-flight", type=int, default=2, help="proofs in flight on the GPU in the timed loop that gives `value` (single-GPU runs only): "
-                    "that many provers, each on its own host thread and stream, share the K steps; 1 = one proof at a time (that loop is "
-                    "always run as well: ms_per_step_one_at_a_time, stages, roofline)")
+    ap.add_argument("--in-flight", type=int, default=2, help="2 (default): the extras leg after the timed loop also measures throughput with two proofs in flight "
+                    "(throughput_two_in_flight); 1 skips it.  `value` is always one proof at a time")
     args = ap.parse_args()
 
     if args.gpus > 1 and not args.inproc and "WORLD_SIZE" not in os.environ:
@@ -277,6 +275,7 @@ def main():
         torch.cuda.empty_cache()
         dist.barrier()
         dist.destroy_process_group()
+        dvp.distributed.forget_groups()
         if rank != 0:
             return
         if os.environ.get("DVP_BENCH_NO_INPROC") != "1":
@@ -291,65 +290,10 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = m * args.steps / elapsed
     single = world == 1 and n_dev_inproc == 1
-    seq_ms, seq_value = ms_per_step, value  # one proof at a time: what stages_ms_per_step and the roofline block describe
+    # `value` / `ms_per_step` are ONE PROOF AT A TIME: the quantity BASELINE's metric measures (the reference's prove() is one proof
+    # per call), and the loop that stages_ms_per_step, the roofline block and every committed profile describe.  Throughput with
+    # two proofs in flight is an extra, measured after the timed loop and reported under its own key (throughput_two_in_flight).
     n_in_flight = 1
-    in_flight_error = None
-    # (needs room for one more prover per extra proof in flight: tables, bases, vectors, a second MSM workspace)
-    if single and args.in_flight > 1 and args.steps >= args.in_flight and free_b > 1.15 * (args.in_flight - 1) * (total_b - free_b):
-        # The headline loop: the same K steps with `--in-flight` proofs on the GPU at a time -- that many provers (own tables, own
-        # stream, own host thread) over the same circuit and witness.  A proof alone leaves the chip partly idle for ~3 ms of its
-        # ~23.5 (merge levels, the single-workgroup tail, late pair rounds, host round trips); a second one in flight fills them
-        # (msm.hip: two MSM workspaces per device, HeavyGate).  Every proof is compared with the one-at-a-time bytes.
-        in_flight_error = None
-        try:
-            import threading
-            n_in_flight = args.in_flight
-            provers = [pv]
-            for _ in range(n_in_flight - 1):
-                q = dvp.proving.Prover(inst)
-                q.set_srs(srs)
-                provers.append(q)
-            tstreams = [torch.cuda.Stream() for _ in provers]
-            bad = []
-
-            errs = []
-
-            def _loop(i, k):
-                try:
-                    for _ in range(k):
-                        if provers[i].prove_dev(assignment.data_ptr(), tstreams[i].cuda_stream) != proof:
-                            bad.append(i)
-                except Exception as e:  # an exception in a thread would otherwise vanish and leave a short, wrong timing
-                    errs.append(repr(e))
-
-            def _run(counts):
-                th = [threading.Thread(target=_loop, args=(i, k)) for i, k in enumerate(counts)]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-                if errs:
-                    raise RuntimeError("in-flight loop: " + "; ".join(errs))
-
-            _run([max(2, args.warmup)] * n_in_flight)  # concurrent warm-up: the second MSM workspace is allocated on first overlap
-            counts = [args.steps // n_in_flight + (1 if i < args.steps % n_in_flight else 0) for i in range(n_in_flight)]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            _run(counts)
-            torch.cuda.synchronize()
-            elapsed = time.perf_counter() - t0
-            assert not bad, "a proof computed with several in flight differs from the one-at-a-time bytes"
-            ms_per_step = elapsed / args.steps * 1e3
-            value = m * args.steps / elapsed
-            free_b, total_b = torch.cuda.mem_get_info(dev)
-            hbm_resident_gb = (total_b - free_b) / 1e9
-            for q in provers[1:]:
-                q.close()
-            del provers, tstreams
-        except (RuntimeError, MemoryError, dvp.DvpError) as e:  # (a byte mismatch is an AssertionError and still fails the run) the one-at-a-time figures above stand; the line says what happened instead of being lost
-            in_flight_error = repr(e)
-            log(f"[bench] in-flight loop failed, reporting the one-at-a-time loop: {in_flight_error}")
-            n_in_flight, ms_per_step, value = 1, seq_ms, seq_value
     extras = single and not args.no_extras
 
     # ---- outside the timed region ---------------------------------------------------------------------------------------
@@ -406,42 +350,50 @@ def main():
             del d_bases, d_sc
         # throughput with TWO proofs in flight on this GPU: a second prover (own tables, own stream, own host thread) over the same
         # circuit; the library lets the two MSMs overlap everything but their pair rounds (msm.hip: HeavyGate).  Every proof is
-        # compared with the timed loop's bytes.  Not the headline: `value` stays one proof at a time.
-        try:
-            if n_in_flight > 1:
-                raise StopIteration  # already the headline loop
+        # compared with the timed loop's bytes.  Not the headline: `value` stays one proof at a time.  The leg is skipped only on a
+        # PRE-CHECKED capacity condition (no room for a second prover); any library / HIP error inside it fails the run.
+        free_b2, total_b2 = torch.cuda.mem_get_info(dev)
+        if args.in_flight < 2:
+            in_flight = None
+        elif free_b2 <= 1.15 * (total_b2 - free_b2):
+            in_flight = {"skipped": f"no room for a second prover: {free_b2 / 1e9:.1f} GB free, {(total_b2 - free_b2) / 1e9:.1f} GB in use by the first"}
+        else:
             import threading
             pv_b = dvp.proving.Prover(inst)
-            pv_b.set_srs(srs)
-            st_b = torch.cuda.Stream()
-            pair = ((pv, stream), (pv_b, st_b.cuda_stream))
-            k_each = max(4, min(args.steps, 12))
-            bad = []
+            try:
+                pv_b.set_srs(srs)
+                st_b = torch.cuda.Stream()
+                pair = ((pv, stream), (pv_b, st_b.cuda_stream))
+                k_each = max(4, min(args.steps, 12))
+                bad, errs = [], []
 
-            def _loop(pvx, stx, k):
-                for _ in range(k):
-                    if pvx.prove_dev(assignment.data_ptr(), stx) != proof:
-                        bad.append(1)
-            for k in (2, k_each):  # first pass = concurrent warm-up (the second MSM workspace is allocated on first overlap)
-                th = [threading.Thread(target=_loop, args=(a, b, k)) for a, b in pair]
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-                torch.cuda.synchronize()
-                dt2 = time.perf_counter() - t1
-            assert not bad, "a proof computed with two in flight differs"
-            in_flight = {"provers": 2, "proofs": 2 * k_each, "ms_per_proof": dt2 / (2 * k_each) * 1e3,
-                         "constraints_per_s": m * 2 * k_each / dt2,
-                         "note": "two provers on two host threads and two streams of this GPU, started together; aggregate over both; "
-                                 "each proof's own latency is about twice ms_per_proof"}
-            pv_b.close()
-        except StopIteration:
-            in_flight = None
-        except Exception as e:  # an extra: report, do not lose the line
-            in_flight = {"error": repr(e)}
+                def _loop(pvx, stx, k):
+                    try:
+                        for _ in range(k):
+                            if pvx.prove_dev(assignment.data_ptr(), stx) != proof:
+                                bad.append(1)
+                    except Exception as e:  # an exception in a thread would otherwise vanish and leave a short, wrong timing
+                        errs.append(repr(e))
+                for k in (2, k_each):  # first pass = concurrent warm-up (the second MSM workspace is allocated on first overlap)
+                    th = [threading.Thread(target=_loop, args=(a, b, k)) for a, b in pair]
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t1
+                    if errs:
+                        raise RuntimeError("two-in-flight loop: " + "; ".join(errs))
+                assert not bad, "a proof computed with two in flight differs"
+                free_b3, total_b3 = torch.cuda.mem_get_info(dev)
+                in_flight = {"provers": 2, "proofs": 2 * k_each, "ms_per_proof": dt2 / (2 * k_each) * 1e3,
+                             "constraints_per_s": m * 2 * k_each / dt2, "hbm_resident_gb": (total_b3 - free_b3) / 1e9,
+                             "note": "two provers on two host threads and two streams of this GPU, started together; aggregate over both; "
+                                     "each proof's own latency is about twice ms_per_proof"}
+            finally:
+                pv_b.close()
 
         # footprint: the other table flavour beside the timed one.  The default (round 3) is the aligned signed-window table
         # (W rows per base, ~5 GB at 2^20); the sliding-window flavour holds a multiple 2^j P for every bit position (233 rows,
@@ -536,6 +488,20 @@ def main():
             "frac": mul_frac,
         },
     }
+    # the same triple per launch SHAPE (the commit MSM and the K MSM are different sizes; the block above is their average)
+    n_sh = dvp.lib.dvp_profile_round0_shapes(None, None, None, 0)
+    if n_sh > 0:
+        a_p, a_ms, a_n = (C.c_uint64 * n_sh)(), (C.c_double * n_sh)(), (C.c_uint64 * n_sh)()
+        dvp.lib.dvp_profile_round0_shapes(a_p, a_ms, a_n, n_sh)
+        per = []
+        for k in range(n_sh):
+            pairs_k, ms_k = float(a_p[k]), a_ms[k] / max(a_n[k], 1)
+            adds_k = pairs_k * w_eff * 0.5
+            per.append({"pairs": int(a_p[k]), "launches": int(a_n[k]), "avg_launch_ms": ms_k,
+                        "achieved_gb_s": 96.0 * pairs_k / (ms_k * 1e-3) / 1e9, "frac": 96.0 * pairs_k / (ms_k * 1e-3) / 1e9 / 8000.0,
+                        "additions_per_launch": adds_k,
+                        "work_model_frac": (adds_k * per_add / (ms_k * 1e-3)) / mul_rate if mul_rate else None})
+        roof["per_msm"] = per
     traffic = load_profile("pmc_traffic_k_affine_round0")
     if traffic and log_m == 20 and n_shards == 1:
         raw = traffic["traffic_bytes_per_launch_raw"]
@@ -560,15 +526,6 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "in_flight": n_in_flight,
-        "in_flight_error": in_flight_error,
-        "value_one_at_a_time": seq_value,
-        "ms_per_step_one_at_a_time": seq_ms,
-        "in_flight_note": ("`value` / `ms_per_step`: the K steps run with `in_flight` proofs on the GPU at a time (that many provers, own host thread "
-                           "and stream each, every proof compared with the one-at-a-time bytes): sustained throughput; a proof's own latency is "
-                           "then about in_flight x ms_per_step.  `*_one_at_a_time`: the same K steps one after the other (the loop timed first; "
-                           "stages_ms_per_step, roofline and the profiles describe that loop).  --in-flight 1 makes it the headline."
-                           if n_in_flight > 1 else "one proof at a time"),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -587,11 +544,13 @@ def main():
             "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "sliding": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
                             "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "sliding": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
             "witness": "resident in HBM",
-            "proofs_in_flight": n_in_flight,
+            "proofs_in_flight": 1,
+            "latency_ms_one_proof": ms_per_step,
+            "constraints_per_s_two_in_flight": (in_flight or {}).get("constraints_per_s"),
         },
         "hbm_resident_gb": hbm_resident_gb,
         "hbm_resident_note": "device memory in use on this rank's GPU after the timed loops (every prover in flight: tables, bases, MSM workspaces, trees; the torch context)",
-        "ms_per_step_aligned_tables": aligned_ms if aligned_ms is not None else (None if (tables[0][1] or tables[1][1]) else seq_ms),
+        "ms_per_step_aligned_tables": aligned_ms if aligned_ms is not None else (None if (tables[0][1] or tables[1][1]) else ms_per_step),
         "aligned_tables_gb": aligned_gb if aligned_gb is not None else (None if (tables[0][1] or tables[1][1]) else round((tables[0][0] + tables[1][0]) / 1e9, 2)),
         "ms_per_step_sliding_tables": sliding_ms,
         "sliding_tables_gb": sliding_gb,

@@ -45,6 +45,7 @@ _SIGS = {
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),
     "dvp_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "dvp_profile_round0_shapes": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
     "dvp_ecfft_create": (C.c_int, [u32, C.c_int, u32, C.POINTER(vp)]),
     "dvp_ecfft_destroy": (None, [vp]),
     "dvp_ecfft_log2_leaves": (u32, [vp]),
@@ -97,6 +98,7 @@ _SIGS = {
     "dvp_prove_extend_vectors": (C.c_int, [vp, u32, vp]),
     "dvp_prover_extended_ptr": (C.c_int, [vp, u32, C.POINTER(vp)]),
     "dvp_prove_quotient": (C.c_int, [vp, vp]),
+    "dvp_prove_mark_extended": (C.c_int, [vp, u32]),
     "dvp_prover_msm_size": (C.c_size_t, [vp, C.c_int]),
     "dvp_prover_msm_plan": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dvp_prover_msm_table_bytes": (C.c_uint64, [vp, C.c_int, C.POINTER(C.c_int)]),

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <tuple>
 #include <string>
@@ -212,16 +213,22 @@ std::string join(const char* dir, const char* name) {
 // prover is destroyed when the last prove in flight returns.
 struct OpenEntry {
   dvp_prover* p = nullptr;
-  std::mutex mu;
+  std::mutex mu;                    // guards the opening of `p`
   std::atomic<bool> opened{false};  // the files have been read (under mu); rc then holds the result
   int rc = DVP_OK;
   // A second prover over the same files, opened the first time a proof arrives while the first prover is busy: two host
   // threads calling dvp_prove_cache_dir on one cache_dir then have two proofs in flight on the GPU (+11 % constraints/s at
-  // 2^20) instead of taking turns.  Costs one more decode of the SRS files and one more set of tables.
+  // 2^20) instead of taking turns.  Costs one more decode of the SRS files and one more set of tables,
+  // so it is opened only when (i) the first prover has finished a proof (its tables and MSM workspaces exist: what is in use
+  // on the device is then a fair measure of one prover) and (ii) free HBM exceeds 1.25 x what is in use -- a replica must never
+  // make the first prover's own allocations fail.  Callers take whichever of the two provers frees first (slot_cv).
   dvp_prover* p2 = nullptr;
-  std::mutex mu2;
-  bool opened2 = false;
+  bool opened2 = false, opening2 = false;
   int rc2 = DVP_OK;
+  std::mutex slot_mu;
+  std::condition_variable slot_cv;
+  bool busy[2] = {false, false};
+  uint64_t proofs_done = 0;
   ~OpenEntry() {
     if (p) dvp_prover_destroy(p);
     if (p2) dvp_prover_destroy(p2);
@@ -435,21 +442,46 @@ extern "C" int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public
   std::shared_ptr<OpenEntry> e;
   int rc = open_entry(cache_dir, n_public, &e);
   if (rc) return rc;
-  std::unique_lock<std::mutex> g(e->mu, std::try_to_lock);
   long long replicas = 1;
   (void)dvp_tune_get("DVP_CACHE_REPLICAS", &replicas);
-  if (!g.owns_lock() && replicas >= 2) {
-    std::unique_lock<std::mutex> g2(e->mu2, std::try_to_lock);
-    if (g2.owns_lock()) {
-      if (!e->opened2) {
-        e->rc2 = dvp_prover_open_cache_dir(cache_dir, n_public, &e->p2);  // e.g. out of memory at 2^23 beside other tenants:
-        e->opened2 = true;                                                 // then callers keep taking turns on the first prover
+  int slot = -1;
+  {
+    std::unique_lock<std::mutex> g(e->slot_mu);
+    for (;;) {
+      if (!e->busy[0]) { slot = 0; break; }
+      if (replicas >= 2 && e->opened2 && e->rc2 == DVP_OK && !e->busy[1]) { slot = 1; break; }
+      if (replicas >= 2 && !e->opened2 && !e->opening2 && e->proofs_done > 0) {
+        size_t free_b = 0, total_b = 0;
+        const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > 1.25 * (double)(total_b - free_b);
+        if (!room) {  // callers keep taking turns on the first prover; asked again only after a release + reopen
+          e->opened2 = true;
+          e->rc2 = DVP_ENOMEM;
+          continue;
+        }
+        e->opening2 = true;
+        g.unlock();
+        dvp_prover* q = nullptr;
+        const int r2 = dvp_prover_open_cache_dir(cache_dir, n_public, &q);
+        g.lock();
+        e->p2 = q;
+        e->rc2 = r2;
+        e->opened2 = true;
+        e->opening2 = false;
+        e->slot_cv.notify_all();
+        continue;
       }
-      if (e->rc2 == DVP_OK) return dvp_prove(e->p2, public_inputs, n_public, private_inputs, n_private, proof);
+      e->slot_cv.wait(g);
     }
+    e->busy[slot] = true;
   }
-  if (!g.owns_lock()) g.lock();
-  return dvp_prove(e->p, public_inputs, n_public, private_inputs, n_private, proof);
+  rc = dvp_prove(slot == 0 ? e->p : e->p2, public_inputs, n_public, private_inputs, n_private, proof);
+  {
+    std::lock_guard<std::mutex> g(e->slot_mu);
+    e->busy[slot] = false;
+    if (rc == DVP_OK) ++e->proofs_done;
+  }
+  e->slot_cv.notify_one();
+  return rc;
 }
 
 // the prover dvp_prove_cache_dir uses for (cache_dir, n_public) on the current device, opened if need be: BORROWED --

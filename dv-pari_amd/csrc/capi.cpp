@@ -1,6 +1,7 @@
 // Library-wide C ABI pieces: status strings, device selection, last-error bookkeeping.
 #include "common.h"
 
+#include <map>
 #include <mutex>
 #include <vector>
 #include <cstring>
@@ -14,11 +15,13 @@ bool g_prof_enabled = false;
 static std::mutex g_prof_mu;
 static double g_prof_ms[PROF_NSLOTS] = {0};
 static uint64_t g_prof_n[PROF_NSLOTS] = {0};
-struct Pending { int slot; hipEvent_t e0, e1; };
+struct Pending { int slot; hipEvent_t e0, e1; uint64_t key; };
+struct Shape { double ms = 0; uint64_t n = 0; };
+static std::map<uint64_t, Shape> g_prof_round0;  // first pair rounds by launch shape (key = (scalar, base) pairs of the MSM)
 static std::vector<Pending> g_prof_pending;
 static const char* kProfNames[PROF_NSLOTS] = {"msm_affine_round0", "msm_total", "extend_total", "prove_total", "msm_affine_rest", "msm_sort", "msm_tail"};
 
-ProfScope::ProfScope(int slot_, hipStream_t st_) : slot(slot_), st(st_) {
+ProfScope::ProfScope(int slot_, hipStream_t st_, uint64_t key_) : slot(slot_), st(st_), key(key_) {
   if (!g_prof_enabled) return;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, st);
@@ -27,7 +30,7 @@ void ProfScope::stop() {
   if (!e0) return;
   (void)hipEventRecord(e1, st);
   std::lock_guard<std::mutex> g(g_prof_mu);
-  g_prof_pending.push_back({slot, e0, e1});
+  g_prof_pending.push_back({slot, e0, e1, key});
   e0 = e1 = nullptr;
 }
 void prof_collect() {
@@ -37,6 +40,7 @@ void prof_collect() {
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       g_prof_ms[p.slot] += ms;
       g_prof_n[p.slot] += 1;
+      if (p.slot == PROF_MSM_ACCUM_AFFINE && p.key) { Shape& sh = g_prof_round0[p.key]; sh.ms += ms; sh.n += 1; }
     }
     (void)hipEventDestroy(p.e0);
     (void)hipEventDestroy(p.e1);
@@ -57,6 +61,7 @@ static void tune_from_env(Tune& t) {
   t.msm_aff_min = geti("DVP_MSM_AFF_MIN", t.msm_aff_min);
   t.msm_aff_bmax = geti("DVP_MSM_AFF_BMAX", t.msm_aff_bmax);
   t.msm_aff_bmin = geti("DVP_MSM_AFF_BMIN", t.msm_aff_bmin);
+  t.ecfft_radix4 = geti("DVP_ECFFT_RADIX4", t.ecfft_radix4);
   t.msm_ws_slots = geti("DVP_MSM_WS_SLOTS", t.msm_ws_slots);
   t.msm_gate_min = geti("DVP_MSM_GATE_MIN", t.msm_gate_min);
   t.msm_aff_tpb = geti("DVP_MSM_AFF_TPB", t.msm_aff_tpb);
@@ -84,7 +89,7 @@ static long long* tune_slot(const char* name) {
   dvp::Tune& t = dvp::tune();
   struct { const char* n; long long* v; } tab[] = {
       {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi}, {"DVP_MSM_SLIDE", &t.msm_slide},
-      {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax}, {"DVP_MSM_AFF_BMIN", &t.msm_aff_bmin}, {"DVP_MSM_WS_SLOTS", &t.msm_ws_slots}, {"DVP_MSM_GATE_MIN", &t.msm_gate_min}, {"DVP_MSM_AFF_TPB", &t.msm_aff_tpb}, {"DVP_CACHE_REPLICAS", &t.cache_replicas},
+      {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax}, {"DVP_MSM_AFF_BMIN", &t.msm_aff_bmin}, {"DVP_ECFFT_RADIX4", &t.ecfft_radix4}, {"DVP_MSM_WS_SLOTS", &t.msm_ws_slots}, {"DVP_MSM_GATE_MIN", &t.msm_gate_min}, {"DVP_MSM_AFF_TPB", &t.msm_aff_tpb}, {"DVP_CACHE_REPLICAS", &t.cache_replicas},
       {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_ACCUM_QUAD_MAX", &t.msm_accum_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub},
       {"DVP_MSM_TABLE_MAX_GB", &t.msm_table_max_gb}, {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}};
   for (auto& e : tab)
@@ -110,6 +115,19 @@ extern "C" void dvp_profile_reset(void) {
   dvp::prof_collect();
   std::lock_guard<std::mutex> g(dvp::g_prof_mu);
   for (int i = 0; i < dvp::PROF_NSLOTS; ++i) { dvp::g_prof_ms[i] = 0; dvp::g_prof_n[i] = 0; }
+  dvp::g_prof_round0.clear();
+}
+// the "msm_affine_round0" slot split by launch shape: one entry per distinct MSM size seen since the last reset
+extern "C" int dvp_profile_round0_shapes(uint64_t* pairs, double* total_ms, uint64_t* launches, int cap) {
+  if (cap < 0 || (cap > 0 && (!pairs || !total_ms || !launches))) return DVP_EINVAL;
+  dvp::prof_collect();
+  std::lock_guard<std::mutex> g(dvp::g_prof_mu);
+  int k = 0;
+  for (auto& e : dvp::g_prof_round0) {
+    if (k < cap) { pairs[k] = e.first; total_ms[k] = e.second.ms; launches[k] = e.second.n; }
+    ++k;
+  }
+  return k;
 }
 extern "C" int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches) {
   if (!name || !total_ms || !launches) return DVP_EINVAL;

@@ -173,6 +173,49 @@ __global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const 
   }
 }
 
+// TWO butterfly layers in one pass (radix 4): layer d (pairs h1 = 2^lh apart) and layer d + 1 (pairs h2 = h1 / 2 apart) only mix
+// the four values {j, j + h2, j + h1, j + h1 + h2} of a block of 4 h2, so one thread loads them once, applies both layers in
+// registers and stores them once: half the HBM round trips of the data (the per-layer passes above stream 3 x 64 MB per layer at
+// m = 2^20 and are as much HBM- as VALU-bound).  Matrices: two of layer d (M_d[j], M_d[j + h2]) and one of layer d + 1
+// (M_{d+1}[j], shared by both pairs).  DEC = decompose order (wide layer first); recombine runs the narrow layer first.
+// BATCH vectors: lane = (quad of values, vector) with the vector index fastest, so the BATCH lanes that need the same three
+// matrices sit in the same wave and their loads are one request (holding the twelve matrix entries in registers across a loop
+// over the vectors instead costs 256 VGPRs, or 400-600 bytes of scratch per lane at three waves per SIMD).
+template <int BATCH, bool DEC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_butterfly4(Fr* __restrict__ data, const Fr29* __restrict__ mats_wide,
+                                                    const Fr29* __restrict__ mats_narrow, int lh2, uint32_t n) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tid = gid / BATCH, bv = gid - tid * BATCH;
+  if (tid >= (n >> 2)) return;
+  const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
+  const uint32_t j = tid & (h2 - 1);
+  const uint32_t i0 = ((tid >> lh2) << (lh2 + 2)) | j;
+  const Fr29* ma = mats_wide + 4 * (size_t)j;
+  const Fr29* mb = mats_wide + 4 * (size_t)(j + h2);
+  const Fr29* mc = mats_narrow + 4 * (size_t)j;
+  Fr* v = data + (size_t)bv * n + i0;
+  Fr x0 = v[0], x1 = v[h2], x2 = v[h1], x3 = v[h1 + h2];
+  Fr29 e0 = fr29_from(x0), e1 = fr29_from(x1), e2 = fr29_from(x2), e3 = fr29_from(x3);
+  if (DEC) {
+    x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);  // layer d: (j, j + h1)
+    x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);  //          (j + h2, j + h2 + h1)
+    e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
+    const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
+    x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);  // layer d + 1: (j, j + h2)
+    x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);  //              (j + h1, j + h1 + h2)
+  } else {
+    {
+      const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
+      x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);
+      x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);
+    }
+    e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
+    x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);
+    x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);
+  }
+  v[0] = x0; v[h2] = x1; v[h1] = x2; v[h1 + h2] = x3;
+}
+
 // Fused bottom of an extend: the last `lb` decompose layers and the first `lb` recombine layers only mix
 // elements inside aligned blocks of 2^lb <= 2048 values, so a workgroup keeps 2048 consecutive values
 // (64 KB) in LDS and runs all 2*lb butterfly layers on them in ONE launch and ONE HBM round trip (the
@@ -302,13 +345,40 @@ int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, 
     else if (batch == 2) launch_bfly<2>(data, mats, lh, n, st);
     else launch_bfly<1>(data, mats, lh, (uint32_t)((size_t)batch * n), st);
   };
+  // two layers per pass (k_butterfly4) while two top layers remain; `wide` = layer d, `narrow` = layer d + 1
+  auto pass4 = [&](const Fr29* base, int d, bool dec) {
+    const Fr29* wide = base + 4 * (size_t)(n - (n >> d));
+    const Fr29* narrow = base + 4 * (size_t)(n - (n >> (d + 1)));
+    const int lh2 = ln - d - 2;
+    const dim3 g(cdiv((size_t)(n >> 2) * batch, TPB)), b(TPB);
+    const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
+    const dim3 g1(cdiv(nn >> 2, TPB));
+#define DVP_BF4(B, GRID) \
+  do { if (dec) hipLaunchKernelGGL((k_butterfly4<B, true>), GRID, b, 0, st, data, wide, narrow, lh2, nn); \
+       else hipLaunchKernelGGL((k_butterfly4<B, false>), GRID, b, 0, st, data, wide, narrow, lh2, nn); } while (0)
+    if (batch == 4) DVP_BF4(4, g); else if (batch == 3) DVP_BF4(3, g); else if (batch == 2) DVP_BF4(2, g); else DVP_BF4(1, g1);
+#undef DVP_BF4
+  };
   const int lb = ln < FUSE_LOG ? ln : FUSE_LOG;  // layers handled inside LDS
-  for (int d = 0; d < ln - lb; ++d) pass(ms->dec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+  const int top = ln - lb;
+  const bool radix4 = tune().ecfft_radix4 != 0;
+  {
+    int d = 0;
+    if (radix4)
+      for (; d + 1 < top; d += 2) pass4(ms->dec, d, true);
+    for (; d < top; ++d) pass(ms->dec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+  }
   {
     size_t total = (size_t)batch * n;
     hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, data, ms->dec, ms->rec, n, ln, lb, total);
   }
-  for (int d = ln - lb - 1; d >= 0; --d) pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+  {
+    int d = top - 1;
+    if (radix4 && (top & 1)) { pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1); --d; }  // the odd layer is the innermost one, as in the decompose
+    if (radix4)
+      for (; d >= 1; d -= 2) pass4(ms->rec, d - 1, false);
+    for (; d >= 0; --d) pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+  }
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }

@@ -1735,7 +1735,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t grid = r_max * (aff_cap / aff_tpb) + 1;
     const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
     {
-      ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st);  // r == 0 is the dominant kernel: it gathers the bases
+      ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st, (uint64_t)n);  // r == 0 is the dominant kernel: it gathers the bases
       WaveTrace wt{g_wave_trace.load(), g_wave_trace_cap, g_wave_trace_tag.fetch_add(wt_on ? 1u : 0u)};
       const uint2* dsc = items_are_desc ? (const uint2*)items : (const uint2*)gdesc;
       if (r == 0 && wt.buf)

@@ -369,6 +369,7 @@ struct dvp_prover {
   MsmFixedCtx* fx[2] = {nullptr, nullptr};
   size_t fx_lo[2] = {0, 0}, fx_hi[2] = {0, 0};  // index range of the bases the context of MSM `which` was built for
   bool last_begin_extended = false;            // dvp_prove_begin_partial(need_extend): q2 / k_r are valid only if true
+  uint32_t ext_filled = 0;                     // bit v: extended vector v of this proof is in E2 (extended here, or received and marked)
   // in-library multi-GPU (dvp_set_devices): one shard per listed device, each with its slice of both base vectors
   struct Shard {
     int device = 0;
@@ -681,7 +682,8 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
 // k_r part of the second MSM's scalars are then NOT valid on this prover until the next full begin.
 extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream) {
   if (!p || !d_assignment || !prover_ready(p)) return DVP_EINVAL;
-  p->last_begin_extended = need_extend != 0;
+  p->last_begin_extended = false;  // set by dvp_prove_quotient once every extended vector is in place
+  p->ext_filled = 0;
   hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
   const size_t nw = p->n_wires;
@@ -743,6 +745,14 @@ extern "C" int dvp_prove_extend_vectors(dvp_prover* p, uint32_t mask, void* stre
     pe.stop();
     v = e;
   }
+  p->ext_filled |= mask;
+  return DVP_OK;
+}
+// extended vector v of the CURRENT proof has been written into dvp_prover_extended_ptr(v) by the caller (a broadcast from the
+// rank that extended it): dvp_prove_quotient refuses to run until every vector is either extended here or marked
+extern "C" int dvp_prove_mark_extended(dvp_prover* p, uint32_t v) {
+  if (!p || v >= prover_n_ext(p)) return DVP_EINVAL;
+  p->ext_filled |= 1u << v;
   return DVP_OK;
 }
 // r2 = a2 b2 - i2, q2 = (r2 - c2) / Z_D on D' (src/proving.rs:492-508) from the extended vectors in place
@@ -751,6 +761,7 @@ extern "C" int dvp_prove_quotient(dvp_prover* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
   const size_t nw = p->n_wires;
+  if (p->ext_filled != (1u << prover_n_ext(p)) - 1) return DVP_EINVAL;  // a missed broadcast would otherwise give a silently wrong q2
   dim3 gm(cdiv(m, PT)), bt(PT);
   if (prover_n_ext(p) == 3)
     hipLaunchKernelGGL(k_quotient<true>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);

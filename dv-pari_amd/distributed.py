@@ -105,6 +105,11 @@ class GpuBackend:
             self._ext_views[v] = self.torch.as_tensor(view, device=self.device)
         return self._ext_views[v]
 
+    def mark_extended(self, v):
+        """extended vector v has been received into extended_tensor(v) (dvp_prove_mark_extended): the quotient refuses to run
+        until every vector is extended here or marked"""
+        self.prover.mark_extended(v)
+
     def quotient(self):
         self.prover.quotient(self.torch.cuda.current_stream().cuda_stream)
 
@@ -151,7 +156,30 @@ class GpuBackend:
         return self.prover.finish(point.data_ptr(), point.data_ptr() + 64, self.torch.cuda.current_stream().cuda_stream)
 
 
-_GATHER_MODE = {}  # process group (id) -> "tensor" | "list", decided ONCE by probe_collectives
+import weakref
+
+_WORLD = type("_DefaultGroup", (), {})()  # stands for group=None (the default process group) as a cache key
+
+
+class _GroupCache:
+    """per-process-group cache keyed by the group OBJECT (weakly): an entry dies with its group, so a new group that happens
+    to reuse the id() of a destroyed one can never inherit its collective mode or extender sub-group"""
+
+    def __init__(self):
+        self._d = weakref.WeakKeyDictionary()
+
+    def slot(self, group):
+        key = _WORLD if group is None else group
+        try:
+            return self._d.setdefault(key, {})
+        except TypeError:  # a group type that cannot be weakly referenced: no caching, every call decides afresh
+            return {}
+
+    def clear(self):
+        self._d = weakref.WeakKeyDictionary()
+
+
+_GATHER_MODE = _GroupCache()  # process group -> {"mode": "tensor" | "list"}, decided ONCE by probe_collectives
 
 
 def probe_collectives(device, group=None):
@@ -164,9 +192,9 @@ def probe_collectives(device, group=None):
     import torch
     import torch.distributed as dist
 
-    key = id(group) if group is not None else 0
-    if key in _GATHER_MODE:
-        return _GATHER_MODE[key]
+    slot = _GATHER_MODE.slot(group)
+    if "mode" in slot:
+        return slot["mode"]
     world = dist.get_world_size(group)
     probe = torch.zeros(10, dtype=torch.int64, device=device)
     out = torch.empty(world * 10, dtype=torch.int64, device=device)  # flat: the one output shape every backend accepts
@@ -183,7 +211,7 @@ def probe_collectives(device, group=None):
             raise
     if mode == "list":
         dist.all_gather([torch.empty_like(probe) for _ in range(world)], probe, group=group)
-    _GATHER_MODE[key] = mode
+    slot["mode"] = mode
     return mode
 
 
@@ -202,7 +230,7 @@ def _all_gather_records(part, world, group):
     return torch.stack(gathered)
 
 
-_EXT_GROUPS = {}  # (id of the parent group, extender ranks) -> process group of the extender ranks
+_EXT_GROUPS = _GroupCache()  # parent group -> {extender ranks: process group of the extender ranks}
 
 
 def _extender_group(ext_ranks, group):
@@ -210,12 +238,20 @@ def _extender_group(ext_ranks, group):
     rank calls this at the same point of its first sharded proof (the result is cached)"""
     import torch.distributed as dist
 
-    key = (id(group) if group is not None else 0, tuple(ext_ranks))
-    if key not in _EXT_GROUPS:
+    slot = _EXT_GROUPS.slot(group)
+    key = tuple(ext_ranks)
+    if key not in slot:
         # new_group takes GLOBAL ranks; ext_ranks are ranks of `group`
         glob = [dist.get_global_rank(group, r) for r in ext_ranks] if group is not None else list(ext_ranks)
-        _EXT_GROUPS[key] = dist.new_group(ranks=glob) if len(ext_ranks) < dist.get_world_size(group) else group
-    return _EXT_GROUPS[key]
+        slot[key] = dist.new_group(ranks=glob) if len(ext_ranks) < dist.get_world_size(group) else group
+    return slot[key]
+
+
+def forget_groups():
+    """drop every cached collective mode / extender sub-group (call after dist.destroy_process_group(): the default group is
+    keyed by a module-level stand-in that outlives it)"""
+    _GATHER_MODE.clear()
+    _EXT_GROUPS.clear()
 
 
 def extend_owner(v, ext_ranks):
@@ -250,8 +286,10 @@ def prove_sharded(backend, assignment, group=None, always_gather=False, shard_ex
         backend.extend_vectors([v for v in range(n_ext) if extend_owner(v, ext_ranks) == rank])
         work = [dist.broadcast(backend.extended_tensor(v), src=dist.get_global_rank(group, extend_owner(v, ext_ranks)) if group is not None
                                else extend_owner(v, ext_ranks), group=ext_group, async_op=True) for v in range(n_ext)]
-        for wk in work:
+        for v, wk in enumerate(work):
             wk.wait()
+            if extend_owner(v, ext_ranks) != rank and hasattr(backend, "mark_extended"):
+                backend.mark_extended(v)
         backend.quotient()
     else:
         backend.begin(assignment, need_extend)

@@ -227,6 +227,9 @@ class Prover:
         check(lib.dvp_prover_extended_ptr(self._h, v, C.byref(out)), "dvp_prover_extended_ptr")
         return out.value
 
+    def mark_extended(self, v: int):
+        check(lib.dvp_prove_mark_extended(self._h, v), "dvp_prove_mark_extended")
+
     def quotient(self, stream: int = 0):
         check(lib.dvp_prove_quotient(self._h, stream), "dvp_prove_quotient")
 

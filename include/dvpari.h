@@ -204,6 +204,10 @@ int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_ex
 uint32_t dvp_prover_extend_count(const dvp_prover* p);
 int dvp_prove_extend_vectors(dvp_prover* p, uint32_t mask, void* stream);
 int dvp_prover_extended_ptr(dvp_prover* p, uint32_t v, void** d_ptr);
+/* vector v of the current proof has been written into dvp_prover_extended_ptr(v) by the caller (received from the rank that
+ * extended it).  dvp_prove_quotient returns DVP_EINVAL unless every vector was either extended here or marked since the
+ * last begin: a missed exchange cannot turn into a silently wrong q2. */
+int dvp_prove_mark_extended(dvp_prover* p, uint32_t v);
 int dvp_prove_quotient(dvp_prover* p, void* stream);
 size_t dvp_prover_msm_size(const dvp_prover* p, int which);
 /* window bits / window count chosen for MSM `which` (0,0 until its fixed-base tables exist) */
@@ -271,8 +275,9 @@ int dvp_prover_open_cache_dir(const char* cache_dir, uint32_t n_public, dvp_prov
 /* Proof::prove(cache_dir, public_inputs, private_inputs) itself: opens cache_dir on first use and keeps the prover in
  * a process-wide table keyed by (cache_dir, n_public, current HIP device); dvp_cache_dir_release(NULL) drops every entry.
  * Thread safety: concurrent calls are allowed; one prover = one set of device buffers, so an entry opens a SECOND prover
- * from the same files the first time two calls on it overlap (two proofs in flight on the GPU; DVP_CACHE_REPLICAS=1 in the
- * environment turns that off) and further callers wait for one of the two; a release during a prove takes effect when that
+ * from the same files when two calls on it overlap after the first prover has completed a proof AND free device memory
+ * exceeds 1.25 x what is in use (two proofs in flight on the GPU; DVP_CACHE_REPLICAS=1 in the environment turns that
+ * off); callers take whichever prover frees first and otherwise wait; a release during a prove takes effect when that
  * prove returns.  Files that change on disk after the first
  * call are not re-read: release the entry first.  Only SRS files whose 30-byte encodings follow this library's codec
  * rule are supported until that rule is pinned against xs233 (tools/pin_xsk233.py). */

@@ -30,6 +30,9 @@ void dvp_tune_reset(void);
 void dvp_profile_enable(int on);
 void dvp_profile_reset(void);
 int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
+/* "msm_affine_round0" split by launch shape: entry k = (pairs of the MSM, summed ms, launches) for every distinct MSM size
+ * since the last reset; returns the number of shapes (fills at most `cap`), < 0 on error */
+int dvp_profile_round0_shapes(uint64_t* pairs, double* total_ms, uint64_t* launches, int cap);
 
 /* microbenchmark of the MSM kernels' GF(2^233) multiplier alone (products per second, whole chip, the pair rounds'
  * occupancy): the ceiling of bench.py's work model, measured in the same run */

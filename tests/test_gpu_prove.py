@@ -300,6 +300,13 @@ def test_extends_by_vector_simulated_ranks(dvp, horner_max_pub):
                 if r != dvp.distributed.extend_owner(v, ext_ranks):
                     be.extended_tensor(v).copy_(src)
         torch.cuda.synchronize()
+        # a vector that never arrived must stop the quotient (DVP_EINVAL), not give a silently wrong q2
+        with pytest.raises(dvp.DvpError):
+            ranks[0].quotient()
+        for r, be in enumerate(ranks):
+            for v in range(n_ext):
+                if r != dvp.distributed.extend_owner(v, ext_ranks):
+                    be.mark_extended(v)
         for be in ranks:
             be.quotient()
             for n in want:
