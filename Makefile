@@ -5,7 +5,7 @@
 HIPCC  ?= /opt/rocm/bin/hipcc
 ARCH   ?= gfx950
 CSRC   := dv-pari_amd/csrc
-SRCS   := capi.cpp cache.cpp tree_io.cpp ecfft.hip msm.hip codec.hip fr_ops.hip prove.hip
+SRCS   := capi.cpp cache.cpp tree_io.cpp ecfft.hip msm.hip codec.hip fr_ops.hip prove.hip setup.hip
 OBJS   := $(addprefix $(CSRC)/,$(addsuffix .o,$(basename $(SRCS))))
 HDRS   := $(wildcard $(CSRC)/*.h $(CSRC)/*.cuh include/*.h)
 LIB    := dv-pari_amd/libdvpari_hip.so

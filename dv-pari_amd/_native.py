@@ -122,6 +122,8 @@ _SIGS = {
     "dvp_fftr_sections": (C.c_int, [C.c_char_p, u32, u8p, u64p, C.POINTER(u32)]),
     "dvp_fftr_read_fr": (C.c_int, [C.c_char_p, u32, C.c_uint8, u64p, sz, C.POINTER(C.c_size_t)]),
     "dvp_fftr_write": (C.c_int, [C.c_char_p, u32, u8p, vp, u64p]),
+    "dvp_setup_cache_dir": (C.c_int, [u64p, u64p, u64p, C.c_char_p, u32, C.c_int]),
+    "dvp_setup_cache_dir_ex": (C.c_int, [u64p, u64p, u64p, C.c_char_p, u32, C.c_int, u64p, sz, C.POINTER(u32), C.POINTER(u32)]),
     "dvp_prover_open_cache_dir": (C.c_int, [C.c_char_p, u32, C.POINTER(vp)]),
     "dvp_prove_cache_dir": (C.c_int, [C.c_char_p, u64p, u32, u64p, u32, u8p]),
     "dvp_cache_dir_release": (None, [C.c_char_p]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdvpari_hip.so")
-SOURCES = ["capi.cpp", "cache.cpp", "tree_io.cpp", "ecfft.hip", "msm.hip", "codec.hip", "fr_ops.hip", "prove.hip"]
+SOURCES = ["capi.cpp", "cache.cpp", "tree_io.cpp", "ecfft.hip", "msm.hip", "codec.hip", "fr_ops.hip", "prove.hip", "setup.hip"]
 HEADERS = ["common.h", "fr.cuh", os.path.join("..", "..", "include", "dvpari.h")]
 
 

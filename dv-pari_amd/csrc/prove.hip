@@ -1180,23 +1180,28 @@ extern "C" int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* 
 
 // Domain tables for setup-side callers (compute_barycentric_weights / evaluate_vanishing_poly_at_domain +
 // batch_inversion, src/ec_fft.rs:284-335,407-419): which = 0 -> (1/Z_D'(D), 1/Z_D(D')), which = 1 -> mirrored.
-extern "C" int dvp_ecfft_domain_tables(dvp_ecfft* t, int which, uint64_t* bar_weights, uint64_t* zinv_other) {
-  if (!t || !bar_weights || !zinv_other || (which != 0 && which != 1) || t->log_n < 2) return DVP_EINVAL;
+// device flavour (setup.hip): canonical outputs, m = leaves / 2 entries each
+int ecfft_domain_tables_dev(dvp_ecfft* t, int which, Fr* d_bar_weights, Fr* d_zinv_other, hipStream_t st) {
+  if (!t || !d_bar_weights || !d_zinv_other || (which != 0 && which != 1) || t->log_n < 2) return DVP_EINVAL;
   const size_t m = t->n_leaves / 2;
   const int kk = t->log_n - 1;
   DVP_TRY(ecfft_device_consts(t));
-  DevBuf bw, zi, o1, o2;
+  hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, st, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, kk, t->layer(kk),
+                     which, d_bar_weights, d_zinv_other);
+  hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, st, d_bar_weights, d_bar_weights, m);
+  hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, st, d_zinv_other, d_zinv_other, m);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+extern "C" int dvp_ecfft_domain_tables(dvp_ecfft* t, int which, uint64_t* bar_weights, uint64_t* zinv_other) {
+  if (!t || !bar_weights || !zinv_other || (which != 0 && which != 1) || t->log_n < 2) return DVP_EINVAL;
+  const size_t m = t->n_leaves / 2;
+  DevBuf bw, zi;
   DVP_TRY(bw.alloc(m * sizeof(Fr)));
   DVP_TRY(zi.alloc(m * sizeof(Fr)));
-  DVP_TRY(o1.alloc(m * sizeof(Fr)));
-  DVP_TRY(o2.alloc(m * sizeof(Fr)));
-  hipLaunchKernelGGL(k_domain_tables, dim3(cdiv(m, PT)), dim3(PT), 0, 0, t->layer(0), (uint32_t)m, t->d_x0, t->d_t, kk, t->layer(kk),
-                     which, bw.as<Fr>(), zi.as<Fr>());
-  hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, 0, bw.as<Fr>(), o1.as<Fr>(), m);
-  hipLaunchKernelGGL(k_from_mont_vec, dim3(cdiv(m, PT)), dim3(PT), 0, 0, zi.as<Fr>(), o2.as<Fr>(), m);
-  DVP_HIP(hipGetLastError());
-  DVP_HIP(hipMemcpy(bar_weights, o1.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
-  DVP_HIP(hipMemcpy(zinv_other, o2.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
+  DVP_TRY(ecfft_domain_tables_dev(t, which, bw.as<Fr>(), zi.as<Fr>(), 0));
+  DVP_HIP(hipMemcpy(bar_weights, bw.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
+  DVP_HIP(hipMemcpy(zinv_other, zi.p, m * sizeof(Fr), hipMemcpyDeviceToHost));
   return DVP_OK;
 }
 extern "C" int dvp_prover_domain_tables(dvp_prover* p, int which, uint64_t* bar_weights, uint64_t* zinv_other) {

@@ -1,0 +1,370 @@
+// SRS::verifier_runs_setup behind the C ABI (src/srs.rs:177-361 -> compute_srs_matrices, src/srs.rs:112-167): reads
+// cache_dir/r1cs_to_dvsnark, computes the five scalar vectors of the SRS on the device, turns them into points with the batched
+// fixed-base multiplication (codec.hip: k_mulgen), writes g_m, g_q, g_k_0..2 in the reference's point-vector format and --
+// optionally -- the domain files a reference prover / verifier would otherwise spend hours on (z_poly, z_polyd, bar_wts,
+// bar_wtsd, z_vals2inv, z_vals2dinv; src/artifacts.rs:86-110).  Every vector stays on the device between the stages: the
+// python orchestration this replaces (dv-pari_amd/srs.py, round 1-3) bounced each one through host memory per operation.
+//
+//   L_i(tau)  = Z_D(tau) / ((tau - d_i) Z_D'(d_i))                                    src/ec_fft.rs:340-390
+//   L'_i(tau) likewise on D'; the unified-domain values interleaved [D_i, D'_i]        src/ec_fft.rs:424-450
+//   m_j(tau, delta) = sum_i (A_ij + delta B_ij + delta^2 C'_ij) L_i(tau)               src/srs.rs:53-84 (accumulate_m_values)
+//       with C' = C - D, D_ij = d_i^j on the public wires                              src/gnark_r1cs.rs:333-386
+//   g_m[j] = eps m_j G,  g_q[i] = eps Z_D(tau) delta^2 L'_i(tau) G,
+//   g_k[0][i] = L_i(tau) G,  g_k[1][i] = delta L_i(tau) G,  g_k[2] = delta^2 (unified-domain Lagrange values) G    src/srs.rs:126-160
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "ecfft_internal.h"
+#include "k233.cuh"
+
+extern "C" int dvp_ecfft_create(uint32_t log_n, int shifted, uint32_t base_log, dvp_ecfft** out);
+extern "C" void dvp_ecfft_destroy(dvp_ecfft* c);
+extern "C" int dvp_ecfft_exit_dev(dvp_ecfft* c, const void* d_evals, void* d_out, void* stream);
+int ecfft_domain_tables_dev(dvp_ecfft* t, int which, Fr* d_bar_weights, Fr* d_zinv_other, hipStream_t st);
+
+namespace dvp {
+int batch_inverse_dev(Fr* d, size_t n, hipStream_t st);
+int mulgen_dev(const void* d_scalars, size_t n, Aff* d_out, uint8_t* d_inf, hipStream_t st);
+int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st);
+
+namespace {
+constexpr int TPB = 256;
+// canonical copies of D (even leaves) and D' (odd leaves) of the 2m-leaf tree (layer 0 is stored in Montgomery form)
+__global__ void __launch_bounds__(TPB) ks_domains(const Fr* __restrict__ L0, uint32_t m, Fr* __restrict__ d, Fr* __restrict__ d2) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  d[i] = fr_from_mont(L0[2 * (size_t)i]);
+  d2[i] = fr_from_mont(L0[2 * (size_t)i + 1]);
+}
+__global__ void __launch_bounds__(TPB) ks_scalar_sub(Fr s, const Fr* __restrict__ a, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_sub(s, a[i]);
+}
+// o = s * a * b   (a, b canonical; s in Montgomery form)
+__global__ void __launch_bounds__(TPB) ks_mul_scale(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr s_m, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_mul(s_m, fr_mul(fr_to_mont(a[i]), b[i]));
+}
+// o[stride * i + off] = s * a[i] * b[i]
+__global__ void __launch_bounds__(TPB) ks_mul_scale_strided(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr s_m, Fr* __restrict__ o, size_t n,
+                                                            uint32_t stride, uint32_t off) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[(size_t)stride * i + off] = fr_mul(s_m, fr_mul(fr_to_mont(a[i]), b[i]));
+}
+__global__ void __launch_bounds__(TPB) ks_scale(const Fr* __restrict__ a, Fr s_m, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_mul(s_m, a[i]);
+}
+__global__ void __launch_bounds__(TPB) ks_mul(const Fr* __restrict__ a, const Fr* __restrict__ b, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_mul(fr_to_mont(a[i]), b[i]);
+}
+__global__ void __launch_bounds__(TPB) ks_fill_one(Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_one_canon();
+}
+__global__ void __launch_bounds__(TPB) ks_dot_partial(const Fr* __restrict__ a, const Fr* __restrict__ b, size_t n, Fr* __restrict__ partial) {
+  __shared__ Fr sh[TPB];
+  Fr s = fr_zero();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    s = fr_add(s, fr_mul(fr_to_mont(a[i]), b[i]));
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = TPB / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+// accumulate_m_values on the TRANSPOSED matrices: thread j owns wire j and sums (A_ij + delta B_ij + delta^2 C_ij) L_i over the
+// rows i that mention it (src/srs.rs:53-84 walks the rows and scatters; a gather per wire needs no atomics).  One CSR per
+// matrix over the wires: col = row index, cid = coefficient id.
+struct CsrT {
+  const uint32_t* ptr;
+  const uint32_t* row;
+  const uint32_t* cid;
+};
+__global__ void __launch_bounds__(TPB) ks_m_values(CsrT A, CsrT B, CsrT C, const Fr* __restrict__ coeffs_m /* Montgomery */, const Fr* __restrict__ l_tau,
+                                                   Fr delta_m, Fr delta2_m, Fr eps_m, uint32_t n_wires, Fr* __restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_wires) return;
+  auto gather = [&](const CsrT& M) {
+    Fr acc = fr_zero();
+    for (uint32_t k = M.ptr[j]; k < M.ptr[j + 1]; ++k) acc = fr_add(acc, fr_mul(coeffs_m[M.cid[k]], l_tau[M.row[k]]));
+    return acc;
+  };
+  Fr v = fr_add(fr_add(gather(A), fr_mul(delta_m, gather(B))), fr_mul(delta2_m, gather(C)));
+  out[j] = fr_mul(eps_m, v);
+}
+__global__ void __launch_bounds__(TPB) ks_to_mont(const Fr* __restrict__ a, Fr* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = fr_to_mont(a[i]);
+}
+// evaluations of Z_S on the 2m leaves: 0 on S's own half, 1 / zinv_other on the other half
+__global__ void __launch_bounds__(TPB) ks_vanish_evals(const Fr* __restrict__ z_other /* canonical Z_S on the other half */, uint32_t m, int which,
+                                                       Fr* __restrict__ ev) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  ev[2 * (size_t)i + which] = fr_zero();
+  ev[2 * (size_t)i + 1 - which] = z_other[i];
+}
+__global__ void __launch_bounds__(TPB) ks_check_monic(const Fr* __restrict__ co, uint32_t m, unsigned int* bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // coefficients m .. 2m-1
+  if (i >= m) return;
+  const Fr c = co[(size_t)m + i];
+  const bool ok = i == 0 ? fr_eq(c, fr_one_canon()) : fr_is_zero(c);
+  if (!ok) atomicExch(bad, 1u);
+}
+
+struct File {
+  const uint8_t* p = nullptr;
+  size_t len = 0;
+  int fd = -1;
+  ~File() {
+    if (p) munmap((void*)p, len);
+    if (fd >= 0) close(fd);
+  }
+  int open_ro(const char* path) {
+    fd = ::open(path, O_RDONLY);
+    if (fd < 0) return DVP_EIO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size <= 0) return DVP_EIO;
+    len = (size_t)st.st_size;
+    void* m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return DVP_EIO;
+    p = (const uint8_t*)m;
+    return DVP_OK;
+  }
+};
+
+// wire-major copy of a row-major CSR (counting sort by wire; stable, so rows ascend inside a wire)
+void transpose(uint32_t n_rows, uint32_t n_wires, const uint32_t* rp, const uint32_t* wire, const uint32_t* cid, std::vector<uint32_t>& tp,
+               std::vector<uint32_t>& trow, std::vector<uint32_t>& tcid) {
+  const size_t nnz = rp[n_rows];
+  tp.assign((size_t)n_wires + 1, 0);
+  for (size_t k = 0; k < nnz; ++k) ++tp[wire[k] + 1];
+  for (uint32_t j = 0; j < n_wires; ++j) tp[j + 1] += tp[j];
+  trow.resize(nnz ? nnz : 1);
+  tcid.resize(nnz ? nnz : 1);
+  std::vector<uint32_t> cur(tp.begin(), tp.end() - 1);
+  for (uint32_t r = 0; r < n_rows; ++r)
+    for (uint32_t k = rp[r]; k < rp[r + 1]; ++k) {
+      const uint32_t pos = cur[wire[k]]++;
+      trow[pos] = r;
+      tcid[pos] = cid[k];
+    }
+}
+
+int up(DevBuf& b, const void* h, size_t bytes) {
+  DVP_TRY(b.alloc(bytes));
+  if (bytes) DVP_HIP(hipMemcpy(b.p, h, bytes, hipMemcpyHostToDevice));
+  return DVP_OK;
+}
+Fr load_fr(const uint64_t v[4]) {
+  Fr r;
+  memcpy(r.v, v, 32);
+  return r;
+}
+}  // namespace
+}  // namespace dvp
+
+using namespace dvp;
+
+// out_scalars (optional, host, (n_wires + 5 m) x 4 u64): the discrete logs of the bases written, in file order g_m | g_q |
+// g_k_0 | g_k_1 | g_k_2 -- what a test pins the proof's commitments with.  *out_n_wires / *out_log2_m (optional) report the sizes.
+extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
+                                      uint32_t n_public, int write_precomputes, uint64_t* out_scalars, size_t out_cap, uint32_t* out_n_wires,
+                                      uint32_t* out_log2_m) {
+  if (!tau || !delta || !epsilon || !cache_dir) return DVP_EINVAL;
+  const Fr tau_c = load_fr(tau), delta_c = load_fr(delta), eps_c = load_fr(epsilon);
+  if (!fr_is_canonical(tau_c) || !fr_is_canonical(delta_c) || !fr_is_canonical(eps_c)) return DVP_EINVAL;
+  if (fr_is_zero(tau_c) || fr_is_zero(delta_c) || fr_is_zero(eps_c)) return DVP_EINVAL;  // src/srs.rs:199-201
+  const std::string dir(cache_dir);
+  auto path = [&](const char* name) { return dir + "/" + name; };
+  // ---- the circuit (src/gnark_r1cs.rs:121-185) ----
+  File dump;
+  DVP_TRY(dump.open_ro(path("r1cs_to_dvsnark").c_str()));  // R1CS_CONSTRAINTS_FILE, src/artifacts.rs:76
+  uint32_t n_coeffs = 0, n_rows = 0, n_wires = 0;
+  uint64_t nnz[3] = {0, 0, 0};
+  DVP_TRY(dvp_r1cs_dump_sizes(dump.p, dump.len, &n_coeffs, &n_rows, nnz, &n_wires));
+  if (n_rows == 0 || n_wires < 1 + (uint64_t)n_public) return DVP_EINVAL;
+  for (int k = 0; k < 3; ++k)
+    if (nnz[k] > 0xffffffffull) return DVP_EINVAL;
+  uint32_t log_m = 0;
+  while ((1ull << log_m) < n_rows) ++log_m;  // next_power_of_two, src/gnark_r1cs.rs:291
+  if (log_m < 1) log_m = 1;
+  if (log_m > DVP_MAX_LOG2_CONSTRAINTS) return DVP_EINVAL;
+  const size_t m = (size_t)1 << log_m;
+  if (out_n_wires) *out_n_wires = n_wires;
+  if (out_log2_m) *out_log2_m = log_m;
+  if (out_scalars && out_cap < (size_t)n_wires + 5 * m) return DVP_EINVAL;
+  std::vector<uint64_t> coeffs((size_t)4 * n_coeffs);
+  std::vector<uint32_t> rp[3], wi[3], ci[3];
+  uint32_t *rpp[3], *wip[3], *cip[3];
+  for (int k = 0; k < 3; ++k) {
+    rp[k].resize((size_t)n_rows + 1);
+    wi[k].resize(nnz[k] ? nnz[k] : 1);
+    ci[k].resize(nnz[k] ? nnz[k] : 1);
+    rpp[k] = rp[k].data(); wip[k] = wi[k].data(); cip[k] = ci[k].data();
+  }
+  DVP_TRY(dvp_r1cs_dump_fill(dump.p, dump.len, coeffs.data(), rpp, wip, cip));
+  DevBuf d_coeffs, tptr[3], trow[3], tcid[3];
+  DVP_TRY(up(d_coeffs, coeffs.data(), (size_t)n_coeffs * 32));
+  for (int k = 0; k < 3; ++k) {
+    std::vector<uint32_t> a, b, c;
+    transpose(n_rows, n_wires, rpp[k], wip[k], cip[k], a, b, c);
+    DVP_TRY(up(tptr[k], a.data(), a.size() * 4));
+    DVP_TRY(up(trow[k], b.data(), b.size() * 4));
+    DVP_TRY(up(tcid[k], c.data(), c.size() * 4));
+    rp[k] = std::vector<uint32_t>(); wi[k] = std::vector<uint32_t>(); ci[k] = std::vector<uint32_t>();
+  }
+  // ---- the domains and their tables (TREE_2N, src/srs.rs:216-346) ----
+  dvp_ecfft* tree = nullptr;
+  DVP_TRY(dvp_ecfft_create(log_m + 1, 0, 0, &tree));
+  struct TreeGuard { dvp_ecfft* t; ~TreeGuard() { if (t) dvp_ecfft_destroy(t); } } tree_guard{tree};
+  hipStream_t st = nullptr;
+  DevBuf d, d2, bar, z2inv, bard, z2dinv, t1, l_tau, l_taud, sc;
+  for (DevBuf* b : {&d, &d2, &bar, &z2inv, &bard, &z2dinv, &t1, &l_tau, &l_taud}) DVP_TRY(b->alloc(m * sizeof(Fr)));
+  const size_t n_sc = (size_t)n_wires + 5 * m;  // g_m | g_q | g_k_0 | g_k_1 | g_k_2
+  DVP_TRY(sc.alloc(n_sc * sizeof(Fr)));
+  Fr* s_gm = sc.as<Fr>();
+  Fr* s_gq = s_gm + n_wires;
+  Fr* s_k0 = s_gq + m;
+  Fr* s_k1 = s_k0 + m;
+  Fr* s_k2 = s_k1 + m;
+  const dim3 gm(cdiv(m, TPB)), bt(TPB);
+  hipLaunchKernelGGL(ks_domains, gm, bt, 0, st, tree->layer(0), (uint32_t)m, d.as<Fr>(), d2.as<Fr>());
+  DVP_TRY(ecfft_domain_tables_dev(tree, 0, bar.as<Fr>(), z2inv.as<Fr>(), st));    // 1/Z_D'(D_i),  1/Z_D(D'_i)
+  DVP_TRY(ecfft_domain_tables_dev(tree, 1, bard.as<Fr>(), z2dinv.as<Fr>(), st));  // 1/Z_D''(D'_i), 1/Z_D'(D_i)
+  uint64_t zt[4], zdt[4];
+  DVP_TRY(dvp_ecfft_vanish_at(tree, 0, tau, zt));
+  DVP_TRY(dvp_ecfft_vanish_at(tree, 1, tau, zdt));
+  const Fr z_tau = load_fr(zt), zd_tau = load_fr(zdt);
+  if (fr_is_zero(z_tau) || fr_is_zero(zd_tau)) return DVP_EINVAL;  // tau lies in a domain
+  const Fr z_tau_m = fr_to_mont(z_tau), zd_tau_m = fr_to_mont(zd_tau), delta_m = fr_to_mont(delta_c), eps_m = fr_to_mont(eps_c);
+  const Fr delta2_m = fr_to_mont(fr_mul(delta_m, delta_c));  // fr_mul(Montgomery, canonical) = canonical product
+  // L_i(tau), L'_i(tau)
+  hipLaunchKernelGGL(ks_scalar_sub, gm, bt, 0, st, tau_c, d.as<Fr>(), t1.as<Fr>(), m);
+  DVP_TRY(batch_inverse_dev(t1.as<Fr>(), m, st));
+  hipLaunchKernelGGL(ks_mul_scale, gm, bt, 0, st, t1.as<Fr>(), bar.as<Fr>(), z_tau_m, l_tau.as<Fr>(), m);
+  hipLaunchKernelGGL(ks_scalar_sub, gm, bt, 0, st, tau_c, d2.as<Fr>(), t1.as<Fr>(), m);
+  DVP_TRY(batch_inverse_dev(t1.as<Fr>(), m, st));
+  hipLaunchKernelGGL(ks_mul_scale, gm, bt, 0, st, t1.as<Fr>(), bard.as<Fr>(), zd_tau_m, l_taud.as<Fr>(), m);
+  // g_k_0 = L(tau), g_k_1 = delta L(tau), g_k_2 = delta^2 x the unified-domain values, interleaved [D_i, D'_i] (src/ec_fft.rs:445-448)
+  DVP_HIP(hipMemcpyAsync(s_k0, l_tau.p, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(ks_scale, gm, bt, 0, st, l_tau.as<Fr>(), delta_m, s_k1, m);
+  const Fr zd_d2_m = fr_to_mont(fr_mul(delta2_m, zd_tau)), z_d2_m = fr_to_mont(fr_mul(delta2_m, z_tau));
+  hipLaunchKernelGGL(ks_mul_scale_strided, gm, bt, 0, st, l_tau.as<Fr>(), z2dinv.as<Fr>(), zd_d2_m, s_k2, m, 2u, 0u);
+  hipLaunchKernelGGL(ks_mul_scale_strided, gm, bt, 0, st, l_taud.as<Fr>(), z2inv.as<Fr>(), z_d2_m, s_k2, m, 2u, 1u);
+  // g_q = eps Z_D(tau) delta^2 L'(tau)
+  const Fr gq_m = fr_to_mont(fr_mul(eps_m, fr_mul(delta2_m, z_tau)));
+  hipLaunchKernelGGL(ks_scale, gm, bt, 0, st, l_taud.as<Fr>(), gq_m, s_gq, m);
+  // g_m = eps m(tau, delta): gather per wire over the transposed matrices
+  {
+    DevBuf coeffs_m;
+    DVP_TRY(coeffs_m.alloc((size_t)(n_coeffs ? n_coeffs : 1) * sizeof(Fr)));
+    if (n_coeffs) hipLaunchKernelGGL(ks_to_mont, dim3(cdiv(n_coeffs, TPB)), bt, 0, st, d_coeffs.as<Fr>(), coeffs_m.as<Fr>(), (size_t)n_coeffs);
+    CsrT A{tptr[0].as<uint32_t>(), trow[0].as<uint32_t>(), tcid[0].as<uint32_t>()};
+    CsrT B{tptr[1].as<uint32_t>(), trow[1].as<uint32_t>(), tcid[1].as<uint32_t>()};
+    CsrT Cm{tptr[2].as<uint32_t>(), trow[2].as<uint32_t>(), tcid[2].as<uint32_t>()};
+    hipLaunchKernelGGL(ks_m_values, dim3(cdiv(n_wires, TPB)), bt, 0, st, A, B, Cm, coeffs_m.as<Fr>(), l_tau.as<Fr>(), delta_m, delta2_m, eps_m,
+                       n_wires, s_gm);
+    DVP_HIP(hipGetLastError());
+    DVP_HIP(hipStreamSynchronize(st));
+  }
+  // the Vandermonde fold C' = C - D: wire 1 + j of EVERY row carries -d_i^j (src/gnark_r1cs.rs:333-386)
+  if (n_public) {
+    DevBuf pw, part;
+    const uint32_t nb = std::min<uint32_t>(cdiv(m, TPB), 1024u);
+    DVP_TRY(pw.alloc(m * sizeof(Fr)));
+    DVP_TRY(part.alloc((size_t)nb * sizeof(Fr)));
+    hipLaunchKernelGGL(ks_fill_one, gm, bt, 0, st, pw.as<Fr>(), m);
+    std::vector<Fr> hp(nb);
+    const Fr ed2_m = fr_to_mont(fr_mul(eps_m, fr_mul(delta2_m, fr_one_canon())));  // eps delta^2
+    for (uint32_t j = 0; j < n_public; ++j) {
+      hipLaunchKernelGGL(ks_dot_partial, dim3(nb), bt, 0, st, pw.as<Fr>(), l_tau.as<Fr>(), m, part.as<Fr>());
+      DVP_HIP(hipMemcpyAsync(hp.data(), part.p, (size_t)nb * sizeof(Fr), hipMemcpyDeviceToHost, st));
+      Fr cur;
+      DVP_HIP(hipMemcpyAsync(&cur, s_gm + 1 + j, sizeof(Fr), hipMemcpyDeviceToHost, st));
+      DVP_HIP(hipStreamSynchronize(st));
+      Fr dot = fr_zero();
+      for (uint32_t k = 0; k < nb; ++k) dot = fr_add(dot, hp[k]);
+      cur = fr_sub(cur, fr_mul(ed2_m, dot));
+      DVP_HIP(hipMemcpyAsync(s_gm + 1 + j, &cur, sizeof(Fr), hipMemcpyHostToDevice, st));
+      DVP_HIP(hipStreamSynchronize(st));
+      if (j + 1 < n_public) hipLaunchKernelGGL(ks_mul, gm, bt, 0, st, pw.as<Fr>(), d.as<Fr>(), pw.as<Fr>(), m);
+    }
+  }
+  DVP_HIP(hipGetLastError());
+  if (out_scalars) {
+    DVP_HIP(hipMemcpyAsync(out_scalars, sc.p, n_sc * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+  }
+  // ---- compute_srs_matrices: one batched fixed-base multiplication + encoding per vector, then the files (src/srs.rs:126-167) ----
+  {
+    static const char* const names[5] = {"g_m", "g_q", "g_k_0", "g_k_1", "g_k_2"};  // src/artifacts.rs:18-27
+    const Fr* vec[5] = {s_gm, s_gq, s_k0, s_k1, s_k2};
+    const size_t cnt[5] = {n_wires, m, m, m, 2 * m};
+    DevBuf pts, inf, enc;
+    DVP_TRY(pts.alloc(2 * m > n_wires ? 2 * m * sizeof(Aff) : (size_t)n_wires * sizeof(Aff)));
+    DVP_TRY(inf.alloc(2 * m > n_wires ? 2 * m : (size_t)n_wires));
+    DVP_TRY(enc.alloc((2 * m > n_wires ? 2 * m : (size_t)n_wires) * 30));
+    std::vector<uint8_t> host;
+    for (int i = 0; i < 5; ++i) {
+      DVP_TRY(mulgen_dev(vec[i], cnt[i], pts.as<Aff>(), inf.as<uint8_t>(), st));
+      DVP_TRY(encode_dev(pts.as<Aff>(), inf.as<uint8_t>(), cnt[i], enc.as<uint8_t>(), st));
+      host.resize(cnt[i] * 30);
+      DVP_HIP(hipMemcpyAsync(host.data(), enc.p, cnt[i] * 30, hipMemcpyDeviceToHost, st));
+      DVP_HIP(hipStreamSynchronize(st));
+      DVP_TRY(dvp_file_point_vec_write(path(names[i]).c_str(), host.data(), cnt[i]));
+    }
+  }
+  // ---- the domain files (src/srs.rs:216-346; the reference quotes "2 hrs+" for z_poly at 2^23, src/artifacts.rs:92) ----
+  if (write_precomputes) {
+    static const char* const zp[2] = {"z_poly", "z_polyd"};
+    static const char* const bw[2] = {"bar_wts", "bar_wtsd"};
+    static const char* const zi[2] = {"z_vals2inv", "z_vals2dinv"};
+    DevBuf ev, co, flag;
+    DVP_TRY(ev.alloc(2 * m * sizeof(Fr)));
+    DVP_TRY(co.alloc(2 * m * sizeof(Fr)));
+    DVP_TRY(flag.alloc(4));
+    std::vector<uint64_t> host(4 * (m + 1));
+    for (int which = 0; which < 2; ++which) {
+      Fr* b = which ? bard.as<Fr>() : bar.as<Fr>();
+      Fr* z = which ? z2dinv.as<Fr>() : z2inv.as<Fr>();
+      DVP_HIP(hipMemcpyAsync(host.data(), b, m * sizeof(Fr), hipMemcpyDeviceToHost, st));
+      DVP_HIP(hipStreamSynchronize(st));
+      DVP_TRY(dvp_file_fr_vec_write(path(bw[which]).c_str(), host.data(), m));
+      DVP_HIP(hipMemcpyAsync(host.data(), z, m * sizeof(Fr), hipMemcpyDeviceToHost, st));
+      DVP_HIP(hipStreamSynchronize(st));
+      DVP_TRY(dvp_file_fr_vec_write(path(zi[which]).c_str(), host.data(), m));
+      // compute_vanishing_polynomial (src/ec_fft.rs:241-282): Z_S on the 2m leaves (0 on S, 1 / zinv on the other half) -> exit
+      DVP_HIP(hipMemcpyAsync(t1.p, z, m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+      DVP_TRY(batch_inverse_dev(t1.as<Fr>(), m, st));
+      hipLaunchKernelGGL(ks_vanish_evals, gm, bt, 0, st, t1.as<Fr>(), (uint32_t)m, which, ev.as<Fr>());
+      DVP_TRY(dvp_ecfft_exit_dev(tree, ev.p, co.p, st));
+      DVP_HIP(hipMemsetAsync(flag.p, 0, 4, st));
+      hipLaunchKernelGGL(ks_check_monic, gm, bt, 0, st, co.as<Fr>(), (uint32_t)m, flag.as<unsigned int>());
+      unsigned int bad = 0;
+      DVP_HIP(hipMemcpyAsync(&bad, flag.p, 4, hipMemcpyDeviceToHost, st));
+      DVP_HIP(hipMemcpyAsync(host.data(), co.p, (m + 1) * sizeof(Fr), hipMemcpyDeviceToHost, st));
+      DVP_HIP(hipStreamSynchronize(st));
+      if (bad) return DVP_EINVAL;  // not monic of degree m: the tree and the tables disagree
+      DVP_TRY(dvp_file_fr_vec_write(path(zp[which]).c_str(), host.data(), m + 1));
+    }
+  }
+  return DVP_OK;
+}
+
+extern "C" int dvp_setup_cache_dir(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
+                                   uint32_t n_public, int write_precomputes) {
+  return dvp_setup_cache_dir_ex(tau, delta, epsilon, cache_dir, n_public, write_precomputes, nullptr, 0, nullptr, nullptr);
+}

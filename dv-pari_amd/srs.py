@@ -33,7 +33,9 @@ class SRS:
 
 
 def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
-    """The scalars k with base = k*G for every SRS vector: verifier_runs_setup + compute_srs_matrices,
+    """(The in-memory flavour, for instances that exist only in python -- bench.py's synthetic circuits, the tests; the
+    cache_dir flavour below is one library call with every vector resident on the device, dvp_setup_cache_dir.)
+    The scalars k with base = k*G for every SRS vector: verifier_runs_setup + compute_srs_matrices,
     src/srs.rs:112-167,177-361 (Lagrange bases at tau through the barycentric formula,
     src/ec_fft.rs:340-390,424-450; accumulate_m_values, src/srs.rs:53-84)."""
     assert td.tau % P and td.delta % P and td.epsilon % P  # src/srs.rs:199-201
@@ -71,32 +73,39 @@ def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
 def verifier_runs_setup_cache_dir(td: Trapdoor, cache_dir, num_public_inputs: int, write_precomputes: bool = True,
                                   return_scalars: bool = False):
     """SRS::verifier_runs_setup(trapdoor, cache_dir, num_public_inputs, ..), src/srs.rs:177-361, as the reference
-    runs it: reads cache_dir/r1cs_to_dvsnark, writes g_m, g_q, g_k_0..2 as point-vector files
-    (compute_srs_matrices -> write_point_vec_to_file) and, with write_precomputes, the domain files a reference
-    prover/verifier would otherwise spend hours on (z_poly, z_polyd, bar_wts, bar_wtsd, z_vals2inv, z_vals2dinv).
-    Returns (instance, prover context with the SRS loaded)."""
+    runs it: ONE library call (dvp_setup_cache_dir, csrc/setup.hip) reads cache_dir/r1cs_to_dvsnark, computes the SRS
+    scalars on the device, writes g_m, g_q, g_k_0..2 as point-vector files (compute_srs_matrices ->
+    write_point_vec_to_file) and, with write_precomputes, the domain files a reference prover/verifier would otherwise
+    spend hours on (z_poly, z_polyd, bar_wts, bar_wtsd, z_vals2inv, z_vals2dinv).
+    Returns (instance, prover context with the SRS loaded from the files just written)."""
+    import ctypes as C
+
     from . import artifacts as A, io_utils
-    from .ec_fft import FFTree, compute_vanishing_polynomial
+    from ._native import lib, check, ptr
     from .proving import Prover
 
     os.makedirs(cache_dir, exist_ok=True)
-    inst = R1CSInstance.from_dump_file(os.path.join(cache_dir, A.R1CS_CONSTRAINTS_FILE), num_public_inputs)
+    t, d, e = (fr.limbs(x) for x in (td.tau, td.delta, td.epsilon))
+    scalars = None
+    if return_scalars:  # the discrete logs of the bases just written (tests pin the proof's commitments with them)
+        nw, lg = C.c_uint32(0), C.c_uint32(0)
+        inst = R1CSInstance.from_dump_file(os.path.join(cache_dir, A.R1CS_CONSTRAINTS_FILE), num_public_inputs)
+        m = inst.num_constraints
+        buf = np.zeros((inst.n_wires + 5 * m, 4), dtype=np.uint64)
+        check(lib.dvp_setup_cache_dir_ex(ptr(t), ptr(d), ptr(e), os.fsencode(cache_dir), num_public_inputs, int(write_precomputes),
+                                         ptr(buf), buf.shape[0], C.byref(nw), C.byref(lg)), "dvp_setup_cache_dir")
+        assert nw.value == inst.n_wires and (1 << lg.value) == m
+        o = inst.n_wires
+        scalars = (buf[:o], buf[o:o + m], [buf[o + m:o + 2 * m], buf[o + 2 * m:o + 3 * m], buf[o + 3 * m:]])
+    else:
+        check(lib.dvp_setup_cache_dir(ptr(t), ptr(d), ptr(e), os.fsencode(cache_dir), num_public_inputs, int(write_precomputes)),
+              "dvp_setup_cache_dir")
+        inst = R1CSInstance.from_dump_file(os.path.join(cache_dir, A.R1CS_CONSTRAINTS_FILE), num_public_inputs)
     pv = Prover(inst)
-    g_m, g_q, g_k = srs_scalars(pv, inst, td)
-    for name, sc in zip(A.SRS_FILES, (g_m, g_q, g_k[0], g_k[1], g_k[2])):
-        io_utils.write_point_vec_to_file(os.path.join(cache_dir, name), curve.point_scalar_mul_gen_batch_bytes(sc))
-    if write_precomputes:
-        tree2n = FFTree(2 * inst.num_constraints)
-        for which, (zp, bw, zi) in enumerate(((A.Z_POLY, A.BAR_WTS, A.Z_VALS2_INV), (A.Z_POLYD, A.BAR_WTSD, A.Z_VALS2D_INV))):
-            bar, zinv = tree2n.domain_tables(which)
-            io_utils.write_fr_vec_to_file(os.path.join(cache_dir, zp), compute_vanishing_polynomial(tree2n, which))
-            io_utils.write_fr_vec_to_file(os.path.join(cache_dir, bw), bar)
-            io_utils.write_fr_vec_to_file(os.path.join(cache_dir, zi), zinv)
-        tree2n.close()
     for which, name in enumerate(A.SRS_FILES):
         pv.set_srs_encoded(which, io_utils.read_point_vec_payload(os.path.join(cache_dir, name)))
-    if return_scalars:  # the discrete logs of the bases just written (tests pin the proof's commitments with them)
-        return inst, pv, (g_m, g_q, g_k)
+    if return_scalars:
+        return inst, pv, scalars
     return inst, pv
 
 

@@ -268,6 +268,17 @@ int dvp_fftr_sections(const char* path, uint32_t depth, uint8_t ids[13], uint64_
 int dvp_fftr_read_fr(const char* path, uint32_t depth, uint8_t section_id, uint64_t* out, size_t cap, size_t* n_elems);
 int dvp_fftr_write(const char* path, uint32_t n_sections, const uint8_t* ids, const uint64_t* const* data, const uint64_t* elems);
 
+/* SRS::verifier_runs_setup(trapdoor, cache_dir, num_public_inputs, ..) (src/srs.rs:177-361 -> compute_srs_matrices,
+ * src/srs.rs:112-167): reads cache_dir/r1cs_to_dvsnark, computes the five SRS scalar vectors on the device (Lagrange values
+ * at tau on D, D' and the unified domain through the barycentric formula, accumulate_m_values over the transposed matrices,
+ * the Vandermonde fold on the public wires), multiplies them onto the generator in batches and writes g_m, g_q, g_k_0,
+ * g_k_1, g_k_2 as point-vector files (src/io_utils.rs:42-124).  write_precomputes != 0 also writes z_poly, z_polyd, bar_wts,
+ * bar_wtsd, z_vals2inv, z_vals2dinv (Fr-vector files, src/artifacts.rs:86-110), so the directory is complete for a
+ * reference prover / verifier.  tau, delta, epsilon: canonical, non-zero (src/srs.rs:199-201: DVP_EINVAL otherwise, and when
+ * tau lies in an evaluation domain).  The is_fresh_setup / checksum bookkeeping of the reference is not part of this entry. */
+int dvp_setup_cache_dir(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
+                        uint32_t n_public, int write_precomputes);
+
 /* The loading half of Proof::prove (src/proving.rs:435-470,509-511,666-672): reads cache_dir/r1cs_to_dvsnark and the
  * SRS vectors g_m, g_q, g_k_0, g_k_1, g_k_2 (src/artifacts.rs:18-27,76), decodes the points on the GPU
  * (DVP_EDECODE = the reference's assert!(valid)) and returns a ready prover; the witness length is |g_m|. */

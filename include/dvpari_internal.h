@@ -60,6 +60,13 @@ int dvp_debug_recode_binary(const uint64_t* scalars, size_t n, int c_bits, uint3
  * digit is negative | w << 20 | |digit| (|digit| = 2^(c-1) is stored as key 0); *windows = ceil(234 / c_bits) */
 int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* windows);
 
+/* dvp_setup_cache_dir that also returns the discrete logs of the bases it wrote (host, (n_wires + 5 m) x 4 u64, file order
+ * g_m | g_q | g_k_0 | g_k_1 | g_k_2; NULL = not wanted; out_cap in elements) and the circuit's sizes: parity tests pin the SRS
+ * and the proof's commitments with them */
+int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
+                           uint32_t n_public, int write_precomputes, uint64_t* out_scalars, size_t out_cap, uint32_t* out_n_wires,
+                           uint32_t* out_log2_m);
+
 /* intermediates of the last proof, for parity tests (names: see prove.hip) */
 int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);
 

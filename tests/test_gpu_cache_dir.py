@@ -145,6 +145,62 @@ def test_toy_cache_dir_end_to_end(dvp, tmp_path):
     pv.close()
 
 
+@pytest.mark.parametrize("shape", ["toy", "sparse7", "sparse12"])
+def test_setup_cache_dir_entry_scalars(dvp, tmp_path, shape):
+    """dvp_setup_cache_dir (csrc/setup.hip: SRS::verifier_runs_setup behind the C ABI, src/srs.rs:177-361) against (i) the
+    oracle's brute-force setup (domain tables by products over the whole domain, accumulate_m_values row by row) where the
+    big-int oracle can go, and (ii) the python orchestration over the per-operation seams (dvp.srs.srs_scalars), which the
+    GPU tests of the prover already pin to the oracle; then the files: every point file decodes to scalar x G."""
+    A, g = dvp.artifacts, dvp.gnark_r1cs
+    cache = tmp_path / "c"
+    cache.mkdir()
+    if shape == "toy":
+        (cache / A.R1CS_CONSTRAINTS_FILE).write_bytes(py_dump(g.TOY_ROWS, g.TOY_COEFFS))
+        n_pub = 2
+    else:
+        inst0, pub, _ = g.synthetic_sparse(int(shape[6:]))
+        inst0.write_dump_file(cache / A.R1CS_CONSTRAINTS_FILE)
+        n_pub = len(pub)
+    rnd = random.Random(len(shape))
+    trap = (rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    td = dvp.srs.Trapdoor(*trap)
+    inst, pv, (g_m, g_q, g_k) = dvp.srs.verifier_runs_setup_cache_dir(td, cache, n_pub, write_precomputes=True, return_scalars=True)
+    m = inst.num_constraints
+    p_gm, p_gq, p_gk = dvp.srs.srs_scalars(pv, inst, td)
+    assert np.array_equal(g_m, p_gm) and np.array_equal(g_q, p_gq)
+    for j in range(3):
+        assert np.array_equal(g_k[j], p_gk[j]), j
+    if m <= 128:
+        rows = []
+        for i in range(inst.n_rows):
+            row = []
+            for mt in (inst.l, inst.r, inst.o):
+                a, b = int(mt.row_ptr[i]), int(mt.row_ptr[i + 1])
+                row.append([(int(mt.wire[k]), int(mt.coeff[k])) for k in range(a, b)])
+            rows.append(tuple(row))
+        st = o.setup_srs_scalars(o.FFTree(pv.log_m + 1), rows, from_limbs(inst.coeffs), n_pub, trap)
+        assert from_limbs(g_m) == st["g_m"] + [0] * (inst.n_wires - len(st["g_m"]))
+        assert from_limbs(g_q) == st["g_q"]
+        for j in range(3):
+            assert from_limbs(g_k[j]) == st["g_k"][j]
+        tb = st["tables"]
+        for name, key in ((A.BAR_WTS, "bar_wts"), (A.BAR_WTSD, "bar_wtsd"), (A.Z_VALS2_INV, "z_vals2inv"), (A.Z_VALS2D_INV, "z_vals2dinv"),
+                          (A.Z_POLY, "z_poly"), (A.Z_POLYD, "z_polyd")):
+            assert from_limbs(dvp.io_utils.read_fr_vec_from_file(cache / name)) == tb[key], name
+    # the point files hold scalar x generator, in the library's codec
+    for name, sc in zip(A.SRS_FILES, (g_m, g_q, g_k[0], g_k[1], g_k[2])):
+        enc = dvp.io_utils.read_point_vec_payload(cache / name)
+        assert np.array_equal(enc, dvp.curve.point_scalar_mul_gen_batch_bytes(sc)), name
+    # zero / non-canonical trapdoor entries are refused (src/srs.rs:199-201)
+    import ctypes as C
+    z = np.zeros(4, dtype=np.uint64)
+    t, d = dvp.fr.limbs(trap[0]), dvp.fr.limbs(trap[1])
+    from importlib import import_module
+    nat = import_module("dv-pari_amd._native")
+    assert dvp.lib.dvp_setup_cache_dir(nat.ptr(t), nat.ptr(d), nat.ptr(z), os.fsencode(str(cache)), n_pub, 0) == -1
+    pv.close()
+
+
 def test_sparse_cache_dir_with_witness_file(dvp, tmp_path):
     """BASELINE config #5 stand-in at 2^12: SP1-format dump + witness file in, proof out, verifier accepts; the
     Horner and the extend route for i(X) on D' give the same bytes."""
