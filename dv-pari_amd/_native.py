@@ -82,6 +82,8 @@ _SIGS = {
     "dvp_mulgen_batch_affine": (C.c_int, [u64p, sz, u64p, u8p]),
     "dvp_points_encode": (C.c_int, [u64p, u8p, sz, u8p]),
     "dvp_points_decode": (C.c_int, [u8p, sz, u64p, u8p]),
+    "dvp_codec_set_rule": (C.c_int, [C.c_int]),
+    "dvp_codec_get_rule": (C.c_int, []),
     "dvp_points_add": (C.c_int, [u64p, u8p, u64p, u8p, sz, u64p, u8p]),
     "dvp_prover_create": (C.c_int, [u32, u32, u32, C.POINTER(vp)]),
     "dvp_prover_destroy": (None, [vp]),

@@ -13,6 +13,8 @@
 //   P = (x,y) that is  w = sqrt(x + y/x + 1)  (lambda-coordinate of P plus one); neutral -> 0.
 //   Decoding: e = w^2 + w, solve x^2 + e x + 1 = 0 (half-trace), roots are x(P) and x(P+N) = 1/x;
 //   y = x (w^2 + 1 + x); keep the root whose point lies in E[r] = 4E (two trace tests).
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -48,20 +50,49 @@ __device__ __forceinline__ bool k233_on_curve(const Aff& p) {
   return gf_eq(lhs, rhs);
 }
 
-__device__ __forceinline__ void store30(uint8_t* dst, const Gf& w) {
-#pragma unroll
-  for (int b = 0; b < 30; ++b) dst[b] = (uint8_t)(w.w[b >> 2] >> (8 * (b & 3)));
+// ---- the encoding RULE as a run-time constant (dvp_codec_set_rule) -------------------------------------------------------
+// What is settled (tools/pin_xsk233.py): a point travels as ONE field element of 30 bytes from which the
+// decode equation x^2 + (w^2 + w + a) x + b = 0 recovers it, and w = y'/x on the N = (0,0) model satisfies it.  What one vector
+// from xs233 would settle is which equivalent presentation of that element the bytes hold.  Every candidate tools/pin_xsk233.py
+// enumerates (8 formulas x 2 views x 2 generator signs x "+1" x 2 byte orders) collapses -- on the curve sqrt(s/x) = y'/x =
+// sqrt(lambda), s/x = lambda = (y'/x)^2, and w(Q + N) = w(-Q) = w(Q) + 1 -- into the classes below (the formulas y/x and
+// "x alone" are not encodings of this family: their decode is a cubic / needs a sign bit).  rule =
+//   bit 0      the element is w + 1  (= the E[r] representative's own value, = the negated generator's convention)
+//   bit 1      bytes are big-endian
+//   bits 2..3  0: w = sqrt(s/x) itself   1: w^2 (= s/x = lambda)   2: sqrt(w) (= sqrt(y'/x))
+// Rule 0 is the candidate followed since round 1 (Pornin, ePrint 2022/1325, as recalled).  The neutral element is 30 zero bytes
+// under every rule.  A vector from a machine with cargo turns into `dvp_codec_set_rule(k)` (or DVP_CODEC_RULE=k), not a port.
+constexpr int CODEC_RULES = 12;
+__device__ __forceinline__ Gf codec_present(Gf w, int rule, const GfSqrTables& T) {
+  const int tr = (rule >> 2) & 3;
+  if (tr == 1) w = gf_sqr(w);
+  else if (tr == 2) w = gf_sqr_tab(gf_sqr_tab(w, T.t116), T.t116);  // sqrt = 232 squarings = two 116-step table passes
+  if (rule & 1) w.w[0] ^= 1u;
+  return w;
 }
-__device__ __forceinline__ Gf load30(const uint8_t* src, uint32_t* top_bits) {
+__device__ __forceinline__ Gf codec_absorb(Gf t, int rule, const GfSqrTables& T) {
+  if (rule & 1) t.w[0] ^= 1u;
+  const int tr = (rule >> 2) & 3;
+  if (tr == 1) t = gf_sqr_tab(gf_sqr_tab(t, T.t116), T.t116);
+  else if (tr == 2) t = gf_sqr(t);
+  return t;
+}
+__device__ __forceinline__ void store30(uint8_t* dst, const Gf& w, int rule) {
+  const bool be = (rule & 2) != 0;
+#pragma unroll
+  for (int b = 0; b < 30; ++b) dst[be ? 29 - b : b] = (uint8_t)(w.w[b >> 2] >> (8 * (b & 3)));
+}
+__device__ __forceinline__ Gf load30(const uint8_t* src, uint32_t* top_bits, int rule) {
+  const bool be = (rule & 2) != 0;
   Gf w = gf_zero();
 #pragma unroll
-  for (int b = 0; b < 30; ++b) w.w[b >> 2] |= (uint32_t)src[b] << (8 * (b & 3));
+  for (int b = 0; b < 30; ++b) w.w[b >> 2] |= (uint32_t)src[be ? 29 - b : b] << (8 * (b & 3));
   *top_bits = w.w[7] >> 9;
   return w;
 }
 
 __global__ void __launch_bounds__(256)
-k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n, GfSqrTables T, uint8_t* __restrict__ out) {
+k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n, GfSqrTables T, uint8_t* __restrict__ out, int rule) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,14 +102,15 @@ k_encode(const Aff* __restrict__ pts, const uint8_t* __restrict__ inf, size_t n,
     Aff p = pts[i];
     Gf lam1 = gf_add(gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L)), gf_one());
     w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);  // sqrt = 232 squarings = two 116-step table passes
+    if (rule) w = codec_present(w, rule, T);
   }
-  store30(out + i * 30, w);
+  store30(out + i * 30, w, rule);
 }
 
 // one point (a proof's commit_p / kzg_k), latency only: one quad of lanes through the quad-cooperative multiplier
 // (45 us against 90 for a single lane), infinity flag read as the u32 the MSM writes
 __global__ void __launch_bounds__(64)
-k_encode_point(const Aff* __restrict__ pt, const uint32_t* __restrict__ inf32, GfSqrTables T, uint8_t* __restrict__ out) {
+k_encode_point(const Aff* __restrict__ pt, const uint32_t* __restrict__ inf32, GfSqrTables T, uint8_t* __restrict__ out, int rule) {
   extern __shared__ char lds_raw[];
   GfLdsQ L = gf_ldsq_init(lds_raw);
   if (threadIdx.x >= 4) return;
@@ -87,19 +119,20 @@ k_encode_point(const Aff* __restrict__ pt, const uint32_t* __restrict__ inf32, G
     Aff p = *pt;
     Gf lam1 = gf_add(gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L)), gf_one());
     w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
+    if (rule) w = codec_present(w, rule, T);
   }
-  if (threadIdx.x == 0) store30(out, w);
+  if (threadIdx.x == 0) store30(out, w, rule);
 }
 
 __global__ void __launch_bounds__(256, 2)
 k_decode(const uint8_t* __restrict__ enc, size_t n, GfSqrTables T, Aff* __restrict__ out, uint8_t* __restrict__ inf,
-         unsigned long long* __restrict__ err) {
+         unsigned long long* __restrict__ err, int rule) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t top;
-  Gf w = load30(enc + i * 30, &top);
+  Gf w = load30(enc + i * 30, &top, rule);
   Aff r;
   r.x = gf_zero();
   r.y = gf_zero();
@@ -107,6 +140,7 @@ k_decode(const uint8_t* __restrict__ enc, size_t n, GfSqrTables T, Aff* __restri
   if (ok && gf_is_zero(w)) {
     is_inf = true;
   } else if (ok) {
+    if (rule) w = codec_absorb(w, rule, T);
     Gf w2 = gf_sqr(w);
     Gf e = gf_add(w2, w);
     ok = !gf_is_zero(e);
@@ -206,6 +240,19 @@ k_mulgen(const uint32_t* __restrict__ scalars, size_t n, const Aff* __restrict__
   out_inf[i] = fin ? 0 : 1;
 }
 
+// the rule in force: DVP_CODEC_RULE from the environment at first use, dvp_codec_set_rule at run time
+static std::atomic<int> g_codec_rule{-1};
+static int codec_rule() {
+  int r = g_codec_rule.load();
+  if (r < 0) {
+    const char* e = getenv("DVP_CODEC_RULE");
+    r = e ? atoi(e) : 0;
+    if (r < 0 || r >= CODEC_RULES) r = 0;
+    g_codec_rule.store(r);
+  }
+  return r;
+}
+
 static std::mutex g_gen_mu;
 static Aff* g_gen_tab[16] = {nullptr};
 
@@ -255,7 +302,7 @@ int mulgen_dev(const void* d_scalars, size_t n, Aff* d_out, uint8_t* d_inf, hipS
 int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out, hipStream_t st) {
   GfSqrTables T;
   DVP_TRY(gf_sqr_tables(&T, st));
-  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDSK_BYTES_PER_WAVE, st, d_pts, d_inf, n, T, d_out);
+  hipLaunchKernelGGL(k_encode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDSK_BYTES_PER_WAVE, st, d_pts, d_inf, n, T, d_out, codec_rule());
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
@@ -263,7 +310,7 @@ int encode_dev(const Aff* d_pts, const uint8_t* d_inf, size_t n, uint8_t* d_out,
 int encode_point_dev(const Aff* d_pt, const uint32_t* d_inf32, uint8_t* d_out, hipStream_t st) {
   GfSqrTables T;
   DVP_TRY(gf_sqr_tables(&T, st));
-  hipLaunchKernelGGL(k_encode_point, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, d_pt, d_inf32, T, d_out);
+  hipLaunchKernelGGL(k_encode_point, dim3(1), dim3(64), GF_LDS_BYTES_PER_WAVE, st, d_pt, d_inf32, T, d_out, codec_rule());
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
@@ -275,7 +322,7 @@ int decode_dev(const uint8_t* d_enc, size_t n, Aff* d_out, uint8_t* d_inf, hipSt
   GfSqrTables T;
   DVP_TRY(gf_sqr_tables(&T, st));
   hipLaunchKernelGGL(k_decode, dim3(cdiv(n, 256)), dim3(256), 4 * GF_LDSK_BYTES_PER_WAVE, st, d_enc, n, T, d_out, d_inf,
-                     err.as<unsigned long long>());
+                     err.as<unsigned long long>(), codec_rule());
   DVP_HIP(hipGetLastError());
   return read_err(err.as<unsigned long long>(), st, DVP_EDECODE);
 }
@@ -409,3 +456,12 @@ extern "C" int dvp_msm_xsk233(const uint8_t* scalars, const uint8_t* bases_enc, 
   DVP_HIP(hipMemcpy(out_enc, de.p, 30, hipMemcpyDeviceToHost));
   return DVP_OK;
 }
+
+// which presentation of the encoded field element the 30 bytes hold (see the table at the top of this file); 0 = the default
+// candidate.  Affects every later encode / decode of the process (SRS files written under one rule must be read under it).
+extern "C" int dvp_codec_set_rule(int rule) {
+  if (rule < 0 || rule >= CODEC_RULES) return DVP_EINVAL;
+  g_codec_rule.store(rule);
+  return DVP_OK;
+}
+extern "C" int dvp_codec_get_rule(void) { return codec_rule(); }

@@ -154,6 +154,14 @@ int dvp_mulgen_batch_affine(const uint64_t* scalars, size_t n, uint64_t* out_xy 
 /* CurvePoint::to_bytes / from_bytes over vectors (src/curve.rs:93-109, src/io_utils.rs:217-226) */
 int dvp_points_encode(const uint64_t* xy, const uint8_t* inf, size_t n, uint8_t* out_enc);
 int dvp_points_decode(const uint8_t* enc, size_t n, uint64_t* out_xy, uint8_t* out_inf);
+/* Which presentation of the encoded field element the 30 bytes of a point hold.  The reference reaches its codec through
+ * xs233 (src/curve.rs:93-109), whose source is not available offline and for which the reference holds no known-answer
+ * bytes, so the rule is selectable: rule = bit 0: the element is w + 1 | bit 1: big-endian bytes | bits 2..3: 0 w = sqrt(s/x),
+ * 1 w^2 (= s/x = lambda), 2 sqrt(w) -- the classes every candidate of tools/pin_xsk233.py falls into; 0 (default) is the
+ * candidate followed so far.  tools/pin_xsk233.py <k> <bytes of k G from xs233> names the number to set.  Process-wide; files
+ * written under one rule must be read under it.  DVP_CODEC_RULE in the environment sets the initial value. */
+int dvp_codec_set_rule(int rule);
+int dvp_codec_get_rule(void);
 /* CurvePoint::add over two vectors (src/curve.rs:84-90; complete: doubling, inverses, neutral).  Equality of two
  * CurvePoints (src/curve.rs:69-76) is equality of (x, y, infinity) on this representation. */
 int dvp_points_add(const uint64_t* a_xy, const uint8_t* a_inf, const uint64_t* b_xy, const uint8_t* b_inf, size_t n, uint64_t* out_xy,

@@ -275,28 +275,50 @@ def k233_in_prime_subgroup_fast(pt) -> bool:
 XSK_B = 1  # sqrt(B)
 
 
-def xsk233_encode(p_internal) -> bytes:
-    """Restates CurvePoint::to_bytes -> xsk233_encode (src/curve.rs:93-100)."""
+XSK_RULES = 12  # rule = bit 0: "+1" (the E[r] representative's own value) | bit 1: big-endian bytes | bits 2..3: 0 w, 1 w^2, 2 sqrt(w)
+
+
+def xsk233_encode(p_internal, rule: int = 0) -> bytes:
+    """Restates CurvePoint::to_bytes -> xsk233_encode (src/curve.rs:93-100).  `rule` selects which equivalent presentation of
+    the encoded field element the bytes hold (codec.hip: dvp_codec_set_rule; 0 = the candidate followed by default); every
+    candidate tools/pin_xsk233.py enumerates is one of them, each computed HERE from its own defining formula."""
     if p_internal is None:
         return bytes(30)
+    assert 0 <= rule < XSK_RULES
     q = k233_add(p_internal, N_STD)
     assert q is not None, "N itself is not an element of E[r]"
-    x, y = q
+    view = p_internal if rule & 1 else q  # w(Q + N) = w(Q) + 1: the "+1" rules are the value of the E[r] representative itself
+    x, y = view
     yp = y ^ 1
     s = yp ^ gf_sqr(x) ^ gf_mul(K233_A, x) ^ XSK_B
-    w = gf_sqrt(gf_mul(s, gf_inv(x)))
-    return w.to_bytes(30, "little")
+    s_over_x = gf_mul(s, gf_inv(x))
+    tr = (rule >> 2) & 3
+    if tr == 0:
+        t = gf_sqrt(s_over_x)                     # w = sqrt(s/x)  (= y'/x = sqrt(lambda))
+    elif tr == 1:
+        t = s_over_x                              # s/x (= lambda = x + y/x on the standard model)
+        assert t == x ^ gf_mul(y, gf_inv(x))
+    else:
+        t = gf_sqrt(gf_mul(yp, gf_inv(x)))        # sqrt(y'/x)
+    return t.to_bytes(30, "big" if rule & 2 else "little")
 
 
-def xsk233_decode(buf: bytes):
+def xsk233_decode(buf: bytes, rule: int = 0):
     """Restates CurvePoint::from_bytes -> xsk233_decode (src/curve.rs:103-109).
     Returns (internal point, ok)."""
-    assert len(buf) == 30
-    w = int.from_bytes(buf, "little")
+    assert len(buf) == 30 and 0 <= rule < XSK_RULES
+    w = int.from_bytes(buf, "big" if rule & 2 else "little")
     if w >> 233:
         return None, False
     if w == 0:
         return None, True  # neutral N  -> internal infinity
+    if rule & 1:
+        w ^= 1
+    tr = (rule >> 2) & 3
+    if tr == 1:
+        w = gf_sqrt(w)
+    elif tr == 2:
+        w = gf_sqr(w)
     e = gf_sqr(w) ^ w ^ K233_A
     if e == 0:
         return None, False

@@ -116,6 +116,42 @@ def test_codec_roundtrip_and_invalid(dvp):
     assert seen_bad > 0
 
 
+@pytest.mark.parametrize("rule", range(1, 12))
+def test_codec_rule_variants(dvp, rule):
+    """dvp_codec_set_rule: every presentation of the encoded element that tools/pin_xsk233.py can name (w / w^2 / sqrt w,
+    "+1", byte order) -- GPU encode == the oracle's own formula for that rule, GPU decode inverts it, invalid bytes agree, and a
+    proof-shaped round trip (mulgen -> bytes -> wire-format MSM) holds under the rule.  Rule 0 is the default everywhere else."""
+    ks = [1, 2, 3, o.P - 1] + [random.Random(50 + rule).randrange(o.P) for _ in range(12)]
+    try:
+        dvp.check(dvp.lib.dvp_codec_set_rule(rule))
+        assert dvp.lib.dvp_codec_get_rule() == rule
+        enc = dvp.curve.point_scalar_mul_gen_batch_bytes(to_limbs(ks + [0]))
+        for i, k in enumerate(ks):
+            assert enc[i].tobytes() == o.xsk233_encode(co.k233_mulgen(k), rule), (rule, k)
+            assert o.xsk233_decode(enc[i].tobytes(), rule) == (co.k233_mulgen(k), True)
+        assert enc[-1].tobytes() == bytes(30)
+        xy, inf = dvp.curve.from_bytes(enc)
+        for i, k in enumerate(ks):
+            assert np_to_pt(xy[i], inf[i]) == co.k233_mulgen(k)
+        assert inf[-1] == 1 and (dvp.curve.to_bytes(xy, inf) == enc).all()
+        rnd = random.Random(60 + rule)
+        for _ in range(8):
+            w = rnd.getrandbits(233).to_bytes(30, "big" if rule & 2 else "little")
+            exp, ok = o.xsk233_decode(w, rule)
+            try:
+                x, i_ = dvp.curve.from_bytes(np.frombuffer(w, dtype=np.uint8))
+                assert ok and np_to_pt(x[0], i_[0]) == exp
+            except dvp.DvpError as e:
+                assert not ok and e.status == -2
+        n = 64
+        k, s = rand_fr_np(n, 70 + rule), rand_fr_np(n, 71 + rule)
+        out = dvp.curve.multi_scalar_mul_bytes(s.view(np.uint8).reshape(n, 32), dvp.curve.point_scalar_mul_gen_batch_bytes(k))
+        assert out == o.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)), rule)
+    finally:
+        dvp.check(dvp.lib.dvp_codec_set_rule(0))
+    assert dvp.lib.dvp_codec_set_rule(12) == -1 and dvp.lib.dvp_codec_get_rule() == 0
+
+
 def test_msm_wire_format(dvp):
     """scalars 32-B LE + bases 30-B encodings in, 30-B encoding out (the reference's file payloads)."""
     n = 300

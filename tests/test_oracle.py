@@ -96,6 +96,19 @@ def test_xsk233_codec_candidate_roundtrip():
         w = rnd.getrandbits(233).to_bytes(30, "little")
         assert o.xsk233_decode(w) == co.xsk233_decode(w)
     assert o.xsk233_decode(b"\xff" * 30)[1] is False
+    # the selectable presentations (dvp_codec_set_rule): every rule round-trips, rules are pairwise different encodings of the
+    # same point, and the identities that collapse pin_xsk233.py's candidate list hold: w(Q + N) = w(Q) + 1 = w(-Q)
+    for e in VEC["xsk233_candidate"][:6]:
+        pt = co.k233_mulgen(H(e["k"]))
+        encs = [o.xsk233_encode(pt, r) for r in range(o.XSK_RULES)]
+        assert encs[0].hex() == e["enc"] and len(set(encs)) == o.XSK_RULES
+        for r, b in enumerate(encs):
+            assert o.xsk233_decode(b, r) == (pt, True)
+        w0 = int.from_bytes(encs[0], "little")
+        assert int.from_bytes(encs[1], "little") == w0 ^ 1
+        neg = (pt[0], pt[0] ^ pt[1])
+        assert o.xsk233_encode(neg, 0) == encs[1]
+        assert encs[2] == encs[0][::-1]
 
 
 def test_ecfft_extend_matches_interpolation():

@@ -15,8 +15,9 @@ and then
 This script is self-contained (its own GF(2^233) / K-233 arithmetic in python ints; it does not import the oracle).
 It recomputes k*G for each generator convention, applies every candidate encoding rule, and names the combination
 that reproduces the bytes -- "CURRENT RULE CONFIRMED" if it is the one codec.hip implements, otherwise the name of the
-rule to port into codec.hip (encode, decode) and oracle/pyref.py:xsk233_encode.  With --gpu it also checks that the
-library's own dvp_mulgen_batch (k_mulgen + k_encode) emits the same 30 bytes.
+rule NUMBER to hand to dvp_codec_set_rule (include/dvpari.h; every candidate of the family is already implemented in codec.hip
+and in oracle/pyref.py:xsk233_encode(pt, rule), parity-tested rule by rule).  With --gpu it also checks that the library's own
+dvp_mulgen_batch (k_mulgen + k_encode) emits the same 30 bytes under that rule.
 
     python tools/pin_xsk233.py --self-test       # encodes with the current rule and finds it again
 """
@@ -170,6 +171,18 @@ def encode_current(k):
     raise AssertionError
 
 
+TRANSFORM = {0: 0, 1: 1, 2: 0, 3: 2, 4: 1, 5: 0}  # RULES index -> codec.hip transform (0: w, 1: w^2, 2: sqrt w); y/x and x: none
+
+
+def rule_number(key):
+    """the dvp_codec_set_rule number of a candidate (None for the two formulas outside the family): the view, the generator's
+    sign and the explicit "+1" are one parity bit (w(Q + N) = w(-Q) = w(Q) + 1, and squaring / square root commute with + 1)"""
+    gi, vi, ri, plus1, order = key
+    if ri not in TRANSFORM:
+        return None
+    return (gi ^ vi ^ plus1) | (2 if order == "big" else 0) | (TRANSFORM[ri] << 2)
+
+
 def pin(k, target: bytes, out=print):
     """several candidates are the same function written differently (on the curve sqrt(s/x) = y'/x = sqrt(lambda);
     w(Q + N) = w(Q) + 1 = w(-Q)), so the matches are reported as ONE class of equivalent forms"""
@@ -182,6 +195,14 @@ def pin(k, target: bytes, out=print):
         else "MATCH, BUT NOT THE RULE codec.hip IMPLEMENTS -- port this rule (any of its equivalent forms):")
     for key, name in hits:
         out(("  * " if key == CURRENT else "    ") + name)
+    nums = sorted({rule_number(key) for key, _ in hits if rule_number(key) is not None})
+    if len(nums) == 1:
+        out(f"=> dvp_codec_set_rule({nums[0]})   (or DVP_CODEC_RULE={nums[0]} in the environment; oracle: pyref.xsk233_encode(pt, {nums[0]}))"
+            + ("   -- the default" if nums[0] == 0 else ""))
+    elif nums:
+        out(f"=> ambiguous between rules {nums}: supply a second vector")
+    else:
+        out("=> outside the family codec.hip can be switched to (y/x or x alone): a port is needed")
     return 0 if current else 1
 
 
@@ -206,6 +227,9 @@ def main(argv):
 
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         dvp = importlib.import_module("dv-pari_amd")
+        nums = sorted({rule_number(key) for key, enc, _ in candidates(k) if enc == target and rule_number(key) is not None})
+        if len(nums) == 1:
+            dvp.check(dvp.lib.dvp_codec_set_rule(nums[0]))
         got = dvp.curve.point_scalar_mul_gen_batch_bytes(dvp.fr.vec([k]))[0].tobytes()
         print("library (k_mulgen + k_encode):", got.hex(), "== supplied vector" if got == target else "!= supplied vector")
         rc = rc or (0 if got == target else 1)
