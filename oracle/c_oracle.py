@@ -67,6 +67,16 @@ def lib():
         _lib.dvo_fr_butterfly_passes.restype = C.c_int
         _lib.dvo_fr_pointwise_stages.argtypes = [vp, C.c_size_t, C.c_int]
         _lib.dvo_fr_pointwise_stages.restype = C.c_int
+        _lib.dvo_fr_convert.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int]
+        _lib.dvo_fr_extend.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+        _lib.dvo_fr_extend.restype = C.c_int
+        _lib.dvo_prove_load.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+        _lib.dvo_prove_load.restype = C.c_int
+        _lib.dvo_prove_free.argtypes = []
+        _lib.dvo_prove_commit.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, vp, vp, C.POINTER(C.c_int), vp]
+        _lib.dvo_prove_commit.restype = C.c_long
+        _lib.dvo_prove_open.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_int), vp]
+        _lib.dvo_prove_open.restype = C.c_int
         for f in ("dvo_gf_mul",):
             getattr(_lib, f).argtypes = [vp, vp, vp]
         for f in ("dvo_gf_sqr", "dvo_gf_inv"):
@@ -214,6 +224,65 @@ def fr_pointwise_stages(m: int, threads: int = 1, seed: int = 3):
 
 
 _ossl = None
+
+
+def fr_extend(evals: np.ndarray, dec: np.ndarray, rec: np.ndarray, threads: int = 1) -> np.ndarray:
+    """FFTree::extend(evals, Moiety::S1) over explicit butterfly matrices ((n - 1) x 4 canonical Fr each, layer d at matrix offset
+    n - (n >> d)): the loop dvo_prove_commit runs, exposed so that it can be pinned against the recursive oracle extend"""
+    e = np.ascontiguousarray(evals, dtype=np.uint64)
+    n = e.shape[0]
+    d, r = np.ascontiguousarray(dec, dtype=np.uint64), np.ascontiguousarray(rec, dtype=np.uint64)
+    assert d.shape == r.shape == ((n - 1) * 4, 4), (d.shape, n)
+    out = np.zeros_like(e)
+    assert lib().dvo_fr_extend(_p(e), _p(d), _p(r), n, threads, _p(out)) == 0
+    return out
+
+
+class ProveInputs:
+    """what Proof::prove reads from its cache_dir, as arrays (canonical Fr = [n, 4] uint64; points affine [n, 8] uint64)"""
+
+    def __init__(self, m, n_wires, n_pub, csr, coeffs, n_rows, d, d2, bar_wts, z_vals2inv, z_poly, dec, rec, bases_a, bases_k):
+        self.m, self.n_wires, self.n_pub, self.n_rows = m, n_wires, n_pub, n_rows
+        self.csr = [tuple(np.ascontiguousarray(x, dtype=np.uint32) for x in t) for t in csr]  # 3 x (row_ptr, wire, coeff id)
+        self.coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        self.tabs = [np.ascontiguousarray(x, dtype=np.uint64) for x in (d, d2, bar_wts, z_vals2inv, z_poly, dec, rec)]
+        self.bases_a = np.ascontiguousarray(bases_a, dtype=np.uint64)
+        self.bases_k = np.ascontiguousarray(bases_k, dtype=np.uint64)
+        assert self.bases_a.shape == (n_wires + m, 8) and self.bases_k.shape == (4 * m, 8)
+        assert self.tabs[4].shape == (m + 1, 4) and self.tabs[5].shape == ((m - 1) * 4, 4)
+
+
+def prove_cpu(inp: ProveInputs, public_inputs, private_inputs, transcript, threads: int = 1):
+    """Proof::prove (src/proving.rs:426-688) end to end on the CPU: dvo_prove_commit -> transcript(commit_p bytes) -> dvo_prove_open.
+    Returns (commit_p bytes, kzg_k bytes, a0, b0, {stage: seconds}); raises ValueError(row) on an unsatisfied constraint."""
+    L = lib()
+    t = inp.tabs
+    assert L.dvo_prove_load(inp.m, inp.n_wires, inp.n_pub, _p(t[0]), _p(t[1]), _p(t[2]), _p(t[3]), _p(t[4]), _p(t[5]), _p(t[6]), threads) == 0
+    try:
+        w = np.zeros((inp.n_wires, 4), dtype=np.uint64)
+        vals = [1] + [int(x) for x in public_inputs] + [int(x) for x in private_inputs]
+        assert len(vals) == inp.n_wires
+        w[:] = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype="<u8").reshape(-1, 4)
+        arr3 = lambda k: (C.c_void_p * 3)(*[inp.csr[j][k].ctypes.data for j in range(3)])
+        rp, wi, ci = arr3(0), arr3(1), arr3(2)
+        xy = np.zeros(8, dtype=np.uint64)
+        inf = C.c_int(0)
+        st1 = np.zeros(4, dtype=np.float64)
+        rc = L.dvo_prove_commit(rp, wi, ci, _p(inp.coeffs), inp.coeffs.shape[0], inp.n_rows, _p(w), _p(inp.bases_a), _p(xy), C.byref(inf), _p(st1))
+        if rc < 0:
+            raise ValueError(-1 - rc)
+        commit = xsk233_encode(_pt_out(xy, inf))
+        alpha = int(transcript(commit))
+        a0, b0, kxy = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        kinf = C.c_int(0)
+        st2 = np.zeros(3, dtype=np.float64)
+        assert L.dvo_prove_open(_p(_limbs(alpha)), _p(inp.bases_k), _p(a0), _p(b0), _p(kxy), C.byref(kinf), _p(st2)) == 0
+        kzg = xsk233_encode(_pt_out(kxy, kinf))
+        stages = {"matvec_sequential": st1[0], "extend_x4": st1[1], "quotient": st1[2], "msm_commit": st1[3],
+                  "barycentric_x3_sequential": st2[0], "inversions_kscalars": st2[1], "msm_k": st2[2]}
+        return commit, kzg, _int(a0), _int(b0), {k: float(v) for k, v in stages.items()}
+    finally:
+        L.dvo_prove_free()
 
 
 def openssl_msm(scalars: np.ndarray, bases: np.ndarray, threads: int = 1):

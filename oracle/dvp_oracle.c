@@ -860,3 +860,260 @@ int dvo_fr_pointwise_stages(u64* buf, size_t m, int threads) {
   return 0;
 }
 
+
+/* ================================================================================================================
+ * Proof::prove END TO END on the CPU, in the reference's own shape (src/proving.rs:426-688), for the timed cpu_baseline
+ * and as a whole-pipeline checker of the GPU prover's bytes.  Split at the Fiat-Shamir challenge: the transcript is
+ * pyref.transcript_challenge (python) between dvo_prove_commit and dvo_prove_open.  What is SEQUENTIAL in the reference is
+ * sequential here (the R1CS mat-vec, :348-403; the three barycentric evaluations with their Horner pass over z_poly,
+ * src/ec_fft.rs:455-491); what the reference runs on rayon (extends, pointwise maps, batch inversions, the per-point scalar
+ * multiplications of multi_scalar_mul) uses `threads` workers.  Fr vectors cross this boundary CANONICAL (4 x u64 LE) and
+ * are moved to Montgomery form inside (ark-ff keeps Fr in Montgomery form in memory; that conversion is part of loading
+ * the cache_dir files and is not timed).  Inputs are exactly what Proof::prove reads from its cache_dir: the R1CS, the
+ * domains and butterfly matrices of tree2n, bar_wts, z_vals2inv, z_poly, the five SRS vectors (already decoded: the
+ * reference's 6m point decodes are timed separately by the caller if wanted).
+ * ================================================================================================================ */
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+static u64 g_fr_r2[4];
+static int g_fr_r2_ready = 0;
+static void fr_r2_init(void) { /* R^2 mod p by 512 doublings of 1 (R = 2^256) */
+  if (g_fr_r2_ready) return;
+  u64 x[4] = {1, 0, 0, 0};
+  for (int i = 0; i < 512; ++i) fr_add_mod(x, x, x);
+  memcpy(g_fr_r2, x, 32);
+  g_fr_r2_ready = 1;
+}
+static inline void fr_to_mont1(const u64 a[4], u64 out[4]) { fr_mont_mul(a, g_fr_r2, out); }
+static inline void fr_from_mont1(const u64 a[4], u64 out[4]) { const u64 one[4] = {1, 0, 0, 0}; fr_mont_mul(a, one, out); }
+
+typedef void (*range_fn)(size_t lo, size_t hi, void* ctx);
+typedef struct { range_fn fn; void* ctx; size_t lo, hi; } par_job;
+static void* par_worker(void* arg) { par_job* j = (par_job*)arg; if (j->hi > j->lo) j->fn(j->lo, j->hi, j->ctx); return NULL; }
+static void par_for(size_t n, int threads, range_fn fn, void* ctx) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  if (threads == 1 || n < 64) { fn(0, n, ctx); return; }
+  par_job jobs[256];
+  pthread_t th[256];
+  size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+  for (int t = 0; t < threads; ++t) {
+    jobs[t].fn = fn; jobs[t].ctx = ctx;
+    jobs[t].lo = (size_t)t * per < n ? (size_t)t * per : n;
+    jobs[t].hi = (size_t)(t + 1) * per < n ? (size_t)(t + 1) * per : n;
+    pthread_create(&th[t], NULL, par_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+}
+typedef struct { const u64* in; u64* out; int dir; } cv_ctx;
+static void cv_range(size_t lo, size_t hi, void* c) {
+  cv_ctx* x = (cv_ctx*)c;
+  for (size_t i = lo; i < hi; ++i) { if (x->dir) fr_to_mont1(x->in + 4 * i, x->out + 4 * i); else fr_from_mont1(x->in + 4 * i, x->out + 4 * i); }
+}
+/* canonical <-> Montgomery over a vector (dir = 1: to Montgomery) */
+int dvo_fr_convert(const u64* in, u64* out, size_t n, int to_mont, int threads) {
+  fr_r2_init();
+  cv_ctx c = {in, out, to_mont};
+  par_for(n, threads, cv_range, &c);
+  return 0;
+}
+/* FFTree::extend(evals, Moiety::S1) with the tree's own 2x2 matrices (Montgomery form): log2 n decompose layers, then log2 n
+ * recombine layers (src/proving.rs:410-422 -> ecfft); layer d pairs (i, i + n >> (d+1)) inside blocks of n >> d with matrix
+ * i of that layer (matrix offset n - (n >> d)), the layout FFTree::{decompose,recombine}_matrices flatten to */
+typedef struct { u64* data; const u64* mats; size_t half; } ex_ctx;
+static void ex_range(size_t lo, size_t hi, void* c) {
+  ex_ctx* x = (ex_ctx*)c;
+  for (size_t p = lo; p < hi; ++p) {
+    size_t blk = p / x->half, i = p - blk * x->half;
+    u64* e0 = x->data + 4 * (blk * 2 * x->half + i);
+    u64* e1 = e0 + 4 * x->half;
+    const u64* m = x->mats + 16 * i;
+    u64 t0[4], t1[4], t2[4], t3[4];
+    fr_mont_mul(m, e0, t0); fr_mont_mul(m + 4, e1, t1); fr_mont_mul(m + 8, e0, t2); fr_mont_mul(m + 12, e1, t3);
+    fr_add_mod(t0, t1, e0); fr_add_mod(t2, t3, e1);
+  }
+}
+static void fr_extend_mont(u64* data, const u64* dec, const u64* rec, size_t n, int threads) {
+  int ln = 0;
+  while (((size_t)1 << ln) < n) ++ln;
+  for (int d = 0; d < ln; ++d) { ex_ctx c = {data, dec + 16 * (n - (n >> d)), n >> (d + 1)}; par_for(n / 2, threads, ex_range, &c); }
+  for (int d = ln - 1; d >= 0; --d) { ex_ctx c = {data, rec + 16 * (n - (n >> d)), n >> (d + 1)}; par_for(n / 2, threads, ex_range, &c); }
+}
+int dvo_fr_extend(const u64* evals, const u64* dec, const u64* rec, size_t n, int threads, u64* out) { /* canonical in/out, matrices canonical */
+  fr_r2_init();
+  size_t nm = n > 1 ? (n - 1) * 4 : 0;
+  u64* dm = (u64*)malloc((nm ? nm : 1) * 32); u64* rm = (u64*)malloc((nm ? nm : 1) * 32); u64* x = (u64*)malloc(n * 32);
+  if (!dm || !rm || !x) return -1;
+  dvo_fr_convert(dec, dm, nm, 1, threads); dvo_fr_convert(rec, rm, nm, 1, threads); dvo_fr_convert(evals, x, n, 1, threads);
+  fr_extend_mont(x, dm, rm, n, threads);
+  dvo_fr_convert(x, out, n, 0, threads);
+  free(dm); free(rm); free(x);
+  return 0;
+}
+
+typedef struct {
+  size_t m, n_wires, n_rows, n_pub;
+  u64 *w, *E /* a b c i, Montgomery */, *E2 /* a2 b2 c2 i2 */, *r2, *q2;
+  u64 *d, *d2, *bw, *z2inv, *zpoly, *dec, *rec; /* Montgomery copies of the cache_dir tables */
+  int threads;
+} prove_state;
+static prove_state g_ps;
+static void ps_free(void) {
+  u64** p[] = {&g_ps.w, &g_ps.E, &g_ps.E2, &g_ps.r2, &g_ps.q2, &g_ps.d, &g_ps.d2, &g_ps.bw, &g_ps.z2inv, &g_ps.zpoly, &g_ps.dec, &g_ps.rec};
+  for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i) { free(*p[i]); *p[i] = NULL; }
+}
+static u64* mont_copy(const u64* canon, size_t n, int threads) {
+  u64* o = (u64*)malloc((n ? n : 1) * 32);
+  if (o) dvo_fr_convert(canon, o, n, 1, threads);
+  return o;
+}
+/* load the cache_dir tables (untimed: the reference's file reads): canonical inputs, kept in Montgomery form until dvo_prove_free */
+int dvo_prove_load(size_t m, size_t n_wires, size_t n_pub, const u64* d, const u64* d2, const u64* bar_wts, const u64* z_vals2inv,
+                   const u64* z_poly /* m + 1 */, const u64* dec, const u64* rec /* (m - 1) x 4 each */, int threads) {
+  fr_r2_init();
+  ps_free();
+  g_ps.m = m; g_ps.n_wires = n_wires; g_ps.n_pub = n_pub; g_ps.threads = threads;
+  g_ps.d = mont_copy(d, m, threads); g_ps.d2 = mont_copy(d2, m, threads); g_ps.bw = mont_copy(bar_wts, m, threads);
+  g_ps.z2inv = mont_copy(z_vals2inv, m, threads); g_ps.zpoly = mont_copy(z_poly, m + 1, threads);
+  g_ps.dec = mont_copy(dec, (m - 1) * 4, threads); g_ps.rec = mont_copy(rec, (m - 1) * 4, threads);
+  g_ps.w = (u64*)malloc(n_wires * 32); g_ps.E = (u64*)calloc(4 * m, 32); g_ps.E2 = (u64*)malloc(4 * m * 32);
+  g_ps.r2 = (u64*)malloc(m * 32); g_ps.q2 = (u64*)malloc(m * 32);
+  return (g_ps.d && g_ps.d2 && g_ps.bw && g_ps.z2inv && g_ps.zpoly && g_ps.dec && g_ps.rec && g_ps.w && g_ps.E && g_ps.E2 && g_ps.r2 && g_ps.q2) ? 0 : -1;
+}
+void dvo_prove_free(void) { ps_free(); }
+
+static void eval_rows_seq(const uint32_t* rp, const uint32_t* wire, const uint32_t* cid, const u64* coeffs_m, size_t n_rows, const u64* w, u64* out) {
+  for (size_t i = 0; i < n_rows; ++i) { /* eval_row, src/gnark_r1cs.rs:273-280 */
+    u64 acc[4] = {0, 0, 0, 0}, t[4];
+    for (uint32_t k = rp[i]; k < rp[i + 1]; ++k) { fr_mont_mul(coeffs_m + 4 * (size_t)cid[k], w + 4 * (size_t)wire[k], t); fr_add_mod(acc, t, acc); }
+    memcpy(out + 4 * i, acc, 32);
+  }
+}
+typedef struct { const u64 *a2, *b2, *c2, *i2, *zinv; u64 *r2, *q2; } qt_ctx;
+static void qt_range(size_t lo, size_t hi, void* c) {
+  qt_ctx* x = (qt_ctx*)c;
+  for (size_t i = lo; i < hi; ++i) { /* src/proving.rs:492-508 */
+    u64 t[4], u[4];
+    fr_mont_mul(x->a2 + 4 * i, x->b2 + 4 * i, t);
+    fr_sub_mod(t, x->i2 + 4 * i, t);
+    memcpy(x->r2 + 4 * i, t, 32);
+    fr_sub_mod(t, x->c2 + 4 * i, u);
+    fr_mont_mul(u, x->zinv + 4 * i, x->q2 + 4 * i);
+  }
+}
+/* First half of Proof::prove: witness -> a b c' i on D (SEQUENTIAL, :348-403, with the satisfiability check :389-395), the four
+ * extends (:410-422), r2 / q2 (:492-508), commit_p = <w, g_m> + <q2, g_q> (:463,512,515; per-point scalar multiplications + add
+ * tree).  Returns -1 - (first unsatisfied row) or 0; stage_s: matvec, extend, quotient, msm seconds. */
+long dvo_prove_commit(const uint32_t* const rp[3], const uint32_t* const wire[3], const uint32_t* const cid[3], const u64* coeffs, size_t n_coeffs,
+                      size_t n_rows, const u64* witness /* n_wires canonical */, const u64* bases_a /* (n_wires + m) x 8 */, u64 commit_xy[8],
+                      int* commit_inf, double stage_s[4]) {
+  const size_t m = g_ps.m, nw = g_ps.n_wires;
+  const int th = g_ps.threads;
+  u64* coeffs_m = mont_copy(coeffs, n_coeffs, th);
+  dvo_fr_convert(witness, g_ps.w, nw, 1, th);
+  double t0 = now_s();
+  u64 *a = g_ps.E, *b = a + 4 * m, *c = b + 4 * m, *iv = c + 4 * m;
+  memset(g_ps.E, 0, 4 * m * 32);
+  eval_rows_seq(rp[0], wire[0], cid[0], coeffs_m, n_rows, g_ps.w, a);
+  eval_rows_seq(rp[1], wire[1], cid[1], coeffs_m, n_rows, g_ps.w, b);
+  eval_rows_seq(rp[2], wire[2], cid[2], coeffs_m, n_rows, g_ps.w, c);
+  long bad = 0;
+  for (size_t i = 0; i < m && !bad; ++i) { /* i(d_i) by Horner over the public inputs (:369-376); c' = c - i; a b == c' + i (:389-395) */
+    u64 acc[4] = {0, 0, 0, 0}, t[4];
+    for (size_t j = g_ps.n_pub; j-- > 0;) { fr_mont_mul(acc, g_ps.d + 4 * i, acc); fr_add_mod(acc, g_ps.w + 4 * (1 + j), acc); }
+    memcpy(iv + 4 * i, acc, 32);
+    fr_sub_mod(c + 4 * i, acc, c + 4 * i);
+    fr_mont_mul(a + 4 * i, b + 4 * i, t);
+    u64 rhs[4];
+    fr_add_mod(c + 4 * i, acc, rhs);
+    if (memcmp(t, rhs, 32)) bad = -1 - (long)i;
+  }
+  free(coeffs_m);
+  double t1 = now_s();
+  if (bad) return bad;
+  memcpy(g_ps.E2, g_ps.E, 4 * m * 32);
+  for (int v = 0; v < 4; ++v) fr_extend_mont(g_ps.E2 + 4 * m * (size_t)v, g_ps.dec, g_ps.rec, m, th);
+  double t2 = now_s();
+  qt_ctx q = {g_ps.E2, g_ps.E2 + 4 * m, g_ps.E2 + 8 * m, g_ps.E2 + 12 * m, g_ps.z2inv, g_ps.r2, g_ps.q2};
+  par_for(m, th, qt_range, &q);
+  double t3 = now_s();
+  u64* sc = (u64*)malloc((nw + m) * 32); /* into_bigint per scalar, src/curve.rs:162-170 */
+  dvo_fr_convert(g_ps.w, sc, nw, 0, th);
+  dvo_fr_convert(g_ps.q2, sc + 4 * nw, m, 0, th);
+  dvo_msm(sc, bases_a, NULL, nw + m, th, commit_xy, commit_inf);
+  free(sc);
+  double t4 = now_s();
+  stage_s[0] = t1 - t0; stage_s[1] = t2 - t1; stage_s[2] = t3 - t2; stage_s[3] = t4 - t3;
+  return 0;
+}
+static void fr_batch_inv_par_range(size_t lo, size_t hi, void* c) {
+  u64** p = (u64**)c; /* p[0] = values, p[1] = scratch */
+  fr_batch_inv(p[0] + 4 * lo, hi - lo, p[1] + 4 * lo);
+}
+static void fr_batch_inv_par(u64* v, size_t n, u64* scratch, int threads) { u64* p[2] = {v, scratch}; par_for(n, threads, fr_batch_inv_par_range, p); }
+typedef struct { const u64 *d, *alpha; u64* out; int rev; } sub_ctx;
+static void sub_range(size_t lo, size_t hi, void* c) {
+  sub_ctx* x = (sub_ctx*)c;
+  for (size_t i = lo; i < hi; ++i) { if (x->rev) fr_sub_mod(x->alpha, x->d + 4 * i, x->out + 4 * i); else fr_sub_mod(x->d + 4 * i, x->alpha, x->out + 4 * i); }
+}
+/* evaluate_poly_at_alpha_using_barycentric_weights (src/ec_fft.rs:455-491): Z(alpha) by Horner over z_poly, a batch inversion of
+ * (alpha - d_i), then the SEQUENTIAL sum -- recomputed for each of the three calls, as the reference does (:571-591) */
+static void bary_eval(const u64* y, const u64* alpha_m, u64* den, u64* scratch, int threads, u64 out[4]) {
+  const size_t m = g_ps.m;
+  u64 z[4] = {0, 0, 0, 0};
+  for (size_t k = m + 1; k-- > 0;) { fr_mont_mul(z, alpha_m, z); fr_add_mod(z, g_ps.zpoly + 4 * k, z); }
+  sub_ctx s = {g_ps.d, alpha_m, den, 1};
+  par_for(m, threads, sub_range, &s);
+  fr_batch_inv_par(den, m, scratch, threads);
+  u64 acc[4] = {0, 0, 0, 0}, t[4];
+  for (size_t i = 0; i < m; ++i) { fr_mont_mul(y + 4 * i, g_ps.bw + 4 * i, t); fr_mont_mul(t, den + 4 * i, t); fr_add_mod(acc, t, acc); }
+  fr_mont_mul(acc, z, out);
+}
+typedef struct { const u64 *a, *b, *iv, *r2, *den, *den2, *a0, *b0, *r0; u64 *ka, *kb, *kr; } ks_ctx;
+static void ks_range(size_t lo, size_t hi, void* c) {
+  ks_ctx* x = (ks_ctx*)c;
+  for (size_t i = lo; i < hi; ++i) { /* src/proving.rs:619-654 */
+    u64 t[4];
+    fr_sub_mod(x->a + 4 * i, x->a0, t); fr_mont_mul(t, x->den + 4 * i, x->ka + 4 * i);
+    fr_sub_mod(x->b + 4 * i, x->b0, t); fr_mont_mul(t, x->den + 4 * i, x->kb + 4 * i);
+    fr_mont_mul(x->a + 4 * i, x->b + 4 * i, t); fr_sub_mod(t, x->iv + 4 * i, t); fr_sub_mod(t, x->r0, t);
+    fr_mont_mul(t, x->den + 4 * i, x->kr + 8 * i);
+    fr_sub_mod(x->r2 + 4 * i, x->r0, t);
+    fr_mont_mul(t, x->den2 + 4 * i, x->kr + 8 * i + 4);
+  }
+}
+/* Second half: alpha -> a0 b0 i0 (:561-594), denominators and their inverses (:599-616), K scalars interleaved [D_i, D'_i]
+ * (:619-654), kzg_k = <[k_a | k_b | k_r], [g_k_0 | g_k_1 | g_k_2]> (:666-680).  stage_s: barycentric, kscalars, msm. */
+int dvo_prove_open(const u64 alpha[4], const u64* bases_k /* 4m x 8 */, u64 a0_out[4], u64 b0_out[4], u64 kzg_xy[8], int* kzg_inf, double stage_s[3]) {
+  const size_t m = g_ps.m;
+  const int th = g_ps.threads;
+  u64 alpha_m[4], a0[4], b0[4], i0[4], r0[4];
+  fr_to_mont1(alpha, alpha_m);
+  u64 *den = (u64*)malloc(m * 32), *den2 = (u64*)malloc(m * 32), *scr = (u64*)malloc(m * 32), *sk = (u64*)malloc(4 * m * 32);
+  if (!den || !den2 || !scr || !sk) return -1;
+  const u64 *a = g_ps.E, *b = a + 4 * m, *iv = a + 12 * m;
+  double t0 = now_s();
+  bary_eval(a, alpha_m, den, scr, th, a0);
+  bary_eval(b, alpha_m, den, scr, th, b0);
+  bary_eval(iv, alpha_m, den, scr, th, i0);
+  fr_mont_mul(a0, b0, r0);
+  fr_sub_mod(r0, i0, r0);
+  double t1 = now_s();
+  sub_ctx s1 = {g_ps.d, alpha_m, den, 0}, s2 = {g_ps.d2, alpha_m, den2, 0};
+  par_for(m, th, sub_range, &s1);
+  par_for(m, th, sub_range, &s2);
+  fr_batch_inv_par(den, m, scr, th);
+  fr_batch_inv_par(den2, m, scr, th);
+  ks_ctx k = {a, b, iv, g_ps.r2, den, den2, a0, b0, r0, sk, sk + 4 * m, sk + 8 * m};
+  par_for(m, th, ks_range, &k);
+  double t2 = now_s();
+  u64* sc = (u64*)malloc(4 * m * 32);
+  dvo_fr_convert(sk, sc, 4 * m, 0, th);
+  dvo_msm(sc, bases_k, NULL, 4 * m, th, kzg_xy, kzg_inf);
+  double t3 = now_s();
+  fr_from_mont1(a0, a0_out);
+  fr_from_mont1(b0, b0_out);
+  free(sc); free(den); free(den2); free(scr); free(sk);
+  stage_s[0] = t1 - t0; stage_s[1] = t2 - t1; stage_s[2] = t3 - t2;
+  return 0;
+}

@@ -18,6 +18,7 @@ import pytest
 
 import pyref as o
 import c_oracle as co
+from util import to_limbs, from_limbs
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 OSSL = json.load(open(os.path.join(GOLD, "k233_openssl.json")))["vectors"]
@@ -307,3 +308,89 @@ def test_sliding_window_decomposition():
             entries += 1
     assert 11.8 < entries / 3000 < 12.2
     assert max(load.values()) < 4.0 * entries / (1 << (c - 1 - 8))
+
+
+def _cpu_prove_inputs(log_m, rows, coeffs, n_pub, trap):
+    """everything Proof::prove reads from its cache_dir, from the ORACLE alone: brute-force tables and setup scalars (pyref), butterfly
+    matrices from the C restatement of FFTree, SRS bases as scalar x G through the C curve code"""
+    m = 1 << log_m
+    tree = o.FFTree(log_m + 1)
+    st = o.setup_srs_scalars(tree, rows, coeffs, n_pub, trap)
+    tb = st["tables"]
+    ct = co.FFTree(log_m + 1)
+    dec, rec = ct.matrices(False, 0), ct.matrices(False, 1)
+    ct.close()
+    n_wires = len(st["g_m"])
+
+    def pts(scalars):
+        out = np.zeros((len(scalars), 8), dtype=np.uint64)
+        for k, s in enumerate(scalars):
+            x, y = co.k233_mulgen(s)
+            out[k, :4], out[k, 4:] = co._limbs(x), co._limbs(y)
+        return out
+
+    def csr(part):
+        rp, wi, ci = [0], [], []
+        for r in rows:
+            for w_, c_ in r[part]:
+                wi.append(w_)
+                ci.append(c_)
+            rp.append(len(wi))
+        return np.array(rp, dtype=np.uint32), np.array(wi or [0], dtype=np.uint32), np.array(ci or [0], dtype=np.uint32)
+
+    inp = co.ProveInputs(m, n_wires, n_pub, [csr(0), csr(1), csr(2)], to_limbs(coeffs), len(rows), to_limbs(tb["D"]), to_limbs(tb["D2"]),
+                         to_limbs(tb["bar_wts"]), to_limbs(tb["z_vals2inv"]), to_limbs(tb["z_poly"]), dec, rec,
+                         pts(st["g_m"] + st["g_q"]), pts(st["g_k"][0] + st["g_k"][1] + st["g_k"][2]))
+    return tree, st, inp
+
+
+def test_cpu_prove_end_to_end_toy_golden():
+    """dvo_prove_commit / dvo_prove_open (the timed cpu_baseline's Proof::prove, oracle/dvp_oracle.c) on the toy circuit of
+    src/dvsnark_test.rs:131-180: bytes equal the golden toy proof, an unsatisfied witness names its row (src/proving.rs:389-395)."""
+    toy = VEC["toy"]
+    trap = tuple(H(x) for x in toy["trapdoor"])
+    tree, st, inp = _cpu_prove_inputs(3, o.TOY_ROWS, o.TOY_COEFFS, 2, trap)
+    tr = lambda commit: o.transcript_challenge(commit, o.TOY_PUBLIC)
+    for threads in (1, 3):
+        commit, kzg, a0, b0, stages = co.prove_cpu(inp, o.TOY_PUBLIC, o.TOY_PRIVATE, tr, threads=threads)
+        assert commit.hex() == toy["commit_p"] and kzg.hex() == toy["kzg_k"]
+        assert hex(a0) == toy["a0"] and hex(b0) == toy["b0"]
+        assert set(stages) == {"matvec_sequential", "extend_x4", "quotient", "msm_commit", "barycentric_x3_sequential", "inversions_kscalars", "msm_k"}
+    bad = list(o.TOY_PRIVATE)
+    bad[3] += 1
+    with pytest.raises(ValueError) as e:
+        co.prove_cpu(inp, o.TOY_PUBLIC, bad, tr)
+    assert e.value.args[0] == 2
+    # the iterative extend over explicit matrices == the recursive oracle extend
+    ev = [H(x) for x in toy["a"]]
+    assert from_limbs(co.fr_extend(to_limbs(ev), inp.tabs[5], inp.tabs[6], threads=2)) == tree.extend(ev) == [H(x) for x in toy["a2"]]
+
+
+def test_cpu_prove_end_to_end_vs_pyref_2_5():
+    """the same on a random 2^5-row circuit with 3 public inputs: every output equals pyref.prove_scalars' (stage-by-stage big-int
+    restatement), commitments as group elements through the discrete logs"""
+    rnd = random.Random(77)
+    n_pub, m = 3, 32
+    coeffs = [rnd.randrange(1, o.P) for _ in range(6)]
+    wvals = [1] + [rnd.randrange(o.P) for _ in range(n_pub + 6)]
+    rows = []
+    for i in range(m - 3):  # (w_a + c w_b) * w_d = fresh wire
+        a_, b_, d_ = (rnd.randrange(len(wvals)) for _ in range(3))
+        c_ = rnd.randrange(len(coeffs))
+        one = coeffs.index(1) if 1 in coeffs else None
+        if one is None:
+            coeffs.append(1)
+            one = len(coeffs) - 1
+        val = (wvals[a_] + coeffs[c_] * wvals[b_]) * wvals[d_] % o.P
+        wvals.append(val)
+        rows.append(([(a_, one), (b_, c_)], [(d_, one)], [(len(wvals) - 1, one)]))
+    pub, prv = wvals[1:1 + n_pub], wvals[1 + n_pub:]
+    trap = (rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    tree, st, inp = _cpu_prove_inputs(5, rows, coeffs, n_pub, trap)
+    assert inp.n_wires == len(wvals)
+    tr = lambda commit: o.transcript_challenge(commit, pub)
+    commit, kzg, a0, b0, _ = co.prove_cpu(inp, pub, prv, tr, threads=4)
+    pr = o.prove_scalars(tree, st, pub, prv, lambda dl: o.transcript_challenge(co.xsk233_encode(co.k233_mulgen(dl)), pub))
+    assert commit == co.xsk233_encode(co.k233_mulgen(pr["dl_commit_p"])) and kzg == co.xsk233_encode(co.k233_mulgen(pr["dl_kzg"]))
+    assert (a0, b0) == (pr["a0"], pr["b0"])
+    assert o.verify_dl(trap, pub, pr["dl_commit_p"], pr["dl_kzg"], a0, b0, pr["alpha"])
