@@ -25,3 +25,12 @@ oracle:
 clean:
 	rm -f $(OBJS) $(LIB) examples/dvp_prove_cli
 .PHONY: all cli oracle clean
+
+# Host-side parsers under AddressSanitizer + UBSan (CPU build only: GPU entries are stand-ins, tools/asan/stubs.cpp):
+#   make asan        -> builds and runs tools/asan/fuzz with ASAN_ITERS cases (default 20000); see tools/README.md
+ASAN_ITERS ?= 20000
+asan:
+	g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=all -D__HIP_PLATFORM_AMD__ \
+	  -I/opt/rocm/include $(CSRC)/cache.cpp $(CSRC)/tree_io.cpp tools/asan/stubs.cpp tools/asan/fuzz.cpp -pthread -o tools/asan/fuzz
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 ./tools/asan/fuzz $(ASAN_ITERS)
+.PHONY: asan
