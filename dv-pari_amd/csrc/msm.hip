@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -742,27 +743,47 @@ k_dbl_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, GfSqrTables
   }
 }
 
-// signed aligned windows: T[w][i] = 2^(o_w) P_i, o_w = first bit of window w (the n_narrow low windows are c - 1 bits wide)
+// signed aligned windows: T[w][i] = 2^(o_w) P_i, o_w = first bit of window w (the n_narrow low windows are c - 1 bits wide).
+// The ~222 doublings of a base run in Lopez-Dahab coordinates (3M + 5S each) and the W - 1 row snapshots of the base share ONE
+// inversion (Montgomery's trick over their Z's): ~0.9 k field products per base.  The first version doubled in affine
+// coordinates, one table-driven inversion per doubling: 4.2 k products per base, 0.30 s per table at 2^20 constraints and 75 % of
+// the profiled GPU time of a short run (prover open).  zs / pre: thread-private scratch in HBM, (W - 1) x n field elements each
+// ([row][base]: coalesced), freed after the build.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, int n_narrow, GfSqrTables T, Aff* __restrict__ table) {
+k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, int n_narrow, GfSqrTables T, Aff* __restrict__ table, Gf* __restrict__ zs,
+            Gf* __restrict__ pre) {
   extern __shared__ char lds_raw[];
   GfLdsK L = gf_ldsk_init(lds_raw);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Aff p = bases[i];
-  table[i] = p;
-  const Gf one = gf_one();
+  const Aff p0 = bases[i];
+  table[i] = p0;
+  Ld p = ld_from_aff(p0);
+  Gf run = gf_one();
 #pragma unroll 1
   for (int w = 1; w < W; ++w) {
     const int width = (w - 1) < n_narrow ? c - 1 : c;  // row w starts where window w - 1 ends
 #pragma unroll 1
-    for (int k = 0; k < width; ++k) {
-      Gf lam = gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L));
-      Gf x3 = gf_add(gf_sqr(lam), lam);
-      p.y = gf_add(gf_sqr(p.x), gf_mul(gf_add(lam, one), x3, L));
-      p.x = x3;
-    }
-    table[(size_t)w * n + i] = p;
+    for (int k = 0; k < width; ++k) p = ld_dbl(p, L);
+    Aff raw;
+    raw.x = p.X;
+    raw.y = p.Y;
+    table[(size_t)w * n + i] = raw;  // normalised below
+    zs[(size_t)(w - 1) * n + i] = p.Z;
+    pre[(size_t)(w - 1) * n + i] = run;
+    run = gf_mul(run, p.Z, L);
+  }
+  Gf inv = gf_inv_fast(run, T, L);  // a base of E[r] never doubles to infinity: every Z is non-zero
+#pragma unroll 1
+  for (int w = W - 1; w >= 1; --w) {
+    const Gf z = zs[(size_t)(w - 1) * n + i];
+    Gf zi, inv_next;
+    gf_mul2(pre[(size_t)(w - 1) * n + i], z, inv, L, zi, inv_next);  // 1 / Z_w, and the running inverse stripped of Z_w
+    inv = inv_next;
+    Aff a = table[(size_t)w * n + i];
+    a.x = gf_mul(a.x, zi, L);
+    a.y = gf_mul(a.y, gf_sqr(zi), L);
+    table[(size_t)w * n + i] = a;
   }
 }
 
@@ -1946,7 +1967,22 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
       int rc_t = gf_sqr_tables(&Tsq, 0);
       if (rc_t != DVP_OK) { msm_fixed_destroy(c); return rc_t; }
       e = hipFuncSetAttribute((const void*)k_dbl_table, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->c, c->W, c->n_narrow, Tsq, c->table);
+      Gf* scratch = nullptr;  // Z snapshots + prefix products of the shared inversion, (W - 1) x n each
+      const size_t per = (size_t)(c->W > 1 ? c->W - 1 : 1) * n_total;
+      const bool dbg = getenv("DVP_DEBUG_TIMING") != nullptr;
+      auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+      const double t0 = now();
+      if (e == hipSuccess) e = hipMalloc((void**)&scratch, 2 * per * sizeof(Gf));
+      const double t1 = now();
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_dbl_table, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->c, c->W, c->n_narrow, Tsq, c->table,
+                           scratch, scratch + per);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+      }
+      const double t2 = now();
+      if (scratch) (void)hipFree(scratch);
+      if (dbg) fprintf(stderr, "[dvpari] k_dbl_table n=%u W=%d: scratch malloc %.3f s, kernel %.3f s, free %.3f s\n", n_total, c->W, t1 - t0, t2 - t1, now() - t2);
     } else
       hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
     if (e == hipSuccess) e = hipGetLastError();
