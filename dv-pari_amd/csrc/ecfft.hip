@@ -155,7 +155,8 @@ __global__ void __launch_bounds__(256) k_build_mats(const Fr* __restrict__ Ld, i
 // inside each block uses matrix i of this layer.  One thread = one pair for all batch vectors, so
 // the 128-byte matrix is read once per pair and reused `batch` times.
 template <int BATCH>
-__global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const Fr29* __restrict__ mats, int lh, uint32_t n) {
+__global__ void __launch_bounds__(256) k_butterfly(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
+                                                   const Fr29* __restrict__ mats, int lh, uint32_t n) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (n >> 1)) return;
   uint32_t h = 1u << lh;
@@ -167,7 +168,8 @@ __global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const 
 #pragma unroll
   for (int b = 0; b < BATCH; ++b) {
     Fr* v = data + (size_t)b * n;
-    Fr29 e0 = fr29_from(v[i0]), e1 = fr29_from(v[i1]);
+    const Fr* u = src + (size_t)b * n;
+    Fr29 e0 = fr29_from(u[i0]), e1 = fr29_from(u[i1]);
     v[i0] = fr_dot2(m00, e0, m01, e1);
     v[i1] = fr_dot2(m10, e0, m11, e1);
   }
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(256) k_butterfly(Fr* __restrict__ data, const 
 // matrices sit in the same wave and their loads are one request (holding the twelve matrix entries in registers across a loop
 // over the vectors instead costs 256 VGPRs, or 400-600 bytes of scratch per lane at three waves per SIMD).
 template <int BATCH, bool DEC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_butterfly4(Fr* __restrict__ data, const Fr29* __restrict__ mats_wide,
-                                                    const Fr29* __restrict__ mats_narrow, int lh2, uint32_t n) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_butterfly4(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
+                                                    const Fr29* __restrict__ mats_wide, const Fr29* __restrict__ mats_narrow, int lh2, uint32_t n) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t tid = gid / BATCH, bv = gid - tid * BATCH;
   if (tid >= (n >> 2)) return;
@@ -194,7 +196,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
   const Fr29* mb = mats_wide + 4 * (size_t)(j + h2);
   const Fr29* mc = mats_narrow + 4 * (size_t)j;
   Fr* v = data + (size_t)bv * n + i0;
-  Fr x0 = v[0], x1 = v[h2], x2 = v[h1], x3 = v[h1 + h2];
+  const Fr* u = src + (size_t)bv * n + i0;
+  Fr x0 = u[0], x1 = u[h2], x2 = u[h1], x3 = u[h1 + h2];
   Fr29 e0 = fr29_from(x0), e1 = fr29_from(x1), e2 = fr29_from(x2), e3 = fr29_from(x3);
   if (DEC) {
     x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);  // layer d: (j, j + h1)
@@ -238,12 +241,12 @@ __device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ mats, i
 }
 
 __global__ void __launch_bounds__(256)
-k_extend_fused(Fr* __restrict__ data, const Fr29* __restrict__ dec, const Fr29* __restrict__ rec, uint32_t n, int ln, int lb,
-               size_t total) {
+k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr29* __restrict__ dec,
+               const Fr29* __restrict__ rec, uint32_t n, int ln, int lb, size_t total) {
   __shared__ Fr x[FUSE_ELEMS];
   const size_t base = (size_t)blockIdx.x * FUSE_ELEMS;
   const uint32_t elems = (uint32_t)min((size_t)FUSE_ELEMS, total - base);
-  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) x[k] = data[base + k];
+  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) x[k] = src[base + k];
   __syncthreads();
   for (int L = 0; L < lb; ++L) {  // decompose, sub-block size 2^(lb-L)
     int d = ln - lb + L;
@@ -326,24 +329,32 @@ static int build_matset(dvp_ecfft* c, int sl, int to_even, MatSet** out, hipStre
 }
 
 template <int B>
-static void launch_bfly(Fr* data, const Fr29* mats, int lh, uint32_t n, hipStream_t st) {
-  hipLaunchKernelGGL((k_butterfly<B>), dim3(cdiv(n >> 1, TPB)), dim3(TPB), 0, st, data, mats, lh, n);
+static void launch_bfly(const Fr* src, Fr* data, const Fr29* mats, int lh, uint32_t n, hipStream_t st) {
+  hipLaunchKernelGGL((k_butterfly<B>), dim3(cdiv(n >> 1, TPB)), dim3(TPB), 0, st, src, data, mats, lh, n);
 }
 
 // in-place extend of `batch` vectors of n = (N>>sl)/2 values
-int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) {
+int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) { return extend_from(c, sl, to_even, data, data, batch, st); }
+// the same out of place: `src` is read by the first pass only and left untouched (the prover keeps a, b, c on D for its K scalars;
+// a copy of 3 x 32 MB before every extend was one more HBM round trip)
+int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, uint32_t batch, hipStream_t st) {
   uint32_t n = (c->n_leaves >> sl) >> 1;
-  if (n <= 1) return DVP_OK;
+  if (n <= 1) {
+    if (src_in != data && n == 1) DVP_HIP(hipMemcpyAsync(data, src_in, (size_t)batch * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    return DVP_OK;
+  }
+  const Fr* src = src_in;  // becomes `data` after the first launch
   MatSet* ms;
   DVP_TRY(build_matset(c, sl, to_even, &ms, st));
   int ln = 31 - __builtin_clz(n);
   // Blocks are contiguous, so `batch` vectors of n behave like one vector of batch*n for the block
   // structure; the BATCH template only buys matrix reuse when the batch is small and n is large.
   auto pass = [&](const Fr29* mats, int lh) {
-    if (batch == 4) launch_bfly<4>(data, mats, lh, n, st);
-    else if (batch == 3) launch_bfly<3>(data, mats, lh, n, st);
-    else if (batch == 2) launch_bfly<2>(data, mats, lh, n, st);
-    else launch_bfly<1>(data, mats, lh, (uint32_t)((size_t)batch * n), st);
+    if (batch == 4) launch_bfly<4>(src, data, mats, lh, n, st);
+    else if (batch == 3) launch_bfly<3>(src, data, mats, lh, n, st);
+    else if (batch == 2) launch_bfly<2>(src, data, mats, lh, n, st);
+    else launch_bfly<1>(src, data, mats, lh, (uint32_t)((size_t)batch * n), st);
+    src = data;
   };
   // two layers per pass (k_butterfly4) while two top layers remain; `wide` = layer d, `narrow` = layer d + 1
   auto pass4 = [&](const Fr29* base, int d, bool dec) {
@@ -354,10 +365,11 @@ int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, 
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g1(cdiv(nn >> 2, TPB));
 #define DVP_BF4(B, GRID) \
-  do { if (dec) hipLaunchKernelGGL((k_butterfly4<B, true>), GRID, b, 0, st, data, wide, narrow, lh2, nn); \
-       else hipLaunchKernelGGL((k_butterfly4<B, false>), GRID, b, 0, st, data, wide, narrow, lh2, nn); } while (0)
+  do { if (dec) hipLaunchKernelGGL((k_butterfly4<B, true>), GRID, b, 0, st, src, data, wide, narrow, lh2, nn); \
+       else hipLaunchKernelGGL((k_butterfly4<B, false>), GRID, b, 0, st, src, data, wide, narrow, lh2, nn); } while (0)
     if (batch == 4) DVP_BF4(4, g); else if (batch == 3) DVP_BF4(3, g); else if (batch == 2) DVP_BF4(2, g); else DVP_BF4(1, g1);
 #undef DVP_BF4
+    src = data;
   };
   const int lb = ln < FUSE_LOG ? ln : FUSE_LOG;  // layers handled inside LDS
   const int top = ln - lb;
@@ -370,7 +382,8 @@ int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, 
   }
   {
     size_t total = (size_t)batch * n;
-    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, data, ms->dec, ms->rec, n, ln, lb, total);
+    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total);
+    src = data;
   }
   {
     int d = top - 1;
@@ -532,9 +545,8 @@ extern "C" int dvp_ecfft_extend_dev(dvp_ecfft* c, const void* d_in, uint32_t bat
   if (!c || !d_in || !d_out || batch == 0) return DVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   size_t n = c->n_leaves >> 1;
-  if (d_in != d_out)
-    DVP_HIP(hipMemcpyAsync(d_out, d_in, (size_t)batch * n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-  return extend_inplace(c, 0, 0, (Fr*)d_out, batch, st);
+  (void)n;
+  return extend_from(c, 0, 0, (const Fr*)d_in, (Fr*)d_out, batch, st);  // the first pass reads d_in, everything after it d_out
 }
 
 extern "C" int dvp_ecfft_extend(dvp_ecfft* c, const uint64_t* evals, uint32_t batch, uint64_t* out) {

@@ -35,6 +35,8 @@ struct dvp_ecfft {
 
 // in-place extend of `batch` vectors of (N >> sl)/2 values on the stride-2^sl subtree
 int extend_inplace(dvp_ecfft* c, int sl, int to_even, dvp::Fr* data, uint32_t batch, hipStream_t st);
+// out of place: `src` (batch vectors, read by the first pass only) -> `data`
+int extend_from(dvp_ecfft* c, int sl, int to_even, const dvp::Fr* src, dvp::Fr* data, uint32_t batch, hipStream_t st);
 
 namespace dvp {
 // Z_0(x) = U - c0 V through the first kk isogenies (x Montgomery in, Montgomery out)

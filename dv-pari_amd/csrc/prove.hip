@@ -687,16 +687,17 @@ extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, 
   hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
   const size_t nw = p->n_wires;
-  if (d_assignment != p->w) DVP_HIP(hipMemcpyAsync(p->w, d_assignment, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  // the witness goes straight into the scalar vector of the first MSM, [w | q2], and every stage reads it there (p->w is only the
+  // staging buffer of the host-pointer seam): one 32 B / wire copy per proof instead of two
+  if (d_assignment != p->SA) DVP_HIP(hipMemcpyAsync(p->SA, d_assignment, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   p->pub_host.resize((size_t)p->n_pub * 4);
-  if (p->n_pub) DVP_HIP(hipMemcpyAsync(p->pub_host.data(), p->w + 1, (size_t)p->n_pub * 32, hipMemcpyDeviceToHost, st));
+  if (p->n_pub) DVP_HIP(hipMemcpyAsync(p->pub_host.data(), p->SA + 1, (size_t)p->n_pub * 32, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemsetAsync(p->flags, 0xff, 16, st));
   Csr A{p->mat[0].row_ptr, p->mat[0].wire, p->mat[0].coeff, p->mat[0].n_rows};
   Csr B{p->mat[1].row_ptr, p->mat[1].wire, p->mat[1].coeff, p->mat[1].n_rows};
   Csr C{p->mat[2].row_ptr, p->mat[2].wire, p->mat[2].coeff, p->mat[2].n_rows};
   dim3 gm(cdiv(m, PT)), bt(PT);
-  hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->w, p->dD, p->n_pub, m, p->E, p->flags);
-  DVP_HIP(hipMemcpyAsync(p->SA, p->w, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(k_r1cs_eval, gm, bt, 0, st, A, B, C, p->coeffs_m, p->SA, p->dD, p->n_pub, m, p->E, p->flags);
   DVP_HIP(hipGetLastError());
   if (need_extend) {
     DVP_TRY(dvp_prove_extend_vectors(p, (1u << prover_n_ext(p)) - 1, stream));
@@ -739,9 +740,8 @@ extern "C" int dvp_prove_extend_vectors(dvp_prover* p, uint32_t mask, void* stre
     if (!((mask >> v) & 1)) { ++v; continue; }
     uint32_t e = v;
     while (e < n_ext && ((mask >> e) & 1)) ++e;
-    DVP_HIP(hipMemcpyAsync(p->E2 + (size_t)v * m, p->E + (size_t)v * m, (size_t)(e - v) * m * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     ProfScope pe(PROF_EXTEND_TOTAL, st);
-    DVP_TRY(extend_inplace(p->tree, 0, 0, p->E2 + (size_t)v * m, e - v, st));
+    DVP_TRY(extend_from(p->tree, 0, 0, p->E + (size_t)v * m, p->E2 + (size_t)v * m, e - v, st));  // E (a, b, c' on D) stays as it is
     pe.stop();
     v = e;
   }
@@ -764,9 +764,9 @@ extern "C" int dvp_prove_quotient(dvp_prover* p, void* stream) {
   if (p->ext_filled != (1u << prover_n_ext(p)) - 1) return DVP_EINVAL;  // a missed broadcast would otherwise give a silently wrong q2
   dim3 gm(cdiv(m, PT)), bt(PT);
   if (prover_n_ext(p) == 3)
-    hipLaunchKernelGGL(k_quotient<true>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
+    hipLaunchKernelGGL(k_quotient<true>, gm, bt, 0, st, p->E2, p->z2inv, m, p->SA, p->dD2, p->n_pub, p->r2, p->SA + nw);
   else
-    hipLaunchKernelGGL(k_quotient<false>, gm, bt, 0, st, p->E2, p->z2inv, m, p->w, p->dD2, p->n_pub, p->r2, p->SA + nw);
+    hipLaunchKernelGGL(k_quotient<false>, gm, bt, 0, st, p->E2, p->z2inv, m, p->SA, p->dD2, p->n_pub, p->r2, p->SA + nw);
   DVP_HIP(hipGetLastError());
   p->last_begin_extended = true;
   return DVP_OK;
