@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def one(pattern):
@@ -42,6 +42,12 @@ except AssertionError:
     pass
 
 
+try:  # the wave-level trace of the pair rounds (tools/wave_trace.py), when the refresh ran it
+    shutil.copy(os.path.join(SRC, "wave_trace.json"), os.path.join(DST, f"{tag}_wave_trace_pair_rounds.json"))
+except Exception as e:
+    print("no wave trace in this refresh:", e)
+
+
 def round0_dispatches(dirname):
     """per dispatch {counter: value, ms}: the k_affine_round<true> launches, i.e. the FIRST pair round of each MSM (the
     dominant kernel; the later rounds, k_affine_round<false>, run the same code on compacted inputs)"""
@@ -53,7 +59,7 @@ def round0_dispatches(dirname):
     # bench.py's untimed legs (microbenchmarks, stand-alone MSMs, the second table flavour) come after the proofs: only the
     # launches before the first microbenchmark dispatch belong to the timed configuration
     first_extra = min([i for i, d in disp.items() if "k_ubench" in d["name"]], default=None)
-    out = [d for i, d in disp.items() if "k_affine_round<true>" in d["name"] and (first_extra is None or i < first_extra)]
+    out = [d for i, d in disp.items() if "k_affine_round<true" in d["name"] and (first_extra is None or i < first_extra)]
     assert out, dirname
     return out
 

@@ -13,7 +13,7 @@ echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats done"
-# the default command (both timed loops: one proof at a time, then two in flight) under the same tracer: what the driver's bench run executes
+# the default command (the timed one-at-a-time loop, then -- outside it -- the two-in-flight leg and the other extras skipped here) under the same tracer
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o d --output-format csv -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > $OUT/bench_default_under_rocprof.json 2> $OUT/stats_default.err
 echo "stats (default command) done"
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
@@ -30,4 +30,7 @@ echo "pmc tcc done"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 20 22 > $OUT/msm_bench.log 2>&1
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/msm16 -o m --output-format csv -- python3 $ROOT/tools/msm_bench.py 16 > $OUT/msm16_bench.log 2>&1
 echo "msm stats done"
+cd $ROOT && timeout -s USR1 -k 30 300 python3 tools/wave_trace.py 20 $OUT/wave_trace.json > $OUT/wave_trace.log 2>&1 || echo "wave trace failed"
+rm -f $OUT/wave_trace.npy
+echo "wave trace done"
 ls -R $OUT | head -40
