@@ -240,7 +240,42 @@ __device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ mats, i
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256)
+// two layers per barrier inside the block (the radix-4 step of k_butterfly4 on the LDS copy): half the barriers and half the LDS
+// round trips of the per-layer loop.  lh2 = log2 of the narrow layer's pair distance; wide layer first when DEC.
+template <bool DEC>
+__device__ __forceinline__ void lds_bfly4(Fr* x, const Fr29* __restrict__ mats_wide, const Fr29* __restrict__ mats_narrow, int lh2, uint32_t quads) {
+  const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
+  for (uint32_t q = threadIdx.x; q < quads; q += blockDim.x) {
+    const uint32_t j = q & (h2 - 1);
+    const uint32_t i0 = ((q >> lh2) << (lh2 + 2)) | j;
+    const Fr29* ma = mats_wide + 4 * (size_t)j;
+    const Fr29* mb = mats_wide + 4 * (size_t)(j + h2);
+    const Fr29* mc = mats_narrow + 4 * (size_t)j;
+    Fr x0 = x[i0], x1 = x[i0 + h2], x2 = x[i0 + h1], x3 = x[i0 + h1 + h2];
+    Fr29 e0 = fr29_from(x0), e1 = fr29_from(x1), e2 = fr29_from(x2), e3 = fr29_from(x3);
+    if (DEC) {
+      x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);
+      x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);
+      e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
+      const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
+      x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);
+      x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);
+    } else {
+      {
+        const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
+        x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);
+        x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);
+      }
+      e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
+      x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);
+      x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);
+    }
+    x[i0] = x0; x[i0 + h2] = x1; x[i0 + h1] = x2; x[i0 + h1 + h2] = x3;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr29* __restrict__ dec,
                const Fr29* __restrict__ rec, uint32_t n, int ln, int lb, size_t total) {
   __shared__ Fr x[FUSE_ELEMS];
@@ -248,13 +283,20 @@ k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-
   const uint32_t elems = (uint32_t)min((size_t)FUSE_ELEMS, total - base);
   for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) x[k] = src[base + k];
   __syncthreads();
-  for (int L = 0; L < lb; ++L) {  // decompose, sub-block size 2^(lb-L)
-    int d = ln - lb + L;
-    lds_bfly(x, dec + 4 * (size_t)(n - (n >> d)), lb - L - 1, elems >> 1);
+  auto mats_of = [&](const Fr29* base, int L) { return base + 4 * (size_t)(n - (n >> (ln - lb + L))); };
+  const bool whole = elems == FUSE_ELEMS || (elems & 3u) == 0;  // (a short last block still holds whole sub-blocks of every layer it runs)
+  {
+    int L = 0;  // decompose, sub-block size 2^(lb-L); two layers per barrier while two remain
+    if (whole)
+      for (; L + 1 < lb; L += 2) lds_bfly4<true>(x, mats_of(dec, L), mats_of(dec, L + 1), lb - L - 2, elems >> 2);
+    for (; L < lb; ++L) lds_bfly(x, mats_of(dec, L), lb - L - 1, elems >> 1);
   }
-  for (int L = lb - 1; L >= 0; --L) {  // recombine
-    int d = ln - lb + L;
-    lds_bfly(x, rec + 4 * (size_t)(n - (n >> d)), lb - L - 1, elems >> 1);
+  {
+    int L = lb - 1;  // recombine: the odd layer (the innermost one) first, as the decompose left it
+    if (whole && (lb & 1)) { lds_bfly(x, mats_of(rec, L), lb - L - 1, elems >> 1); --L; }
+    if (whole)
+      for (; L >= 1; L -= 2) lds_bfly4<false>(x, mats_of(rec, L - 1), mats_of(rec, L), lb - L - 1, elems >> 2);
+    for (; L >= 0; --L) lds_bfly(x, mats_of(rec, L), lb - L - 1, elems >> 1);
   }
   for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) data[base + k] = x[k];
 }
