@@ -151,70 +151,146 @@ __global__ void __launch_bounds__(256) k_build_mats(const Fr* __restrict__ Ld, i
   }
 }
 
-// One butterfly pass over `batch` vectors of n values (in place).  Blocks of size 2h; pair (i, i+h)
-// inside each block uses matrix i of this layer.  One thread = one pair for all batch vectors, so
-// the 128-byte matrix is read once per pair and reused `batch` times.
-template <int BATCH>
+// ---- TWISTED butterflies (round 4) ---------------------------------------------------------------------------------------
+// The matrices above are  recombine = diag(v0, v1) [[1, s0], [1, s1]]  with v = q(s)^(h - 1) (q = the isogeny's denominator) and
+// decompose = its inverse.  Carry every value divided by the twist  W_d(s) = v_d(s) W_{d+1}(psi_d(s)),  W_bottom = 1  -- the
+// product of the v factors along the point's orbit down the isogeny chain.  Both halves of a decomposition live at the same
+// image point t, so they share ONE twist W_{d+1}(t), and in twisted values Q = P / W a butterfly is just
+//      recombine   Q(s0) = Q0 + s0 Q1,   Q(s1) = Q0 + s1 Q1
+//      decompose   Q1 = (Q(s0) - Q(s1)) / (s0 - s1),   Q0 = Q(s0) - s0 Q1
+// TWO field products per pair (each with its addition folded into the Montgomery accumulation, fr_muladd29: 2 x 96 limb
+// products) instead of the FOUR of a general 2x2 matrix (2 x fr_dot2: 2 x 160), and 64 bytes of constants per pair instead of
+// 128.  The twist depends only on the point, i.e. on the position in the top-level vector: an extend multiplies its input by
+// 1 / W^src once (fused into its first pass) and its output by W^dst once (fused into its last pass); at the bottom both twists
+// are 1, which is where the source and destination halves meet.  Values are the same field elements as before: every parity
+// test (oracle extend / enter / exit element for element, FFTR sections, proofs) is unchanged.
+// Constants per pair (Montgomery form, pre-sliced): decompose (1 / (s0 - s1), -s0), recombine (s0, s1); layer d at offset
+// 2 (n - (n >> d)).  The true 2x2 matrices are still built on demand for dvp_debug_ecfft_matrices / FFTR tree files (k_build_mats).
+__global__ void __launch_bounds__(256) k_build_twiddles(const Fr* __restrict__ Ld, int sl, uint32_t nd, int src, int dst, Fr29* __restrict__ dec,
+                                                        Fr29* __restrict__ rec) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t h = nd >> 1;
+  if (i >= h) return;
+  {
+    Fr s0 = Ld[(size_t)(2 * i + src) << sl];
+    Fr s1 = Ld[(size_t)(2 * i + src + nd) << sl];
+    dec[2 * (size_t)i + 0] = fr29_from(fr_inv(fr_sub(s0, s1)));
+    dec[2 * (size_t)i + 1] = fr29_from(fr_neg(s0));
+  }
+  rec[2 * (size_t)i + 0] = fr29_from(Ld[(size_t)(2 * i + dst) << sl]);
+  rec[2 * (size_t)i + 1] = fr29_from(Ld[(size_t)(2 * i + dst + nd) << sl]);
+}
+// W_d[j] = v_d(point of position j in a block of nd values) * W_{d+1}[j mod (nd / 2)], bottom up; positions j < nd/2 sit at the
+// first point of pair j, the others at the second point of pair j - nd/2 (that is where the in-place butterflies leave them)
+__global__ void __launch_bounds__(256) k_twist_layer(const Fr* __restrict__ Ld, int sl, uint32_t nd, Fr x0, int parity, const Fr* __restrict__ w_next,
+                                                     Fr* __restrict__ w_cur) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nd) return;
+  const uint32_t h = nd >> 1, i = j & (h - 1);
+  const Fr s = Ld[(size_t)(2 * i + parity + (j >= h ? nd : 0)) << sl];
+  Fr v = fr_pow_u64(fr_sub(s, x0), (uint64_t)h - 1);
+  if (w_next) v = fr_mul(v, w_next[i]);
+  w_cur[j] = v;
+}
+__global__ void __launch_bounds__(256) k_twist_finish(const Fr* __restrict__ w_src, const Fr* __restrict__ w_dst, uint32_t n, Fr29* __restrict__ win,
+                                                      Fr29* __restrict__ wout) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  win[j] = fr29_from(fr_inv(w_src[j]));
+  wout[j] = fr29_from(w_dst[j]);
+}
+
+struct Tw {
+  Fr29 a, b;
+};
+__device__ __forceinline__ Tw tw_load(const Fr29* __restrict__ t, uint32_t i) {
+  Tw r;
+  r.a = t[2 * (size_t)i];
+  r.b = t[2 * (size_t)i + 1];
+  return r;
+}
+// (e0, e1) = (Q(s0), Q(s1)) -> (Q0, Q1); t = (1 / (s0 - s1), -s0)
+__device__ __forceinline__ void bf_dec(Fr& e0, Fr& e1, const Tw& t) {
+  const Fr q1 = fr_mul29(t.a, fr29_from(fr_sub(e0, e1)));
+  e0 = fr_muladd29(t.b, fr29_from(q1), fr29_from(e0));
+  e1 = q1;
+}
+// (e0, e1) = (Q0, Q1) -> (Q(s0), Q(s1)); t = (s0, s1)
+__device__ __forceinline__ void bf_rec(Fr& e0, Fr& e1, const Tw& t) {
+  const Fr29 q0 = fr29_from(e0), q1 = fr29_from(e1);
+  e0 = fr_muladd29(t.a, q1, q0);
+  e1 = fr_muladd29(t.b, q1, q0);
+}
+__device__ __forceinline__ Fr tw_scale(const Fr29* __restrict__ w, uint32_t pos, const Fr& x) { return fr_mul29(w[pos], fr29_from(x)); }
+
+// One butterfly pass over `batch` vectors of n values.  Blocks of size 2h; pair (i, i+h) inside each block uses constants i of
+// this layer.  One thread = one pair for all batch vectors, so the constants are read once per pair and reused `batch` times.
+// pre / post (nullptr = none): the twists of the first / last pass of an extend, indexed by the position in the vector.
+template <int BATCH, bool DEC>
 __global__ void __launch_bounds__(256) k_butterfly(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
-                                                   const Fr29* __restrict__ mats, int lh, uint32_t n) {
+                                                   const Fr29* __restrict__ tws, int lh, uint32_t n, const Fr29* __restrict__ pre,
+                                                   const Fr29* __restrict__ post, uint32_t nv /* values per vector (twist index range) */) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (n >> 1)) return;
   uint32_t h = 1u << lh;
   uint32_t i = tid & (h - 1);
   uint32_t i0 = ((tid >> lh) << (lh + 1)) | i;
   uint32_t i1 = i0 + h;
-  const Fr29* m = mats + 4 * (size_t)i;
-  Fr29 m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
+  const Tw t = tw_load(tws, i);
 #pragma unroll
   for (int b = 0; b < BATCH; ++b) {
     Fr* v = data + (size_t)b * n;
     const Fr* u = src + (size_t)b * n;
-    Fr29 e0 = fr29_from(u[i0]), e1 = fr29_from(u[i1]);
-    v[i0] = fr_dot2(m00, e0, m01, e1);
-    v[i1] = fr_dot2(m10, e0, m11, e1);
+    Fr e0 = u[i0], e1 = u[i1];
+    if (pre) { e0 = tw_scale(pre, i0 & (nv - 1), e0); e1 = tw_scale(pre, i1 & (nv - 1), e1); }
+    if (DEC) bf_dec(e0, e1, t); else bf_rec(e0, e1, t);
+    if (post) { e0 = tw_scale(post, i0 & (nv - 1), e0); e1 = tw_scale(post, i1 & (nv - 1), e1); }
+    v[i0] = e0;
+    v[i1] = e1;
   }
 }
 
 // TWO butterfly layers in one pass (radix 4): layer d (pairs h1 = 2^lh apart) and layer d + 1 (pairs h2 = h1 / 2 apart) only mix
 // the four values {j, j + h2, j + h1, j + h1 + h2} of a block of 4 h2, so one thread loads them once, applies both layers in
-// registers and stores them once: half the HBM round trips of the data (the per-layer passes above stream 3 x 64 MB per layer at
-// m = 2^20 and are as much HBM- as VALU-bound).  Matrices: two of layer d (M_d[j], M_d[j + h2]) and one of layer d + 1
-// (M_{d+1}[j], shared by both pairs).  DEC = decompose order (wide layer first); recombine runs the narrow layer first.
-// BATCH vectors: lane = (quad of values, vector) with the vector index fastest, so the BATCH lanes that need the same three
-// matrices sit in the same wave and their loads are one request (holding the twelve matrix entries in registers across a loop
-// over the vectors instead costs 256 VGPRs, or 400-600 bytes of scratch per lane at three waves per SIMD).
+// registers and stores them once: half the HBM round trips of the data.  Constants: two pairs of layer d (j, j + h2) and one of
+// layer d + 1 (j, shared by both of its pairs).  DEC = decompose order (wide layer first); recombine runs the narrow layer first.
+// BATCH vectors: lane = (quad of values, vector) with the vector index fastest, so the BATCH lanes that need the same constants
+// sit in the same wave and their loads are one request.
 template <int BATCH, bool DEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_butterfly4(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
-                                                    const Fr29* __restrict__ mats_wide, const Fr29* __restrict__ mats_narrow, int lh2, uint32_t n) {
+                                                    const Fr29* __restrict__ tw_wide, const Fr29* __restrict__ tw_narrow, int lh2, uint32_t n,
+                                                    const Fr29* __restrict__ pre, const Fr29* __restrict__ post, uint32_t nv) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t tid = gid / BATCH, bv = gid - tid * BATCH;
   if (tid >= (n >> 2)) return;
   const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
   const uint32_t j = tid & (h2 - 1);
   const uint32_t i0 = ((tid >> lh2) << (lh2 + 2)) | j;
-  const Fr29* ma = mats_wide + 4 * (size_t)j;
-  const Fr29* mb = mats_wide + 4 * (size_t)(j + h2);
-  const Fr29* mc = mats_narrow + 4 * (size_t)j;
   Fr* v = data + (size_t)bv * n + i0;
   const Fr* u = src + (size_t)bv * n + i0;
   Fr x0 = u[0], x1 = u[h2], x2 = u[h1], x3 = u[h1 + h2];
-  Fr29 e0 = fr29_from(x0), e1 = fr29_from(x1), e2 = fr29_from(x2), e3 = fr29_from(x3);
+  if (pre) {
+    const uint32_t p0 = i0 & (nv - 1);
+    x0 = tw_scale(pre, p0, x0); x1 = tw_scale(pre, p0 + h2, x1); x2 = tw_scale(pre, p0 + h1, x2); x3 = tw_scale(pre, p0 + h1 + h2, x3);
+  }
   if (DEC) {
-    x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);  // layer d: (j, j + h1)
-    x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);  //          (j + h2, j + h2 + h1)
-    e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
-    const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
-    x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);  // layer d + 1: (j, j + h2)
-    x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);  //              (j + h1, j + h1 + h2)
+    bf_dec(x0, x2, tw_load(tw_wide, j));
+    bf_dec(x1, x3, tw_load(tw_wide, j + h2));
+    const Tw c = tw_load(tw_narrow, j);
+    bf_dec(x0, x1, c);
+    bf_dec(x2, x3, c);
   } else {
     {
-      const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
-      x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);
-      x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);
+      const Tw c = tw_load(tw_narrow, j);
+      bf_rec(x0, x1, c);
+      bf_rec(x2, x3, c);
     }
-    e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
-    x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);
-    x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);
+    bf_rec(x0, x2, tw_load(tw_wide, j));
+    bf_rec(x1, x3, tw_load(tw_wide, j + h2));
+  }
+  if (post) {
+    const uint32_t p0 = i0 & (nv - 1);
+    x0 = tw_scale(post, p0, x0); x1 = tw_scale(post, p0 + h2, x1); x2 = tw_scale(post, p0 + h1, x2); x3 = tw_scale(post, p0 + h1 + h2, x3);
   }
   v[0] = x0; v[h2] = x1; v[h1] = x2; v[h1 + h2] = x3;
 }
@@ -222,53 +298,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 // Fused bottom of an extend: the last `lb` decompose layers and the first `lb` recombine layers only mix
 // elements inside aligned blocks of 2^lb <= 2048 values, so a workgroup keeps 2048 consecutive values
 // (64 KB) in LDS and runs all 2*lb butterfly layers on them in ONE launch and ONE HBM round trip (the
-// per-layer kernels above then cover only the top layers of long vectors).  The matrices of these layers
-// total < 0.5 MB per tree and are served from L2.  `data` is the concatenation of the batch vectors.
+// per-layer kernels above then cover only the top layers of long vectors).  The constants of these layers
+// total < 0.25 MB per tree and are served from L2.  `data` is the concatenation of the batch vectors.
 constexpr int FUSE_LOG = 11;
 constexpr uint32_t FUSE_ELEMS = 1u << FUSE_LOG;
 
-__device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ mats, int lh, uint32_t pairs) {
+template <bool DEC>
+__device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ tws, int lh, uint32_t pairs) {
   const uint32_t h = 1u << lh;
   for (uint32_t q = threadIdx.x; q < pairs; q += blockDim.x) {
     uint32_t i = q & (h - 1);
     uint32_t i0 = ((q >> lh) << (lh + 1)) | i, i1 = i0 + h;
-    const Fr29* m = mats + 4 * (size_t)i;
-    Fr29 e0 = fr29_from(x[i0]), e1 = fr29_from(x[i1]);
-    x[i0] = fr_dot2(m[0], e0, m[1], e1);
-    x[i1] = fr_dot2(m[2], e0, m[3], e1);
+    Fr e0 = x[i0], e1 = x[i1];
+    if (DEC) bf_dec(e0, e1, tw_load(tws, i)); else bf_rec(e0, e1, tw_load(tws, i));
+    x[i0] = e0;
+    x[i1] = e1;
   }
   __syncthreads();
 }
-
 // two layers per barrier inside the block (the radix-4 step of k_butterfly4 on the LDS copy): half the barriers and half the LDS
 // round trips of the per-layer loop.  lh2 = log2 of the narrow layer's pair distance; wide layer first when DEC.
 template <bool DEC>
-__device__ __forceinline__ void lds_bfly4(Fr* x, const Fr29* __restrict__ mats_wide, const Fr29* __restrict__ mats_narrow, int lh2, uint32_t quads) {
+__device__ __forceinline__ void lds_bfly4(Fr* x, const Fr29* __restrict__ tw_wide, const Fr29* __restrict__ tw_narrow, int lh2, uint32_t quads) {
   const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
   for (uint32_t q = threadIdx.x; q < quads; q += blockDim.x) {
     const uint32_t j = q & (h2 - 1);
     const uint32_t i0 = ((q >> lh2) << (lh2 + 2)) | j;
-    const Fr29* ma = mats_wide + 4 * (size_t)j;
-    const Fr29* mb = mats_wide + 4 * (size_t)(j + h2);
-    const Fr29* mc = mats_narrow + 4 * (size_t)j;
     Fr x0 = x[i0], x1 = x[i0 + h2], x2 = x[i0 + h1], x3 = x[i0 + h1 + h2];
-    Fr29 e0 = fr29_from(x0), e1 = fr29_from(x1), e2 = fr29_from(x2), e3 = fr29_from(x3);
     if (DEC) {
-      x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);
-      x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);
-      e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
-      const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
-      x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);
-      x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);
+      bf_dec(x0, x2, tw_load(tw_wide, j));
+      bf_dec(x1, x3, tw_load(tw_wide, j + h2));
+      const Tw c = tw_load(tw_narrow, j);
+      bf_dec(x0, x1, c);
+      bf_dec(x2, x3, c);
     } else {
       {
-        const Fr29 c00 = mc[0], c01 = mc[1], c10 = mc[2], c11 = mc[3];
-        x0 = fr_dot2(c00, e0, c01, e1); x1 = fr_dot2(c10, e0, c11, e1);
-        x2 = fr_dot2(c00, e2, c01, e3); x3 = fr_dot2(c10, e2, c11, e3);
+        const Tw c = tw_load(tw_narrow, j);
+        bf_rec(x0, x1, c);
+        bf_rec(x2, x3, c);
       }
-      e0 = fr29_from(x0); e1 = fr29_from(x1); e2 = fr29_from(x2); e3 = fr29_from(x3);
-      x0 = fr_dot2(ma[0], e0, ma[1], e2); x2 = fr_dot2(ma[2], e0, ma[3], e2);
-      x1 = fr_dot2(mb[0], e1, mb[1], e3); x3 = fr_dot2(mb[2], e1, mb[3], e3);
+      bf_rec(x0, x2, tw_load(tw_wide, j));
+      bf_rec(x1, x3, tw_load(tw_wide, j + h2));
     }
     x[i0] = x0; x[i0 + h2] = x1; x[i0 + h1] = x2; x[i0 + h1 + h2] = x3;
   }
@@ -277,28 +347,37 @@ __device__ __forceinline__ void lds_bfly4(Fr* x, const Fr29* __restrict__ mats_w
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr29* __restrict__ dec,
-               const Fr29* __restrict__ rec, uint32_t n, int ln, int lb, size_t total) {
+               const Fr29* __restrict__ rec, uint32_t n, int ln, int lb, size_t total, const Fr29* __restrict__ pre, const Fr29* __restrict__ post) {
   __shared__ Fr x[FUSE_ELEMS];
   const size_t base = (size_t)blockIdx.x * FUSE_ELEMS;
   const uint32_t elems = (uint32_t)min((size_t)FUSE_ELEMS, total - base);
-  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) x[k] = src[base + k];
+  const uint32_t pos0 = (uint32_t)(base & (size_t)(n - 1));  // position of the block's first value inside its vector (n is a power of two)
+  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) {
+    Fr v = src[base + k];
+    if (pre) v = tw_scale(pre, (pos0 + k) & (n - 1), v);
+    x[k] = v;
+  }
   __syncthreads();
-  auto mats_of = [&](const Fr29* base, int L) { return base + 4 * (size_t)(n - (n >> (ln - lb + L))); };
+  auto tw_of = [&](const Fr29* b, int L) { return b + 2 * (size_t)(n - (n >> (ln - lb + L))); };
   const bool whole = elems == FUSE_ELEMS || (elems & 3u) == 0;  // (a short last block still holds whole sub-blocks of every layer it runs)
   {
     int L = 0;  // decompose, sub-block size 2^(lb-L); two layers per barrier while two remain
     if (whole)
-      for (; L + 1 < lb; L += 2) lds_bfly4<true>(x, mats_of(dec, L), mats_of(dec, L + 1), lb - L - 2, elems >> 2);
-    for (; L < lb; ++L) lds_bfly(x, mats_of(dec, L), lb - L - 1, elems >> 1);
+      for (; L + 1 < lb; L += 2) lds_bfly4<true>(x, tw_of(dec, L), tw_of(dec, L + 1), lb - L - 2, elems >> 2);
+    for (; L < lb; ++L) lds_bfly<true>(x, tw_of(dec, L), lb - L - 1, elems >> 1);
   }
   {
     int L = lb - 1;  // recombine: the odd layer (the innermost one) first, as the decompose left it
-    if (whole && (lb & 1)) { lds_bfly(x, mats_of(rec, L), lb - L - 1, elems >> 1); --L; }
+    if (whole && (lb & 1)) { lds_bfly<false>(x, tw_of(rec, L), lb - L - 1, elems >> 1); --L; }
     if (whole)
-      for (; L >= 1; L -= 2) lds_bfly4<false>(x, mats_of(rec, L - 1), mats_of(rec, L), lb - L - 1, elems >> 2);
-    for (; L >= 0; --L) lds_bfly(x, mats_of(rec, L), lb - L - 1, elems >> 1);
+      for (; L >= 1; L -= 2) lds_bfly4<false>(x, tw_of(rec, L - 1), tw_of(rec, L), lb - L - 1, elems >> 2);
+    for (; L >= 0; --L) lds_bfly<false>(x, tw_of(rec, L), lb - L - 1, elems >> 1);
   }
-  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) data[base + k] = x[k];
+  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) {
+    Fr v = x[k];
+    if (post) v = tw_scale(post, (pos0 + k) & (n - 1), v);
+    data[base + k] = v;
+  }
 }
 
 // enter combine (one recursion level, all sub-problems at once):
@@ -352,18 +431,40 @@ static int build_matset(dvp_ecfft* c, int sl, int to_even, MatSet** out, hipStre
   uint32_t n = (c->n_leaves >> sl) >> 1;  // evaluations moved by extend on this subtree
   MatSet ms;
   if (n > 1) {
-    size_t bytes = (size_t)(n - 1) * 4 * sizeof(Fr);
+    size_t bytes = (size_t)(n - 1) * 2 * sizeof(Fr29);
     DVP_HIP(hipMalloc((void**)&ms.dec, bytes));
     DVP_HIP(hipMalloc((void**)&ms.rec, bytes));
+    DVP_HIP(hipMalloc((void**)&ms.win, (size_t)n * sizeof(Fr29)));
+    DVP_HIP(hipMalloc((void**)&ms.wout, (size_t)n * sizeof(Fr29)));
     int src = to_even ? 1 : 0, dst = to_even ? 0 : 1;
     int ln = 31 - __builtin_clz(n);
     for (int d = 0; d < ln; ++d) {
       uint32_t nd = n >> d;
-      size_t off = 4 * (size_t)(n - nd);
-      hipLaunchKernelGGL(k_build_mats, dim3(cdiv(nd >> 1, TPB)), dim3(TPB), 0, st, c->layer(d), sl, nd, c->x0[d],
-                         src, dst, ms.dec + off, ms.rec + off);
+      size_t off = 2 * (size_t)(n - nd);
+      hipLaunchKernelGGL(k_build_twiddles, dim3(cdiv(nd >> 1, TPB)), dim3(TPB), 0, st, c->layer(d), sl, nd, src, dst, ms.dec + off, ms.rec + off);
     }
+    // the twists, bottom up: W_d from W_{d+1} (ping-pong), once per parity
+    DevBuf wa, wb, ws, wd;
+    DVP_TRY(wa.alloc((size_t)n * sizeof(Fr)));
+    DVP_TRY(wb.alloc((size_t)n * sizeof(Fr)));
+    DVP_TRY(ws.alloc((size_t)n * sizeof(Fr)));
+    DVP_TRY(wd.alloc((size_t)n * sizeof(Fr)));
+    for (int par = 0; par < 2; ++par) {
+      const int parity = par == 0 ? src : dst;
+      Fr* cur = wa.as<Fr>();
+      Fr* nxt = wb.as<Fr>();
+      const Fr* prev = nullptr;
+      for (int d = ln - 1; d >= 0; --d) {
+        uint32_t nd = n >> d;
+        Fr* outp = d == 0 ? (par == 0 ? ws.as<Fr>() : wd.as<Fr>()) : cur;
+        hipLaunchKernelGGL(k_twist_layer, dim3(cdiv(nd, TPB)), dim3(TPB), 0, st, c->layer(d), sl, nd, c->x0[d], parity, prev, outp);
+        prev = outp;
+        Fr* t = cur; cur = nxt; nxt = t;
+      }
+    }
+    hipLaunchKernelGGL(k_twist_finish, dim3(cdiv(n, TPB)), dim3(TPB), 0, st, ws.as<Fr>(), wd.as<Fr>(), n, ms.win, ms.wout);
     DVP_HIP(hipGetLastError());
+    DVP_HIP(hipStreamSynchronize(st));  // the scratch buffers go out of scope
   }
   c->mats[key] = ms;
   *out = &c->mats[key];
@@ -391,24 +492,37 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   int ln = 31 - __builtin_clz(n);
   // Blocks are contiguous, so `batch` vectors of n behave like one vector of batch*n for the block
   // structure; the BATCH template only buys matrix reuse when the batch is small and n is large.
-  auto pass = [&](const Fr29* mats, int lh) {
-    if (batch == 4) launch_bfly<4>(src, data, mats, lh, n, st);
-    else if (batch == 3) launch_bfly<3>(src, data, mats, lh, n, st);
-    else if (batch == 2) launch_bfly<2>(src, data, mats, lh, n, st);
-    else launch_bfly<1>(src, data, mats, lh, (uint32_t)((size_t)batch * n), st);
+  // The first launch multiplies its input by the source twist, the last one its output by the destination twist (see "TWISTED
+  // butterflies" above); a pass knows which it is from `first` / the `last` flag of its caller.
+  bool first = true;
+  auto pre_of = [&]() { const Fr29* r = first ? ms->win : nullptr; first = false; return r; };
+  auto pass = [&](const Fr29* base, int d, bool dec, bool last) {
+    const Fr29* tws = base + 2 * (size_t)(n - (n >> d));
+    const int lh = ln - d - 1;
+    const Fr29* pre = pre_of();
+    const Fr29* post = last ? ms->wout : nullptr;
+    const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
+    const dim3 g(cdiv(nn >> 1, TPB)), b(TPB);
+#define DVP_BF(B) \
+  do { if (dec) hipLaunchKernelGGL((k_butterfly<B, true>), g, b, 0, st, src, data, tws, lh, nn, pre, post, n); \
+       else hipLaunchKernelGGL((k_butterfly<B, false>), g, b, 0, st, src, data, tws, lh, nn, pre, post, n); } while (0)
+    if (batch == 4) DVP_BF(4); else if (batch == 3) DVP_BF(3); else if (batch == 2) DVP_BF(2); else DVP_BF(1);
+#undef DVP_BF
     src = data;
   };
   // two layers per pass (k_butterfly4) while two top layers remain; `wide` = layer d, `narrow` = layer d + 1
-  auto pass4 = [&](const Fr29* base, int d, bool dec) {
-    const Fr29* wide = base + 4 * (size_t)(n - (n >> d));
-    const Fr29* narrow = base + 4 * (size_t)(n - (n >> (d + 1)));
+  auto pass4 = [&](const Fr29* base, int d, bool dec, bool last) {
+    const Fr29* wide = base + 2 * (size_t)(n - (n >> d));
+    const Fr29* narrow = base + 2 * (size_t)(n - (n >> (d + 1)));
     const int lh2 = ln - d - 2;
+    const Fr29* pre = pre_of();
+    const Fr29* post = last ? ms->wout : nullptr;
     const dim3 g(cdiv((size_t)(n >> 2) * batch, TPB)), b(TPB);
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g1(cdiv(nn >> 2, TPB));
 #define DVP_BF4(B, GRID) \
-  do { if (dec) hipLaunchKernelGGL((k_butterfly4<B, true>), GRID, b, 0, st, src, data, wide, narrow, lh2, nn); \
-       else hipLaunchKernelGGL((k_butterfly4<B, false>), GRID, b, 0, st, src, data, wide, narrow, lh2, nn); } while (0)
+  do { if (dec) hipLaunchKernelGGL((k_butterfly4<B, true>), GRID, b, 0, st, src, data, wide, narrow, lh2, nn, pre, post, n); \
+       else hipLaunchKernelGGL((k_butterfly4<B, false>), GRID, b, 0, st, src, data, wide, narrow, lh2, nn, pre, post, n); } while (0)
     if (batch == 4) DVP_BF4(4, g); else if (batch == 3) DVP_BF4(3, g); else if (batch == 2) DVP_BF4(2, g); else DVP_BF4(1, g1);
 #undef DVP_BF4
     src = data;
@@ -419,20 +533,21 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   {
     int d = 0;
     if (radix4)
-      for (; d + 1 < top; d += 2) pass4(ms->dec, d, true);
-    for (; d < top; ++d) pass(ms->dec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+      for (; d + 1 < top; d += 2) pass4(ms->dec, d, true, false);
+    for (; d < top; ++d) pass(ms->dec, d, true, false);
   }
   {
     size_t total = (size_t)batch * n;
-    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total);
+    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total, pre_of(),
+                       top == 0 ? ms->wout : nullptr);
     src = data;
   }
   {
     int d = top - 1;
-    if (radix4 && (top & 1)) { pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1); --d; }  // the odd layer is the innermost one, as in the decompose
+    if (radix4 && (top & 1)) { pass(ms->rec, d, false, d == 0); --d; }  // the odd layer is the innermost one, as in the decompose
     if (radix4)
-      for (; d >= 1; d -= 2) pass4(ms->rec, d - 1, false);
-    for (; d >= 0; --d) pass(ms->rec + 4 * (size_t)(n - (n >> d)), ln - d - 1);
+      for (; d >= 1; d -= 2) pass4(ms->rec, d - 1, false, d - 1 == 0);
+    for (; d >= 0; --d) pass(ms->rec, d, false, d == 0);
   }
   DVP_HIP(hipGetLastError());
   return DVP_OK;
@@ -546,6 +661,8 @@ extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   for (auto& kv : c->mats) {
     (void)hipFree(kv.second.dec);
     (void)hipFree(kv.second.rec);
+    (void)hipFree(kv.second.win);
+    (void)hipFree(kv.second.wout);
   }
   for (auto& kv : c->xnn) (void)hipFree(kv.second);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -922,12 +1039,22 @@ __global__ void __launch_bounds__(256) k_mats_export(const Fr29* __restrict__ in
 }  // namespace dvp
 extern "C" int dvp_debug_ecfft_matrices(dvp_ecfft* c, int to_even, int which, uint64_t* out) {
   if (!c || !out || (to_even != 0 && to_even != 1) || (which != 0 && which != 1) || c->log_n < 2) return DVP_EINVAL;
-  MatSet* ms;
-  DVP_TRY(build_matset(c, 0, to_even, &ms, 0));
-  const size_t n = ((size_t)(c->n_leaves >> 1) - 1) * 4;
-  DevBuf tmp;
+  // the TRUE 2x2 matrices (what the reference stores), rebuilt on demand: extend() itself runs on the twisted constants
+  const uint32_t nv = c->n_leaves >> 1;
+  const size_t n = ((size_t)nv - 1) * 4;
+  DevBuf dec, rec, tmp;
+  DVP_TRY(dec.alloc(n * sizeof(Fr29)));
+  DVP_TRY(rec.alloc(n * sizeof(Fr29)));
   DVP_TRY(tmp.alloc(n * sizeof(Fr)));
-  hipLaunchKernelGGL(k_mats_export, dim3(cdiv(n, TPB)), dim3(TPB), 0, 0, which ? ms->rec : ms->dec, tmp.as<Fr>(), n);
+  const int src = to_even ? 1 : 0, dst = to_even ? 0 : 1;
+  const int ln = 31 - __builtin_clz(nv);
+  for (int d = 0; d < ln; ++d) {
+    const uint32_t nd = nv >> d;
+    const size_t off = 4 * (size_t)(nv - nd);
+    hipLaunchKernelGGL(k_build_mats, dim3(cdiv(nd >> 1, TPB)), dim3(TPB), 0, 0, c->layer(d), 0, nd, c->x0[d], src, dst, dec.as<Fr29>() + off,
+                       rec.as<Fr29>() + off);
+  }
+  hipLaunchKernelGGL(k_mats_export, dim3(cdiv(n, TPB)), dim3(TPB), 0, 0, which ? rec.as<Fr29>() : dec.as<Fr29>(), tmp.as<Fr>(), n);
   DVP_HIP(hipGetLastError());
   DVP_HIP(hipMemcpy(out, tmp.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
   return DVP_OK;

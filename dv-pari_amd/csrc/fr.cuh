@@ -254,6 +254,46 @@ DVP_HD Fr fr_dot2(const Fr29& a0, const Fr29& b0, const Fr29& a1, const Fr29& b1
   return fr_cond_sub_p(fr_cond_sub_p(fr_from29(r)));
 }
 
+// (a*b)/R + c mod p, fully reduced, for pre-sliced operands: c*R is c's limbs eight columns up (R = 2^232 = eight 29-bit limbs), so the
+// addition rides in the column accumulators of the Montgomery product: 64 + 32 limb products, no modular addition.  The twisted ECFFT
+// butterflies (ecfft.hip) are two of these per pair, against two fr_dot2 (2 x 160 limb products) for the untwisted 2x2 matrices.
+// T = a b + c R + m p < p^2 + 2 p R gives T / R < 3p: two conditional subtractions.  c = nullptr-like zero limbs -> plain product.
+DVP_HD Fr fr_muladd29(const Fr29& a, const Fr29& b, const Fr29& c) {
+  constexpr uint32_t p[8] = DVP_FR_P29_LIMBS;
+  uint32_t m[8], r[8];
+  uint64_t t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) t += (uint64_t)a.l[j] * b.l[i - j];
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+    m[i] = ((uint32_t)t * FR_N0_29) & FR_M29;
+    t += (uint64_t)m[i] * p[0];
+    t >>= 29;
+  }
+#pragma unroll
+  for (int i = 8; i < 16; ++i) {
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j) t += (uint64_t)a.l[j] * b.l[i - j];
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j)
+      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+    t += c.l[i - 8];
+    r[i - 8] = (uint32_t)t & FR_M29;
+    t >>= 29;
+  }
+  r[7] |= (uint32_t)t << 29;  // result < 3p < 2^234: the carry belongs to limb 7
+  return fr_cond_sub_p(fr_cond_sub_p(fr_from29(r)));
+}
+DVP_HD Fr fr_mul29(const Fr29& a, const Fr29& b) {
+  Fr29 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z.l[i] = 0;
+  return fr_muladd29(a, b, z);
+}
+
 DVP_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 DVP_HD Fr fr_to_mont(const Fr& a) { return fr_mul(a, fr_r2()); }
 DVP_HD Fr fr_from_mont(const Fr& a) { return fr_mul(a, fr_one_canon()); }
