@@ -297,7 +297,7 @@ def main():
     extras = single and not args.no_extras
 
     # ---- outside the timed region ---------------------------------------------------------------------------------------
-    host_ms = mul_rate = gather_rate = aligned_ms = aligned_gb = sliding_ms = sliding_gb = None
+    host_ms = mul_rate = gather_rate = None
     msm_standalone = None
     in_flight = None
     if extras:
@@ -395,32 +395,6 @@ def main():
             finally:
                 pv_b.close()
 
-        # footprint: the other table flavour beside the timed one.  The default (round 3) is the aligned signed-window table
-        # (W rows per base, ~5 GB at 2^20); the sliding-window flavour holds a multiple 2^j P for every bit position (233 rows,
-        # 94 GB at 2^20) and is measured here only when it fits beside what is already resident.
-        sliding_default = bool(tables[0][1] or tables[1][1])
-        other = {"DVP_MSM_SLIDE": 0} if sliding_default else {"DVP_MSM_SLIDE": 2}
-        free_b, _tot = torch.cuda.mem_get_info()
-        need_b = 0 if sliding_default else 233 * 64 * (inst.n_wires + 5 * m) + (8 << 30)
-        if need_b < free_b:
-            with dvp.tune(**other):
-                pv2 = dvp.proving.Prover(inst)
-                pv2.set_srs(srs)
-                p3 = pv2.prove_dev(assignment.data_ptr(), stream)
-                assert p3 == proof
-                k2 = max(3, min(args.steps, 10))
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(k2):
-                    pv2.prove_dev(assignment.data_ptr(), stream)
-                torch.cuda.synchronize()
-                other_ms = (time.perf_counter() - t1) / k2 * 1e3
-                other_gb = (pv2.msm_table(0)[0] + pv2.msm_table(1)[0]) / 1e9
-                pv2.close()
-            if sliding_default:
-                aligned_ms, aligned_gb = other_ms, other_gb
-            else:
-                sliding_ms, sliding_gb = other_ms, other_gb
 
     pairs_total = (inst.n_wires + m + 4 * m) * args.steps / n_shards  # (scalar, base) pairs this rank pushed through the kernel
     pairs_per_launch = pairs_total / max(acc_n, 1)
@@ -428,12 +402,11 @@ def main():
     alg_bytes = 96.0 * pairs_per_launch
     achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_n else 0.0
 
-    # entries per scalar: tau-adic expansions are ~234 digits long (the overflow window is empty in practice); a sliding
-    # window spans c + 1 digits on average (msm.hip: k_recode_slide), an aligned one exactly c
-    def per_scalar(c, sliding):
-        return 234.0 / (c + 1) + 0.6 if sliding else float(-(-234 // max(c, 1)))
-    w_eff = (sum(per_scalar(c, sl) * n for (c, _), (_, sl), n in zip(plans, tables, sizes)) / max(sum(sizes), 1)
-             if all(c for c, _ in plans) else 13)
+    # entries per scalar: one per window (the signed aligned windows: ceil(234 / c); the tau-adic ones the same over ~234 digits)
+    def per_scalar(c, _signed):
+        return float(-(-234 // max(c, 1)))
+    w_eff = (sum(per_scalar(c, sg) * n for (c, _), (_, sg), n in zip(plans, tables, sizes)) / max(sum(sizes), 1)
+             if all(c for c, _ in plans) else 12)
     # per addition: 5 products + 1 squaring (~0.13 product) + 1/B of a table-driven inversion (~15 product-equivalents);
     # B is chosen on the device (25..48 in a first round; 36 is typical at this size)
     per_add = 5.13 + 15.0 / 36.0
@@ -541,8 +514,8 @@ def main():
                          "MSM index ranges per rank, all-gather of partial points + local add; extends by vector among the ranks that need q2 / r2 "
                          "(from three such ranks up: one broadcast per vector); challenge "
                          "phase (inversions, barycentric sums, K scalars) by index with one all-gather of 128-byte records" if world > 1 else "single GPU"),
-            "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "sliding": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
-                            "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "sliding": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
+            "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "signed_windows": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
+                            "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "signed_windows": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
             "witness": "resident in HBM",
             "proofs_in_flight": 1,
             "latency_ms_one_proof": ms_per_step,
@@ -550,12 +523,9 @@ def main():
         },
         "hbm_resident_gb": hbm_resident_gb,
         "hbm_resident_note": "device memory in use on this rank's GPU after the timed loops (every prover in flight: tables, bases, MSM workspaces, trees; the torch context)",
-        "ms_per_step_aligned_tables": aligned_ms if aligned_ms is not None else (None if (tables[0][1] or tables[1][1]) else ms_per_step),
-        "aligned_tables_gb": aligned_gb if aligned_gb is not None else (None if (tables[0][1] or tables[1][1]) else round((tables[0][0] + tables[1][0]) / 1e9, 2)),
-        "ms_per_step_sliding_tables": sliding_ms,
-        "sliding_tables_gb": sliding_gb,
-        "tables_note": "the timed configuration uses the aligned signed-window tables (the default); ms_per_step_sliding_tables is the same proof "
-                       "with DVP_MSM_SLIDE=2 (a multiple 2^j P of every base for every bit position), measured after the loop when it fits",
+        "tables_gb": round((tables[0][0] + tables[1][0]) / 1e9, 2),
+        "tables_note": "fixed-base tables: aligned windows of signed binary digits, W rows 2^(o_w) P per base (the sliding-window flavours of "
+                       "rounds 2-3, 94-97 GB at this size for the same proof time, were removed in round 4)",
         "ms_per_step_host_witness": host_ms,
         "throughput_two_in_flight": in_flight,
         "roofline": roof,

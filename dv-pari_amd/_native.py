@@ -72,8 +72,6 @@ _SIGS = {
     "dvp_msm_ctx_destroy": (None, [vp]),
     "dvp_msm_ctx_plan": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dvp_msm_ctx_table_bytes": (C.c_uint64, [vp, C.POINTER(C.c_int)]),
-    "dvp_debug_recode_slide": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]),
-    "dvp_debug_recode_binary": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]),
     "dvp_debug_recode_signed": (C.c_int, [vp, C.c_size_t, C.c_int, vp, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run": (C.c_int, [vp, u64p, sz, sz, u64p, C.POINTER(C.c_int)]),
     "dvp_msm_ctx_run_dev": (C.c_int, [vp, vp, sz, sz, vp, vp, vp]),

@@ -55,7 +55,6 @@ static void tune_from_env(Tune& t) {
   t.msm_k = geti("DVP_MSM_K", t.msm_k);
   t.msm_fixed_c = geti("DVP_MSM_FIXED_C", t.msm_fixed_c);
   t.fx_hi = geti("DVP_FX_HI", t.fx_hi);
-  t.msm_slide = geti("DVP_MSM_SLIDE", t.msm_slide);
   const char* m = getenv("DVP_MSM_MODE");
   t.msm_proj = (m && !strcmp(m, "proj")) ? 1 : 0;
   t.msm_aff_min = geti("DVP_MSM_AFF_MIN", t.msm_aff_min);
@@ -70,7 +69,6 @@ static void tune_from_env(Tune& t) {
   t.msm_accum_quad_max = geti("DVP_MSM_ACCUM_QUAD_MAX", t.msm_accum_quad_max);
   t.msm_fixed_min = geti("DVP_MSM_FIXED_MIN", t.msm_fixed_min);
   t.horner_max_pub = geti("DVP_HORNER_MAX_PUB", t.horner_max_pub);
-  t.msm_table_max_gb = geti("DVP_MSM_TABLE_MAX_GB", t.msm_table_max_gb);
   t.msm_aligned_signed = geti("DVP_MSM_ALIGNED_SIGNED", t.msm_aligned_signed);
 }
 static std::mutex g_dev_mu;
@@ -88,10 +86,10 @@ Tune& tune() {
 static long long* tune_slot(const char* name) {
   dvp::Tune& t = dvp::tune();
   struct { const char* n; long long* v; } tab[] = {
-      {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi}, {"DVP_MSM_SLIDE", &t.msm_slide},
+      {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi},
       {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax}, {"DVP_MSM_AFF_BMIN", &t.msm_aff_bmin}, {"DVP_ECFFT_RADIX4", &t.ecfft_radix4}, {"DVP_MSM_WS_SLOTS", &t.msm_ws_slots}, {"DVP_MSM_GATE_MIN", &t.msm_gate_min}, {"DVP_MSM_AFF_TPB", &t.msm_aff_tpb}, {"DVP_CACHE_REPLICAS", &t.cache_replicas},
       {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_ACCUM_QUAD_MAX", &t.msm_accum_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub},
-      {"DVP_MSM_TABLE_MAX_GB", &t.msm_table_max_gb}, {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}};
+      {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}};
   for (auto& e : tab)
     if (!strcmp(name, e.n)) return e.v;
   return nullptr;

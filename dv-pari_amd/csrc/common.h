@@ -69,7 +69,6 @@ struct Tune {
   long long msm_k = 0;          // DVP_MSM_K: fan-in of the projective reducer (0 = default)
   long long msm_fixed_c = 0;    // DVP_MSM_FIXED_C: fixed-base window bits (0 = cost model)
   long long fx_hi = -1;         // DVP_FX_HI: level-1 partition bits of the fixed-base sort (-1 = c/2)
-  long long msm_slide = -1;     // DVP_MSM_SLIDE: fixed-base table flavour: unset / 0 = aligned windows (W rows per base), 1 = tau-adic sliding windows (240 rows), 2 = binary sliding windows (233 rows)
   long long msm_proj = 0;       // DVP_MSM_MODE=proj: skip the batched-affine rounds
   long long msm_aff_min = 1ll << 19;   // DVP_MSM_AFF_MIN: pair rounds run while a round has this many additions
   long long msm_gate_min = 1;   // DVP_MSM_GATE_MIN: pair rounds with at least this many additions take turns between concurrent MSMs (HeavyGate); smaller ones overlap
@@ -83,8 +82,7 @@ struct Tune {
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables
   long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)
-  long long msm_aligned_signed = 1;    // DVP_MSM_ALIGNED_SIGNED: the aligned-window tables hold 2^(c w) P and the windows are signed binary digits (0 = tau-adic aligned windows)
-  long long msm_table_max_gb = -1;     // DVP_MSM_TABLE_MAX_GB: byte budget (GB) of ONE sliding-window table (DVP_MSM_SLIDE = 1 / 2): above it the aligned flavour is built; -1 = no budget
+  long long msm_aligned_signed = 1;    // DVP_MSM_ALIGNED_SIGNED: the aligned-window tables hold 2^(c w) P and the windows are signed binary digits (0 = the tau-adic aligned windows over rows tau^(o_w) P)
 };
 Tune& tune();
 

@@ -10,8 +10,8 @@
 //              Frobenius (3 squarings) where an integer-window Pippenger needs doublings -- on a
 //              GPU that turns a ~230-step serial doubling chain into a log-depth tree.
 //              Fixed-base contexts (the prover's SRS vectors) pre-rotate the bases so that all windows share ONE bucket
-//              set, and -- when HBM allows the 240-rotation table -- let a window start at any nonzero digit (sliding
-//              windows: odd patterns only, ~8 % fewer entries; k_recode_slide, MsmFixedCtx).
+//              set (MsmFixedCtx; the default flavour cuts SIGNED windows from the scalar's binary digits instead,
+//              k_recode_signed).
 //  2. sort     counting sort of (key, point index): histogram (atomics) -> scan -> scatter.
 //  3. reduce   segmented sum per key by fixed fan-in K: level 1 gathers affine bases and does mixed
 //              Lopez-Dahab additions; further levels add projective partials.  Tasks never span
@@ -94,119 +94,7 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
   if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than W*c digits
 }
 
-// Sliding-window recode (fixed-base mode with a table of ALL 240 rotations of every base, MsmFixedCtx::slide).
-// A window starts at a nonzero digit, so its value v is odd: only the 2^(c-1) odd patterns need buckets (key = v >> 1)
-// and the zeros between windows cost nothing -- a scalar has ~234/(c+1) + 0.6 entries instead of 234/c at the same
-// number of buckets per bit of window.  Entry = (row = position of the window's first digit, key): it adds
-// tau^row(P_i) -- row `row` of the table -- to bucket `key`, and the merge multiplies bucket `key` by 2*key + 1.
-// Widths are evened out over the whole expansion (slide_window_width): greedy c-digit windows would leave a final window
-// of random width 1..c per scalar, and a window of w digits reaches only the 2^(w-1) smallest keys -- n/c entries per
-// width piled into a handful of buckets (measured: 175 000 entries in key 0 at n = 4.2 M against an average of 190).
-// With R digits to go and a window + the zeros after it spanning c + 1 digits on average, k = ceil((R+1)/(c+1)) windows
-// remain and each takes ceil((R+1)/k) - 1 digits: the slack is spread one digit at a time (windows are c or c-1 wide,
-// rarely less), the entry count stays at 234/(c+1) + 0.6 and the fullest keys hold ~2.7x the average.
-__host__ __device__ __forceinline__ int slide_window_width(int R, int c) {
-  const int k = (R + 1 + c) / (c + 1);
-  if (k <= 1) return R < c ? R : c;
-  const int w = (R + k) / k - 1;  // ceil((R+1)/k) - 1, in [1, c]
-  return w < R ? w : R;
-}
-// entry slots a scalar can need: the all-ones expansion (no zeros to skip) of the full length
-static int slide_slots(int c) {
-  int best = 0;
-  for (int len = 1; len <= TAU_DIGITS; ++len) {
-    int cnt = 0;
-    for (int R = len; R > 0; R -= slide_window_width(R, c)) ++cnt;
-    if (cnt > best) best = cnt;
-  }
-  return best;
-}
-// INTEGER: the windows are cut from the scalar's BINARY expansion instead (MsmFixedCtx::integer: table row j holds 2^j P, not
-// tau^j P).  With every multiple of every base precomputed, what a window multiplier is made of -- Frobenius or doublings -- no
-// longer matters to the bucket rounds, the entry count is the same (one window per c + 1 digits of a ~232-digit string either
-// way), and the recode loses its expensive half: no partial reduction modulo delta, no multi-limb tau-adic expansion (~3 000
-// instructions per scalar, 0.68 ms per 2^20-constraint proof) -- the digits are the scalar's own bits.
-template <bool INTEGER>
-__global__ void __launch_bounds__(256)
-k_recode_slide(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, const uint8_t* __restrict__ width_tab,
-               int slots, uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
-  // width_tab[R] = slide_window_width(R, c) for R <= TAU_DIGITS (two integer divisions per window otherwise: they cost
-  // more than the rest of the window loop)
-  __shared__ uint8_t wtab[256];
-  wtab[threadIdx.x] = width_tab[threadIdx.x];
-  __syncthreads();
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
-  bool skip = inf && inf[i];
-  if (!tau_scalar_is_canonical(s)) {
-    atomicMin(err, (unsigned long long)i);
-    skip = true;
-  }
-  uint32_t d[8];
-  if (INTEGER) {  // a canonical scalar is < r < 2^232: its bits are the digit string
-#pragma unroll
-    for (int k = 0; k < 8; ++k) d[k] = skip ? 0u : s[k];
-  } else {
-    uint32_t r0[5], r1[5];
-    tau_partial_reduce(s, r0, r1);
-    if (skip) {
-#pragma unroll
-      for (int k = 0; k < 5; ++k) r0[k] = r1[k] = 0;
-    }
-    // the digits, least significant first: 8 words of 2 x 16 digits pushed through a shift register (static indices, one
-    // copy of the expansion step in the code); digits >= TAU_DIGITS = 240 land in the top half of d[7] and must be zero
-#pragma unroll
-    for (int k = 0; k < 8; ++k) d[k] = 0;
-#pragma unroll 1
-    for (int k = 0; k < 8; ++k) {
-      uint32_t wlo = tau_step16(r0, r1);
-      uint32_t whi = tau_step16(r0, r1);
-#pragma unroll
-      for (int q = 0; q < 7; ++q) d[q] = d[q + 1];
-      d[7] = wlo | (whi << 16);
-    }
-    uint32_t rest = d[7] >> (TAU_DIGITS - 224);
-    d[7] &= (1u << (TAU_DIGITS - 224)) - 1;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) rest |= r0[k] | r1[k];
-    if (rest) atomicMin(err, (unsigned long long)i | (1ull << 62));  // expansion longer than TAU_DIGITS (proven impossible, tau.cuh)
-  }
-  int len = 0;  // number of significant digits
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-    if (d[k]) len = 32 * k + 32 - __clz(d[k]);
-  auto shr = [&](int sh) {  // 0 <= sh < 32
-#pragma unroll
-    for (int k = 0; k < 7; ++k) d[k] = __funnelshift_r(d[k], d[k + 1], sh);
-    d[7] >>= sh;
-  };
-  int pos = 0, slot = 0;
-#pragma unroll 1
-  while (pos < len) {
-    while (d[0] == 0) {  // terminates: a significant digit lies above pos
-#pragma unroll
-      for (int k = 0; k < 7; ++k) d[k] = d[k + 1];
-      d[7] = 0;
-      pos += 32;
-    }
-    const int z = __ffs(d[0]) - 1;
-    shr(z);
-    pos += z;
-    const int width = wtab[len - pos];  // >= 1 digits are left, the lowest of them is 1
-    const uint32_t v = d[0] & ((1u << width) - 1);
-    if (slot < slots) words[(size_t)slot * n + i] = FXW_VALID | ((uint32_t)pos << FXW_ROW_SHIFT) | (v >> 1);
-    else atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: slots = slide_slots(c)
-    ++slot;
-    shr(width);
-    pos += width;
-  }
-  for (; slot < slots; ++slot) words[(size_t)slot * n + i] = 0;
-}
-
-// Signed aligned windows over the BINARY digits (MsmFixedCtx::integer without the sliding table; table row w = 2^(c w) P): the
+// Signed aligned windows over the BINARY digits (MsmFixedCtx::signed_digits; table row w = 2^(o_w) P): the
 // textbook signed-digit bucket method.  Window w holds d_w = bits [c w, c w + c) plus the carry of the window below; a digit
 // above 2^(c-1) becomes d_w - 2^c with a carry of one, so |d_w| <= 2^(c-1): HALF the buckets per window bit of the unsigned
 // windows (key = |d_w|; |d_w| = 2^(c-1), probability 2^-c, shares key 0, whose bucket the tail weighs by 2^(c-1)), the sign
@@ -703,43 +591,6 @@ k_frob_table(const Aff* __restrict__ bases, uint32_t n, int FX_C, int FX_W, int 
     p.x = gf_sqr_n(p.x, width);
     p.y = gf_sqr_n(p.y, width);
     table[(size_t)w * n + i] = p;
-  }
-}
-
-// sliding-window mode: every rotation, T[j][i] = tau^j(P_i), j < rows
-__global__ void __launch_bounds__(256)
-k_frob_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, Aff* __restrict__ table) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Aff p = bases[i];
-  table[i] = p;
-#pragma unroll 1
-  for (int j = 1; j < rows; ++j) {
-    p.x = gf_sqr(p.x);
-    p.y = gf_sqr(p.y);
-    table[(size_t)j * n + i] = p;
-  }
-}
-
-// integer sliding-window mode: T[j][i] = 2^j P_i, j < rows, by affine doublings (lambda = x + y / x, x3 = lambda^2 + lambda,
-// y3 = x^2 + (lambda + 1) x3): one table-driven inversion + 2 products + 2 squarings per row and base -- setup, once per
-// context.  A base of odd prime order never doubles to infinity or to x = 0; bases flagged infinite get no entries.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_dbl_table_all(const Aff* __restrict__ bases, uint32_t n, int rows, GfSqrTables T, Aff* __restrict__ table) {
-  extern __shared__ char lds_raw[];
-  GfLdsK L = gf_ldsk_init(lds_raw);
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Aff p = bases[i];
-  table[i] = p;
-  const Gf one = gf_one();
-#pragma unroll 1
-  for (int j = 1; j < rows; ++j) {
-    Gf lam = gf_add(p.x, gf_mul(p.y, gf_inv_fast(p.x, T, L), L));
-    Gf x3 = gf_add(gf_sqr(lam), lam);
-    p.y = gf_add(gf_sqr(p.x), gf_mul(gf_add(lam, one), x3, L));
-    p.x = x3;
-    table[(size_t)j * n + i] = p;
   }
 }
 
@@ -1240,24 +1091,21 @@ __global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uin
 // treated as infinity when count is odd), then the projective -> affine conversion.  Every step is pure latency -- 18..240
 // points, log-depth -- so seven launches (each a ~5 us boundary plus a grid ramp) buy nothing over __syncthreads between
 // the levels of one 256-thread block (64 quads, one addition per quad and pass).  buf: 2 * cnt Ld of scratch.
-// n_narrow < 0 = sliding-window mode (W = 1): bucket key b stands for the odd pattern 2b + 1, so the result is
-// A[0] (the sum of all buckets, power 0) + sum_t tau^t(A[t]) for t = 1 .. c-1 (A[t] = the buckets whose key has bit t-1).
+// n_narrow == -3: signed aligned windows over the binary digits (the default fixed-base flavour, W = 1): key = |digit|, so the
+// result is sum_t 2^t A[1 + t], t < c - 1, plus 2^(c-1) x bucket 0 (doublings instead of Frobenius powers).
 __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
                                                  uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
   extern __shared__ char lds_raw[];
   GfLdsQ L = gf_ldsq_init(lds_raw);
   const uint32_t cnt0 = (uint32_t)(W * c);
-  const bool slide = n_narrow < 0;
   Ld* in = buf;
   Ld* out = buf + cnt0;
-  if (n_narrow <= -2) {
-    // integer sliding windows (MsmFixedCtx::integer, -2): bucket key b stands for the odd integer 2b + 1, so the result is
-    // A[0] + sum_t 2^t A[t], t = 1 .. c-1: t doublings of A[t], one point per quad of lanes (a serial chain of <= c - 1
-    // doublings at 3 products + 5 squarings each).  Signed aligned windows (-3): key = |digit|, so the result is
-    // sum_t 2^t A[1 + t], t < c - 1, plus 2^(c-1) x bucket 0 (the digits of magnitude 2^(c-1); saved at buf[2 cnt0] before the
-    // merge turned slot 0 into the total)
+  if (n_narrow == -3) {
+    // signed aligned windows: t doublings of A[1 + t], one point per quad of lanes (a serial chain of <= c - 1 doublings at
+    // 3 products + 5 squarings each); the last point is bucket 0 (the digits of magnitude 2^(c-1); saved at buf[2 cnt0] before
+    // the merge turned slot 0 into the total)
     for (uint32_t pt = threadIdx.x >> 2; pt < cnt0; pt += EC_TPB / 4) {
-      Ld p = n_narrow == -2 ? A[pt] : (pt + 1 < cnt0 ? A[1 + pt] : buf[2 * cnt0]);
+      Ld p = pt + 1 < cnt0 ? A[1 + pt] : buf[2 * cnt0];
 #pragma unroll 1
       for (uint32_t k = 0; k < pt; ++k) p = ld_dbl(p, L);
       if (L.r == 0) in[pt] = p;
@@ -1265,8 +1113,8 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   } else {
     for (uint32_t tid = threadIdx.x; tid < cnt0; tid += EC_TPB) {
       uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
-      int k = slide ? (int)tid : (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
-      Ld p = slide ? A[tid] : A[((size_t)w << c) + 1 + t];
+      int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
+      Ld p = A[((size_t)w << c) + 1 + t];
       p.X = gf_sqr_n_fast(p.X, k, T);
       p.Y = gf_sqr_n_fast(p.Y, k, T);
       p.Z = gf_sqr_n_fast(p.Z, k, T);
@@ -1444,11 +1292,9 @@ struct MsmFixedCtx {
     n_narrow = w_main * cc - 234;
     W = w_main + 1;
   }
-  // sliding-window mode (k_recode_slide): the table holds all TAU_DIGITS rotations, W = entry slots per scalar, keys are
-  // the odd c-digit patterns (c - 1 key bits)
-  bool slide = false;
-  bool integer = false;          // windows over the scalar's BINARY digits: table rows hold 2^j P (k_dbl_table_all / k_dbl_table)
-  bool signed_digits = false;    // aligned windows with digits in [-2^(c-1), 2^(c-1)] (k_recode_signed): 2^(c-1) buckets
+  bool signed_digits = false;    // aligned windows with digits in [-2^(c-1), 2^(c-1)] over the scalar's BINARY digits (k_recode_signed,
+                                 // table rows 2^(o_w) P from k_dbl_table): 2^(c-1) buckets.  false = the tau-adic aligned windows
+                                 // (k_recode, table rows tau^(o_w) P from k_frob_table)
   // 234 bits (a canonical scalar < 2^232, the last carry, one spare so that the top digit stays positive) in W = ceil(234 / c)
   // windows whose widths differ by at most one: the n_narrow LOW windows are c - 1 wide.  A request whose windows would all be
   // narrow is the next smaller c.
@@ -1459,18 +1305,10 @@ struct MsmFixedCtx {
       if (n_narrow < W || cc <= 2) break;
     }
     c = cc;
-    integer = true;
     signed_digits = true;
   }
-  uint8_t* width_tab = nullptr;  // device, 256 entries: slide_window_width(R, c)
-  void set_c_slide(int cc) {
-    c = cc;
-    n_narrow = 0;
-    W = slide_slots(cc);
-    slide = true;
-  }
-  int rows() const { return slide ? (integer ? 233 : TAU_DIGITS) : W; }  // a canonical scalar has <= 232 binary digits
-  int key_bits() const { return (slide || signed_digits) ? c - 1 : c; }
+  int rows() const { return W; }
+  int key_bits() const { return signed_digits ? c - 1 : c; }
   int hi_bits = -1;  // level-1 partition bits of the sort (set at creation)
   FxBits bits() const { FxBits b; b.hi = hi_bits; b.lo = key_bits() - b.hi; return b; }
 };
@@ -1652,14 +1490,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
-  const bool slide = fx && fx->slide;
-  if (slide && fx->integer)
-    hipLaunchKernelGGL(k_recode_slide<true>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
-                       fx->width_tab, p.W, digits32, err);
-  else if (slide)
-    hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
-                       fx->width_tab, p.W, digits32, err);
-  else if (fx && fx->signed_digits)
+  if (fx && fx->signed_digits)
     hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
                        p.c, p.W, p.n_narrow, digits32, err);
   else if (fx)
@@ -1709,9 +1540,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipStreamWaitEvent(g_ws.aux, g_ws.ev, 0));
   DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
   const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
-  // entries that really exist: the overflow windows are empty in practice; a sliding window spans c + 1 digits on average
-  const size_t e_est = slide ? (size_t)((double)n * (234.0 / (p.c + 1) + 0.6))
-                             : (size_t)n * (size_t)((fx && fx->signed_digits) ? p.W : (234 + p.c - 1) / p.c);
+  // entries that really exist: the overflow windows are empty in practice
+  const size_t e_est = (size_t)n * (size_t)((fx && fx->signed_digits) ? p.W : (234 + p.c - 1) / p.c);
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -1874,7 +1704,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
   (void)cntT;
-  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, slide ? (fx->integer ? -2 : -1) : (sign_mask ? -3 : (fx ? 0 : p.n_narrow)), Tsq, ta, (uint32_t*)d_out_xy,
+  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
                      (uint32_t*)d_out_inf);
   ps_tail.stop();
   ps_total.stop();
@@ -1910,26 +1740,24 @@ int msm_affine_dev(const void* d_scalars, const void* d_bases, const void* d_inf
 // range_hint = number of bases a typical call will cover (the per-GPU shard): the shared window size c
 // minimises an empirical cost in field multiplications (pair additions + a per-bucket term, see below)
 void msm_fixed_destroy(MsmFixedCtx* c);
-static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hint, bool slide, bool integer, MsmFixedCtx** out, hipError_t* alloc_err) {
+// Table flavours: the default is aligned windows of SIGNED binary digits over W rows 2^(o_w) P (768 B per base at W = 12: 4.8 GB for
+// both SRS vectors of a 2^20-constraint prover); DVP_MSM_ALIGNED_SIGNED = 0 selects round 1-2's aligned tau-adic windows over rows
+// tau^(o_w) P instead (one window and twice the buckets more: 24.6 against 23.5 ms per proof in round 3) -- kept because it shares
+// its recode, merge and Frobenius tail with the one-shot MSM and is the independent cross-check of the signed flavour in the
+// tests.  (Rounds 2-3 also carried two SLIDING-window flavours over a multiple of every base for every digit position, 94-97 GB
+// of tables at 2^20; the signed aligned windows matched their speed at a twentieth of the memory -- 23.54 against 23.57 / 23.98 ms
+// -- and they were removed in round 4 together with their recoders, table builders and test matrix.)
+static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out, hipError_t* alloc_err) {
   MsmFixedCtx* c = new MsmFixedCtx();
   c->n_total = n_total;
-  c->integer = slide && integer;
   double best = 1e300;
   int best_c = 8;
-  const int c_max = FX_C_MAX + (slide ? 1 : 0);  // <= 20 key bits either way
-  for (int cc = 8; cc <= c_max; ++cc) {
-    // pair additions at ~5.6 product-equivalents + a per-bucket term for merge/reducer/sort; measured on MI355X at 2^20
-    // constraints: 2^18 buckets beat 2^16, 2^17, 2^19 and 2^20 for every shard from 0.26 M to 4.2 M pairs of the aligned
-    // windows (2^20 wins from ~8 M pairs); with sliding windows 2^18 and 2^19 buckets tie at 2.1 M and 2^19 wins at 4.2 M
-    const int kb = slide ? cc - 1 : cc;
-    const double per_scalar = slide ? 234.0 / (cc + 1) + 0.6 : (double)((234 + cc - 1) / cc);
-    double cost = per_scalar * (double)range_hint * 5.6 + 10.0 * (double)(1u << kb) + (kb > 18 ? 25.0 * (double)((1u << kb) - (1u << 18)) : 0.0);
-    if (cost < best) { best = cost; best_c = cc; }
-  }
-  if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= c_max) best_c = (int)tune().msm_fixed_c;
-  const bool signed_aligned = !slide && tune().msm_aligned_signed != 0;
-  if (signed_aligned) {  // same cost model over its own entry and bucket counts: ceil(234 / c) entries, 2^(c-1) buckets
-    best = 1e300;
+  const bool signed_aligned = tune().msm_aligned_signed != 0;
+  // pair additions at ~5.6 product-equivalents + a per-bucket term for merge/reducer/sort; measured on MI355X at 2^20
+  // constraints: 2^18 buckets beat 2^16, 2^17, 2^19 and 2^20 for every shard from 0.26 M to 4.2 M pairs of the tau-adic aligned
+  // windows (2^20 wins from ~8 M pairs); the signed windows run the same model over their own entry and bucket counts
+  // (ceil(234 / c) entries, 2^(c-1) buckets)
+  if (signed_aligned) {
     for (int cc = 8; cc <= FX_C_MAX + 1; ++cc) {
       MsmFixedCtx probe;
       probe.set_c_signed(cc);
@@ -1941,48 +1769,36 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
     }
     if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= FX_C_MAX + 1) best_c = (int)tune().msm_fixed_c;
     c->set_c_signed(best_c);
-  } else if (slide) c->set_c_slide(best_c); else c->set_c(best_c);
+  } else {
+    for (int cc = 8; cc <= FX_C_MAX; ++cc) {
+      const double per_scalar = (double)((234 + cc - 1) / cc);
+      double cost = per_scalar * (double)range_hint * 5.6 + 10.0 * (double)(1u << cc) + (cc > 18 ? 25.0 * (double)((1u << cc) - (1u << 18)) : 0.0);
+      if (cost < best) { best = cost; best_c = cc; }
+    }
+    if (tune().msm_fixed_c >= 8 && tune().msm_fixed_c <= FX_C_MAX) best_c = (int)tune().msm_fixed_c;
+    c->set_c(best_c);
+  }
   const int kb = c->key_bits();
   c->hi_bits = kb / 2;  // even split: both levels have <= 2^10 bins and use the LDS-staged scatters
   if (int h = (int)tune().fx_hi; h >= 0 && h <= 10 && kb - h <= 15 && kb - h >= 1) c->hi_bits = h;
   hipError_t e = hipMalloc((void**)&c->table, (size_t)c->rows() * n_total * sizeof(Aff));
   *alloc_err = e;
-  if (e == hipSuccess && slide) {
-    uint8_t wt[256] = {0};
-    for (int R = 1; R <= TAU_DIGITS; ++R) wt[R] = (uint8_t)slide_window_width(R, c->c);
-    e = hipMalloc((void**)&c->width_tab, sizeof(wt));
-    if (e == hipSuccess) e = hipMemcpy(c->width_tab, wt, sizeof(wt), hipMemcpyHostToDevice);
-  }
   if (e == hipSuccess) {
-    if (slide && c->integer) {
-      GfSqrTables Tsq;
-      int rc_t = gf_sqr_tables(&Tsq, 0);
-      if (rc_t != DVP_OK) { msm_fixed_destroy(c); return rc_t; }
-      e = hipFuncSetAttribute((const void*)k_dbl_table_all, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL(k_dbl_table_all, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->rows(), Tsq, c->table);
-    } else if (slide)
-      hipLaunchKernelGGL(k_frob_table_all, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->rows(), c->table);
-    else if (c->signed_digits) {
+    if (c->signed_digits) {
       GfSqrTables Tsq;
       int rc_t = gf_sqr_tables(&Tsq, 0);
       if (rc_t != DVP_OK) { msm_fixed_destroy(c); return rc_t; }
       e = hipFuncSetAttribute((const void*)k_dbl_table, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS);
       Gf* scratch = nullptr;  // Z snapshots + prefix products of the shared inversion, (W - 1) x n each
       const size_t per = (size_t)(c->W > 1 ? c->W - 1 : 1) * n_total;
-      const bool dbg = getenv("DVP_DEBUG_TIMING") != nullptr;
-      auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-      const double t0 = now();
       if (e == hipSuccess) e = hipMalloc((void**)&scratch, 2 * per * sizeof(Gf));
-      const double t1 = now();
       if (e == hipSuccess) {
         hipLaunchKernelGGL(k_dbl_table, dim3(cdiv(n_total, 256)), dim3(256), EC_LDS, 0, d_bases, n_total, c->c, c->W, c->n_narrow, Tsq, c->table,
                            scratch, scratch + per);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
       }
-      const double t2 = now();
       if (scratch) (void)hipFree(scratch);
-      if (dbg) fprintf(stderr, "[dvpari] k_dbl_table n=%u W=%d: scratch malloc %.3f s, kernel %.3f s, free %.3f s\n", n_total, c->W, t1 - t0, t2 - t1, now() - t2);
     } else
       hipLaunchKernelGGL(k_frob_table, dim3(cdiv(n_total, 256)), dim3(256), 0, 0, d_bases, n_total, c->c, c->W, c->n_narrow, c->table);
     if (e == hipSuccess) e = hipGetLastError();
@@ -1998,21 +1814,8 @@ static int msm_fixed_build(const Aff* d_bases, uint32_t n_total, size_t range_hi
 }
 int msm_fixed_create(const Aff* d_bases, uint32_t n_total, size_t range_hint, MsmFixedCtx** out) {
   if ((uint64_t)n_total * 32 >= 0xfffffff0ull) return DVP_EINVAL;  // W <= 31 windows of pre-rotated copies, 32-bit indices
-  // Table flavour (Tune::msm_slide, DVP_MSM_SLIDE):
-  //   unset / 0  aligned windows of signed binary digits over W rows 2^(o_w) P (768 B per base at W = 12: 4.8 GB for both SRS
-  //              vectors of a 2^20-constraint prover) -- the default: it is as fast as the sliding flavours (round 3:
-  //              23.54 ms against 23.57 ms) at a twentieth of their memory;
-  //   2          sliding windows over the binary digits, all 233 multiples 2^j P of every base (14.9 KB per base, 94 GB);
-  //   1          sliding windows over the tau-adic digits, all 240 Frobenius rotations (15.4 KB per base, 97 GB).
-  // DVP_MSM_ALIGNED_SIGNED = 0 turns the aligned flavour back into round 2's tau-adic aligned windows.  A sliding table above
-  // the byte budget DVP_MSM_TABLE_MAX_GB (when set) is refused in favour of the aligned flavour.
-  const uint64_t slide_bytes = (uint64_t)TAU_DIGITS * n_total * sizeof(Aff);
-  const long long mode = tune().msm_slide;
-  bool slide = mode > 0 && (uint64_t)TAU_DIGITS * n_total < 0xfffffff0ull;
-  const long long budget_gb = tune().msm_table_max_gb;
-  if (slide && budget_gb >= 0 && slide_bytes > (uint64_t)budget_gb * 1000000000ull) slide = false;
   hipError_t alloc_err = hipSuccess;
-  return msm_fixed_build(d_bases, n_total, range_hint, slide, mode == 2, out, &alloc_err);
+  return msm_fixed_build(d_bases, n_total, range_hint, out, &alloc_err);
 }
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows) {
   if (!c) return DVP_EINVAL;
@@ -2020,16 +1823,15 @@ int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows) {
   *windows = c->W;
   return DVP_OK;
 }
-// bytes of the pre-rotated table; *sliding = 1 when it holds all TAU_DIGITS rotations (sliding windows)
+// bytes of the pre-rotated table; *signed_flavour = 1 for the signed binary windows (the default), 0 for the tau-adic aligned windows
 const void* msm_fixed_table_ptr(const MsmFixedCtx* c) { return c ? (const void*)c->table : nullptr; }
-uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* sliding) {
-  if (sliding) *sliding = c && c->slide ? 1 : 0;
+uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* signed_flavour) {
+  if (signed_flavour) *signed_flavour = c && c->signed_digits ? 1 : 0;
   return c ? (uint64_t)c->rows() * c->n_total * sizeof(Aff) : 0;
 }
 void msm_fixed_destroy(MsmFixedCtx* c) {
   if (!c) return;
   if (c->table) (void)hipFree(c->table);
-  if (c->width_tab) (void)hipFree(c->width_tab);
   delete c;
 }
 // partial sum over bases [lo, hi) of the context; d_scalars / d_inf point at element lo
@@ -2149,49 +1951,6 @@ extern "C" int dvp_ubench_gather(const void* d_table, size_t table_bytes, int re
   return DVP_OK;
 }
 
-// Parity-test access to the sliding-window recode alone (the counterpart of dvp_prover_debug_read for the MSM): entry
-// words of n canonical scalars for window size c, out_words[slot * n + i] = 0 (empty) or
-// 0x80000000 | position << 20 | pattern >> 1; *slots = entry slots per scalar (out_words holds *slots * n words; pass
-// out_words = NULL to query *slots).
-static int debug_recode(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots, bool integer);
-extern "C" int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots) {
-  return debug_recode(scalars, n, c, out_words, slots, false);
-}
-// the same for the windows over the scalar's binary digits (k_recode_slide<true>, the default sliding flavour)
-extern "C" int dvp_debug_recode_binary(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots) {
-  return debug_recode(scalars, n, c, out_words, slots, true);
-}
-static int debug_recode(const uint64_t* scalars, size_t n, int c, uint32_t* out_words, int* slots, bool integer) {
-  if (!slots || c < 8 || c > FX_C_MAX + 1 || n > (1u << 24)) return DVP_EINVAL;
-  *slots = slide_slots(c);
-  if (!out_words) return DVP_OK;
-  if (!scalars || !n) return DVP_EINVAL;
-  uint8_t wt[256] = {0};
-  for (int R = 1; R <= TAU_DIGITS; ++R) wt[R] = (uint8_t)slide_window_width(R, c);
-  DevBuf ds, dw, dt, de;
-  DVP_TRY(ds.alloc(n * 32));
-  DVP_TRY(dw.alloc((size_t)*slots * n * 4));
-  DVP_TRY(dt.alloc(sizeof(wt)));
-  DVP_TRY(de.alloc(8));
-  DVP_HIP(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
-  DVP_HIP(hipMemcpy(dt.p, wt, sizeof(wt), hipMemcpyHostToDevice));
-  DVP_HIP(hipMemset(de.p, 0xff, 8));
-  if (integer)
-    hipLaunchKernelGGL(k_recode_slide<true>, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
-                       *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
-  else
-    hipLaunchKernelGGL(k_recode_slide<false>, dim3(cdiv(n, 256)), dim3(256), 0, 0, ds.as<uint32_t>(), (const uint8_t*)nullptr, (uint32_t)n, dt.as<uint8_t>(),
-                       *slots, dw.as<uint32_t>(), de.as<unsigned long long>());
-  DVP_HIP(hipGetLastError());
-  DVP_HIP(hipMemcpy(out_words, dw.p, (size_t)*slots * n * 4, hipMemcpyDeviceToHost));
-  unsigned long long e = 0;
-  DVP_HIP(hipMemcpy(&e, de.p, 8, hipMemcpyDeviceToHost));
-  if (e != ~0ull) {
-    g_last_error_index = (int64_t)(e & 0xffffffffull);
-    return DVP_EINVAL;
-  }
-  return DVP_OK;
-}
 
 // the signed aligned windows (k_recode_signed): out_words[w * n + i] = 0 (digit 0) or 0x80000000 | 0x10000000 if the digit is
 // negative | w << 20 | |digit| (|digit| = 2^(c-1) stored as key 0); *windows = ceil(234 / c)
@@ -2280,7 +2039,7 @@ extern "C" int dvp_msm_ctx_plan(const dvp_msm_ctx* c, int* c_bits, int* windows)
   if (!c || !c_bits || !windows) return DVP_EINVAL;
   return msm_fixed_info(c->fx, c_bits, windows);
 }
-extern "C" uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* c, int* sliding) { return c ? msm_fixed_table_bytes(c->fx, sliding) : 0; }
+extern "C" uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* c, int* signed_windows) { return c ? msm_fixed_table_bytes(c->fx, signed_windows) : 0; }
 // sum_{i in [lo,hi)} scalars[i - lo] * base[i]; d_scalars holds hi - lo canonical scalars (device)
 extern "C" int dvp_msm_ctx_run_dev(dvp_msm_ctx* c, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
   if (!c || !d_scalars || !d_out_xy || !d_out_inf || lo > hi || hi > c->n) return DVP_EINVAL;

@@ -46,7 +46,7 @@ int msm_sum_points_dev(const void* d_pts, uint32_t pt_stride_bytes, const void* 
                        void* d_out_inf, hipStream_t st);
 void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
-uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* sliding);
+uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* signed_flavour);
 const void* msm_fixed_table_ptr(const MsmFixedCtx* c);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
@@ -956,15 +956,15 @@ extern "C" int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, 
   if (!p->shards.empty() && p->shards[0].fx[which]) return msm_fixed_info(p->shards[0].fx[which], c_bits, windows);  // multi-GPU: shard 0's
   return DVP_OK;
 }
-// HBM held by the fixed-base table(s) of MSM `which` (all shards); *sliding = 1 when they are the 240-rotation tables
-extern "C" uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, int* sliding) {
-  if (sliding) *sliding = 0;
+// HBM held by the fixed-base table(s) of MSM `which` (all shards); *signed_windows = 1 for the default signed binary windows
+extern "C" uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, int* signed_windows) {
+  if (signed_windows) *signed_windows = 0;
   if (!p || (which != 0 && which != 1)) return 0;
-  uint64_t total = msm_fixed_table_bytes(p->fx[which], sliding);
+  uint64_t total = msm_fixed_table_bytes(p->fx[which], signed_windows);
   for (const auto& sh : p->shards) {
     int s = 0;
     total += msm_fixed_table_bytes(sh.fx[which], &s);
-    if (s && sliding) *sliding = 1;
+    if (s && signed_windows) *signed_windows = 1;
   }
   return total;
 }

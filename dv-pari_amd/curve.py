@@ -128,7 +128,7 @@ class FixedBaseMsm:
         return c.value, w.value
 
     def table(self):
-        """(bytes of HBM, sliding-window flavour?) of the pre-rotated table"""
+        """(bytes of HBM, signed binary windows -- the default flavour -- ?) of the pre-rotated table"""
         s = C.c_int(0)
         b = int(lib.dvp_msm_ctx_table_bytes(self._h, C.byref(s)))
         return b, bool(s.value)

@@ -243,7 +243,7 @@ class Prover:
         return c.value, w.value
 
     def msm_table(self, which: int):
-        """(bytes of HBM, sliding-window flavour?) of the fixed-base tables of MSM `which`"""
+        """(bytes of HBM, signed binary windows -- the default flavour -- ?) of the fixed-base tables of MSM `which`"""
         s = C.c_int(0)
         b = int(lib.dvp_prover_msm_table_bytes(self._h, which, C.byref(s)))
         return b, bool(s.value)

@@ -130,16 +130,14 @@ int dvp_msm_affine_dev(const void* d_scalars, const void* d_bases_xy, const void
 typedef struct dvp_msm_ctx dvp_msm_ctx;
 int dvp_msm_ctx_create(const uint64_t* bases_xy, const uint8_t* bases_inf, size_t n, size_t range_hint, dvp_msm_ctx** out);
 void dvp_msm_ctx_destroy(dvp_msm_ctx* ctx);
-/* window bits c and window count (aligned windows: all W windows share one set of 2^(c-1) buckets of |digit|; sliding windows:
- * entry slots per scalar, 2^(c-1) buckets of odd patterns) the context settled on */
+/* window bits c and window count the context settled on (all W windows share one bucket set: 2^(c-1) buckets of |digit| for the
+ * default signed windows) */
 int dvp_msm_ctx_plan(const dvp_msm_ctx* ctx, int* c_bits, int* windows);
 /* HBM held by the context's precomputed table.  Default flavour: aligned windows of signed binary digits over W ~ 12 multiples
- * 2^(o_w) P of every base (0.77 KB per base: 3.2 GB for the 4m bases of a 2^20-constraint prover).  DVP_MSM_SLIDE = 2 / 1 (environment,
- * read once) asks for sliding windows over a multiple of the base for EVERY digit position instead -- the 233 integer multiples 2^j P
- * (14.9 KB per base: 63 GB for the same bases) / the 240 Frobenius rotations tau^j P -- which measured no faster;
- * DVP_MSM_TABLE_MAX_GB = <n> refuses a sliding table above n GB in favour of the default.  *sliding reports which one this is.
- * Results do not depend on the flavour. */
-uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* sliding);
+ * 2^(o_w) P of every base (0.77 KB per base: 3.2 GB for the 4m bases of a 2^20-constraint prover); DVP_MSM_ALIGNED_SIGNED = 0
+ * (environment, read once) selects aligned tau-adic windows over W + 1 Frobenius images instead.  *signed_windows (may be NULL)
+ * reports which one this is (1 = the default).  Results do not depend on the flavour. */
+uint64_t dvp_msm_ctx_table_bytes(const dvp_msm_ctx* ctx, int* signed_windows);
 int dvp_msm_ctx_run(dvp_msm_ctx* ctx, const uint64_t* scalars, size_t lo, size_t hi, uint64_t out_xy[8], int* out_is_infinity);
 int dvp_msm_ctx_run_dev(dvp_msm_ctx* ctx, const void* d_scalars, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 /* same seam with the reference's own wire formats: scalars n x 32 B canonical LE, bases n x 30 B
@@ -221,7 +219,7 @@ size_t dvp_prover_msm_size(const dvp_prover* p, int which);
 /* window bits / window count chosen for MSM `which` (0,0 until its fixed-base tables exist) */
 int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows);
 /* HBM held by the fixed-base tables of MSM `which` on all devices (see dvp_msm_ctx_table_bytes) */
-uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, int* sliding);
+uint64_t dvp_prover_msm_table_bytes(const dvp_prover* p, int which, int* signed_windows);
 int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream);
 int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream);
 /* The same phase for provers that share one proof by INDEX (one process per GPU): the pointwise stages, the batch

@@ -50,13 +50,7 @@ int dvp_ubench_gather(const void* d_table, size_t table_bytes, int reps, double*
  * (NULL / 0 before the first proof) -- what dvp_ubench_gather is pointed at */
 int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_table, uint64_t* bytes);
 
-/* parity-test access to the sliding-window recode alone: entry words of n canonical scalars for window size c (8..21),
- * out_words[slot * n + i] = 0 (empty slot) or 0x80000000 | first digit position << 20 | odd pattern >> 1;
- * *slots = entry slots per scalar (out_words must hold *slots * n words; out_words = NULL only queries *slots). */
-int dvp_debug_recode_slide(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
-/* the same for the default sliding flavour, windows cut from the scalar's BINARY digits (position = bit position) */
-int dvp_debug_recode_binary(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* slots);
-/* the signed aligned windows of the small-table flavour: out_words[w * n + i] = 0 (digit 0) or 0x80000000 | 0x10000000 when the
+/* parity-test access to the recode of the default fixed-base flavour alone (signed aligned windows): out_words[w * n + i] = 0 (digit 0) or 0x80000000 | 0x10000000 when the
  * digit is negative | w << 20 | |digit| (|digit| = 2^(c-1) is stored as key 0); *windows = ceil(234 / c_bits) */
 int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* windows);
 

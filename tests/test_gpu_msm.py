@@ -11,7 +11,7 @@ import pytest
 
 import pyref as o
 import c_oracle as co
-from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast, tau_adversarial_scalars, slide_slots
+from util import to_limbs, from_limbs, pts_to_np, np_to_pt, rand_fr_np, np_dot_mod, np_dot_mod_fast, tau_adversarial_scalars
 
 pytestmark = pytest.mark.gpu
 OSSL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k233_openssl.json")))["vectors"]
@@ -161,18 +161,18 @@ def test_msm_wire_format(dvp):
     assert out == co.xsk233_encode(co.k233_mulgen(np_dot_mod(s, k)))
 
 
-@pytest.mark.parametrize("slide", [0, 1, 2, 3])  # signed aligned binary windows / tau sliding / binary sliding / tau aligned windows
+@pytest.mark.parametrize("slide", [0, 3])  # signed aligned binary windows (the default) / tau-adic aligned windows
 @pytest.mark.parametrize("hint", [0, 1 << 10, 1 << 24])
 def test_fixed_base_msm_context(dvp, hint, slide):
     """dvp_msm_ctx_*: pre-rotated bases, shared bucket set; full range, sub-ranges (the per-GPU shards) and a
-    neutral base, for several window sizes (range_hint drives the choice; 2^24 forces c = 20, two-level sort), with the
-    aligned windows (W-row table) and the sliding windows (240-row table, odd patterns only)."""
+    neutral base, for several window sizes (range_hint drives the choice; 2^24 forces c = 20, two-level sort), with both
+    table flavours (signed binary windows over rows 2^(o_w) P, tau-adic windows over rows tau^(o_w) P)."""
     n = 6000
     k, s = rand_fr_np(n, 61), rand_fr_np(n, 62)
     bases, _ = dvp.curve.point_scalar_mul_gen_batch(k)
     inf = np.zeros(n, dtype=np.uint8)
     inf[5] = 1
-    knobs = {"DVP_MSM_SLIDE": 0, "DVP_MSM_ALIGNED_SIGNED": 0} if slide == 3 else {"DVP_MSM_SLIDE": slide}
+    knobs = {"DVP_MSM_ALIGNED_SIGNED": 0 if slide == 3 else 1}
     if hint <= n:
         with dvp.tune(**knobs):
             fb = dvp.curve.FixedBaseMsm(bases, inf, hint)
@@ -261,7 +261,7 @@ def test_msm_full_size_dlog_and_linearity(dvp, log_n):
 
 
 def test_fixed_base_vs_one_shot_randomised(dvp):
-    """differential sweep: every fixed-base window size 8..20 of the aligned and 8..21 of the sliding windows (both sort
+    """differential sweep: every fixed-base window size 8..21 of the signed and 8..20 of the tau-adic aligned windows (both sort
     flavours, 4/8/16-slot pair rounds) against the one-shot path on random sub-ranges, plus scalars with long runs of
     zero / one digits"""
     rnd = random.Random(2026)
@@ -276,10 +276,9 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     assert max(len(co.tau_digits(x)) for x in special) >= 236
     s[: len(special)] = to_limbs(special)
     ks, ss = from_limbs(k), from_limbs(s)
-    # slide: 0 = aligned windows (signed binary digits: the default small-table flavour), 3 = aligned tau-adic windows,
-    # 1 = tau-adic sliding windows, 2 = sliding windows over the binary digits
-    for c, slide in [(c, 0) for c in range(8, 22)] + [(c, 3) for c in range(8, 21)] + [(c, 1) for c in range(8, 22)] + [(c, 2) for c in range(8, 22)]:
-        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_SLIDE=0 if slide == 3 else slide, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1,
+    # slide: 0 = aligned windows of signed binary digits (the default flavour), 3 = aligned tau-adic windows
+    for c, slide in [(c, 0) for c in range(8, 22)] + [(c, 3) for c in range(8, 21)]:
+        with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1,
                       DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
                       DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
             fb = dvp.curve.FixedBaseMsm(bases)
@@ -289,7 +288,7 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
                     ce -= 1
                 assert fb.plan() == (ce, (234 + ce - 1) // ce)
             else:
-                assert fb.plan() == (c, slide_slots(c) if slide in (1, 2) else (234 + c - 1) // c + 1)
+                assert fb.plan() == (c, (234 + c - 1) // c + 1)
             for _ in range(3):
                 lo = rnd.randrange(0, n - 1)
                 hi = rnd.randrange(lo + 1, n + 1)
@@ -331,80 +330,6 @@ def test_one_shot_randomised_shapes_and_knobs(dvp):
                      DVP_MSM_AFF_MIN=rnd.choice([1, 64, 1 << 19]), DVP_MSM_PROJ=int(trial % 7 == 6), DVP_MSM_AFF_BMAX=rnd.choice([1, 5, 48]))
         with dvp.tune(**knobs):
             assert gpu_msm(dvp, to_limbs(sv), bases[lo:lo + n], inf) == exp, (trial, n, knobs)
-
-
-@pytest.mark.parametrize("c", [8, 13, 19, 20, 21])
-def test_sliding_recode_words_vs_restatement(dvp, c):
-    """k_recode_slide word for word: the entries of random and adversarial scalars (i) are disjoint windows that
-    reassemble to a {0,1}-digit expansion whose value sum d_j tau^j is the scalar (tau acts on the group as the root
-    lambda of x^2 + x + 2 mod r), (ii) are exactly what the window rule restated in tests/util.py cuts out of that
-    expansion, slot count and empty slots included, and (iii) for scalars away from the rounding boundaries of the
-    partial reduction the expansion is the C oracle's, digit for digit (on a boundary the GPU's fixed-point quotient may
-    pick the neighbouring representative modulo delta: another valid expansion of the same scalar)"""
-    import ctypes as C
-    from util import slide_windows, TAU_D0, TAU_D1
-    lam = (-TAU_D0 * pow(TAU_D1, -1, o.P)) % o.P
-    assert (lam * lam + lam + 2) % o.P == 0
-    probe = list(co.tau_digits(12345))
-    if sum(d * pow(lam, j, o.P) for j, d in enumerate(probe)) % o.P != 12345:
-        lam = (-1 - lam) % o.P                      # the other root of x^2 + x + 2: the one tau acts as
-    assert sum(d * pow(lam, j, o.P) for j, d in enumerate(probe)) % o.P == 12345
-    rnd = random.Random(300 + c)
-    adv = tau_adversarial_scalars()[:200]
-    vals = [0, 1, 2, 3, o.P - 1, (1 << 231) - 1, 1 << 230] + adv + [rnd.randrange(o.P) for _ in range(1500)]
-    s = to_limbs(vals)
-    slots = C.c_int(0)
-    dvp.check(dvp.lib.dvp_debug_recode_slide(None, 0, c, None, C.byref(slots)), "slots")
-    assert slots.value == slide_slots(c)
-    words = np.zeros((slots.value, len(vals)), dtype=np.uint32)
-    dvp.check(dvp.lib.dvp_debug_recode_slide(s.ctypes.data, len(vals), c, words.ctypes.data, C.byref(slots)), "recode")
-    same_as_oracle = 0
-    for i, x in enumerate(vals):
-        got = [(int(w >> 20) & 0xFF, 2 * int(w & 0xFFFFF) + 1) for w in words[:, i] if w]
-        assert all(int(w) >> 31 for w in words[: len(got), i]) and not words[len(got):, i].any()
-        digits, end, value = [0] * 262, 0, 0
-        for pos, v in got:
-            assert pos >= end and v < (1 << c)
-            for t in range(c):
-                digits[pos + t] = (v >> t) & 1
-            end = pos + v.bit_length()
-            value = (value + sum(((v >> t) & 1) * pow(lam, pos + t, o.P) for t in range(c))) % o.P
-        assert end <= 240 and value == x % o.P, (c, i, hex(x))
-        assert slide_windows(digits, c) == got, (c, i, hex(x))
-        ref = list(co.tau_digits(x))
-        same = digits[: max(len(ref), end)] == (ref + [0] * 262)[: max(len(ref), end)]
-        same_as_oracle += same
-        if i >= 7 + len(adv):
-            assert same, (c, i, hex(x))
-    assert same_as_oracle >= len(vals) - len(adv)
-
-
-@pytest.mark.parametrize("c", [8, 13, 19, 20, 21])
-def test_binary_recode_words_vs_restatement(dvp, c):
-    """k_recode_slide<true> (the default sliding flavour: windows over the scalar's BINARY digits, table rows = 2^j P) word for
-    word: the entries of a scalar are exactly what the window rule restated in tests/util.py (slide_windows) cuts out of its
-    bits -- odd patterns, positions, slot count, empty slots -- and they reassemble to the scalar as an integer."""
-    import ctypes as C
-    from util import slide_windows
-
-    rnd = random.Random(400 + c)
-    vals = [0, 1, 2, 3, o.P - 1, (1 << 231) - 1, 1 << 230, (1 << 231) + 1] + [rnd.randrange(o.P) for _ in range(1500)] \
-        + [rnd.randrange(1 << rnd.randrange(1, 232)) for _ in range(300)]
-    s = to_limbs(vals)
-    slots = C.c_int(0)
-    dvp.check(dvp.lib.dvp_debug_recode_binary(None, 0, c, None, C.byref(slots)), "slots")
-    assert slots.value == slide_slots(c)
-    words = np.zeros((slots.value, len(vals)), dtype=np.uint32)
-    dvp.check(dvp.lib.dvp_debug_recode_binary(s.ctypes.data, len(vals), c, words.ctypes.data, C.byref(slots)), "recode")
-    for i, x in enumerate(vals):
-        got = [(int(w >> 20) & 0xFF, 2 * int(w & 0xFFFFF) + 1) for w in words[:, i] if w]
-        assert all(int(w) >> 31 for w in words[: len(got), i]) and not words[len(got):, i].any()
-        assert sum(v << pos for pos, v in got) == x, (c, i, hex(x))
-        assert slide_windows([(x >> j) & 1 for j in range(233)], c) == got, (c, i, hex(x))
-    # a scalar >= r is refused with its index, as in every other entry of the boundary
-    bad = to_limbs([5, o.P])
-    w2 = np.zeros((slots.value, 2), dtype=np.uint32)
-    assert dvp.lib.dvp_debug_recode_binary(bad.ctypes.data, 2, c, w2.ctypes.data, C.byref(slots)) == -1 and dvp.lib.dvp_last_error_index() == 1
 
 
 @pytest.mark.parametrize("c", [8, 13, 18, 19, 20, 21])

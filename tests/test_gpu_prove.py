@@ -406,29 +406,26 @@ def test_in_library_multi_gpu_same_bytes(dvp, log_m, devices):
 
 
 def test_table_flavours_same_bytes(dvp):
-    """the fixed-base table flavours (aligned windows over W rows / sliding windows over all 240 Frobenius rotations / sliding
-    windows over the 233 integer multiples 2^j P, DVP_MSM_SLIDE = 0 / 1 / 2), the default (unset: the aligned signed windows)
-    and round 2's aligned tau-adic windows produce the same proof; dvp_prover_msm_table_bytes reports flavour and size
-    (rows x bases x 64 B)"""
+    """the two fixed-base table flavours -- the default aligned windows of signed binary digits (rows 2^(o_w) P) and round 2's
+    aligned tau-adic windows (rows tau^(o_w) P, DVP_MSM_ALIGNED_SIGNED = 0): different recoders, table builders, bucket counts and
+    tails -- produce the same proof; dvp_prover_msm_table_bytes reports flavour and size (rows x bases x 64 B)"""
     log_m = 13
     inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
     rnd = random.Random(77)
     td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
     proofs = []
-    for slide in (0, 1, 2, -1, 3):  # 3 = aligned tau-adic windows (DVP_MSM_ALIGNED_SIGNED = 0); 0 = aligned signed binary windows
-        with dvp.tune(DVP_MSM_FIXED_MIN=1, DVP_MSM_SLIDE=0 if slide == 3 else slide, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1):
+    for signed in (1, 0):
+        with dvp.tune(DVP_MSM_FIXED_MIN=1, DVP_MSM_ALIGNED_SIGNED=signed):
             pv = dvp.proving.Prover(inst)
             pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
             assert pv.msm_table(0) == (0, False)      # no table before the first proof
             proofs.append(pv.prove(pub, prv))
             for which in (0, 1):
-                nbytes, sliding = pv.msm_table(which)
-                # sliding tables: 240 Frobenius rotations (DVP_MSM_SLIDE = 1) or 233 integer multiples 2^j P (= 2)
-                rows = (240 if slide == 1 else 233) if sliding else pv.msm_plan(which)[1]
-                assert nbytes == rows * pv.msm_size(which) * 64
-                assert sliding == (slide in (1, 2))  # the default (-1) is the aligned signed-window table
+                nbytes, is_signed = pv.msm_table(which)
+                assert nbytes == pv.msm_plan(which)[1] * pv.msm_size(which) * 64
+                assert is_signed == bool(signed)
             pv.close()
-    assert proofs[0] == proofs[1] == proofs[2] == proofs[3] == proofs[4] and dvp.srs.verify(td, pub, proofs[0])
+    assert proofs[0] == proofs[1] and dvp.srs.verify(td, pub, proofs[0])
 
 
 def test_points_sum_records(dvp):

@@ -272,44 +272,6 @@ def test_cpu_pippenger_matches_reference_shaped_msm():
     assert co.msm_pippenger(s[:0], pts[:0], threads=2) is None
 
 
-def test_sliding_window_decomposition():
-    """the window rule of the fixed-base MSM's sliding mode (msm.hip: slide_window_width / k_recode_slide), restated in
-    tests/util.py and checked on the oracle's tau-adic expansions: windows are disjoint, start at a nonzero digit (odd
-    pattern), at most c digits wide, reassemble to the expansion, and never need more than slide_slots(c) entries; for
-    c = 19 a scalar has ~12.0 entries and no 256-key block of the 2^18 buckets collects more than 4x the average load
-    (greedy c-digit windows pile 900x the average into key 0: the reason the widths are evened out)"""
-    import collections
-    import random
-    from util import slide_slots, slide_windows, tau_adversarial_scalars
-
-    rnd = random.Random(19)
-    scalars = [0, 1, 2, 3, o.P - 1, (1 << 231) - 1] + tau_adversarial_scalars()[:120] + [rnd.randrange(o.P) for _ in range(3000)]
-    digs = [list(co.tau_digits(x)) for x in scalars]
-    for c in (8, 13, 19, 21):
-        slots = slide_slots(c)
-        for d in digs:
-            ws = slide_windows(d, c)
-            assert len(ws) <= slots
-            rebuilt = [0] * 260
-            end = 0
-            for pos, v in ws:
-                assert pos >= end and (v & 1) and v < (1 << c)
-                for t in range(c):
-                    rebuilt[pos + t] = (v >> t) & 1
-                end = pos + v.bit_length()
-            n = max(len(d), 1)
-            assert rebuilt[:n] == (d + [0])[:n] and not any(rebuilt[n:])
-    assert [slide_slots(c) for c in (8, 19, 20, 21)] == [30, 13, 12, 12]
-    c = 19
-    load, entries = collections.Counter(), 0
-    for d in digs[126:]:
-        for pos, v in slide_windows(d, c):
-            load[(v >> 1) >> 8] += 1
-            entries += 1
-    assert 11.8 < entries / 3000 < 12.2
-    assert max(load.values()) < 4.0 * entries / (1 << (c - 1 - 8))
-
-
 def _cpu_prove_inputs(log_m, rows, coeffs, n_pub, trap):
     """everything Proof::prove reads from its cache_dir, from the ORACLE alone: brute-force tables and setup scalars (pyref), butterfly
     matrices from the C restatement of FFTree, SRS bases as scalar x G through the C curve code"""

@@ -93,38 +93,3 @@ def tau_adversarial_scalars(seed=7, n_boundary=40):
             s0 = ((2 * k + 1) << 255) // A
             out += [(s0 + d) % p for d in (-1, 0, 1)]
     return out
-
-
-# ---- the sliding-window decomposition of the fixed-base MSM, restated (msm.hip: slide_window_width, k_recode_slide) ----
-def slide_window_width(R, c):
-    """digits the next window takes when R significant digits are left (the lowest of them is 1)"""
-    k = (R + 1 + c) // (c + 1)
-    return min(R, c) if k <= 1 else min((R + k) // k - 1, R)
-
-
-def slide_slots(c):
-    """entry slots a scalar can need: the all-ones expansion of every length up to 240 digits"""
-    best = 0
-    for length in range(1, 241):
-        cnt, R = 0, length
-        while R > 0:
-            R -= slide_window_width(R, c)
-            cnt += 1
-        best = max(best, cnt)
-    return best
-
-
-def slide_windows(digits, c):
-    """[(position, odd pattern)] of a {0,1}-digit tau-adic expansion (least significant digit first)"""
-    d = list(digits)
-    while d and d[-1] == 0:
-        d.pop()
-    out, pos = [], 0
-    while pos < len(d):
-        while d[pos] == 0:
-            pos += 1
-        w = slide_window_width(len(d) - pos, c)
-        v = sum(d[pos + t] << t for t in range(w))
-        out.append((pos, v))
-        pos += w
-    return out

@@ -1,4 +1,4 @@
-"""fixed-base MSM of n = 2^lg points (the shard sizes of a W-way split) under every window size, aligned signed and binary sliding
+"""fixed-base MSM of n = 2^lg points (the shard sizes of a W-way split) under every window size, aligned signed and aligned tau-adic
 tables: python tools/shard_c_sweep.py [lg ...]  -- checks the cost model's own choice (first line of each block) against the sweep"""
 import importlib, os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
@@ -12,7 +12,7 @@ for lg in [int(x) for x in sys.argv[1:]] or [18, 19, 20]:
     n = 1 << lg
     bases, _ = dvp.curve.point_scalar_mul_gen_batch(rand_fr(n))
     s = rand_fr(n)
-    for name, knobs in (("signed aligned", {}), ("binary sliding", {"DVP_MSM_SLIDE": 2})):
+    for name, knobs in (("signed aligned", {}), ("tau-adic aligned", {"DVP_MSM_ALIGNED_SIGNED": 0})):
         ref = None
         for c in [0] + list(range(14, 22)):
             kn = dict(knobs); 

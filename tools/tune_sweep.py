@@ -10,7 +10,7 @@ log_m = int(os.environ.get("LOG_M", "20"))
 reps = int(os.environ.get("REPS", "5"))
 inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
 td = dvp.srs.Trapdoor(0x1234567 + (1 << 200), 0x7654321 + (1 << 190), 0xABCDEF + (1 << 180))
-CREATE = {"DVP_MSM_FIXED_C", "DVP_MSM_SLIDE", "DVP_FX_HI", "DVP_MSM_FIXED_MIN"}
+CREATE = {"DVP_MSM_FIXED_C", "DVP_MSM_ALIGNED_SIGNED", "DVP_FX_HI", "DVP_MSM_FIXED_MIN"}
 knobs = [(a.split("=")[0], [int(v) for v in a.split("=")[1].split(",")]) for a in sys.argv[1:]]
 outer = [(k, v) for k, v in knobs if k in CREATE]
 inner = [(k, v) for k, v in knobs if k not in CREATE]
