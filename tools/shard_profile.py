@@ -57,6 +57,9 @@ for world in [int(x) for x in os.environ.get("SHARD_WORLDS", "1,2,4,8").split(",
                 def beg():
                     be.begin(assignment, False)
                     be.extend_vectors(own)
+                    for v in range(pv.extend_count()):  # stand-in for the broadcasts (not in a one-GPU projection): whatever the buffers hold
+                        if v not in own:
+                            be.mark_extended(v)
                     be.quotient()
                 _, ph["begin"] = timed(beg)
             else:
