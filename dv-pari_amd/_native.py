@@ -124,6 +124,9 @@ _SIGS = {
     "dvp_fftr_write": (C.c_int, [C.c_char_p, u32, u8p, vp, u64p]),
     "dvp_setup_cache_dir": (C.c_int, [u64p, u64p, u64p, C.c_char_p, u32, C.c_int]),
     "dvp_setup_cache_dir_ex": (C.c_int, [u64p, u64p, u64p, C.c_char_p, u32, C.c_int, u64p, sz, C.POINTER(u32), C.POINTER(u32)]),
+    "dvp_prover_prepares_precomputes": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(u32)]),
+    "dvp_ecfft_write_tree_file": (C.c_int, [vp, C.c_char_p]),
+    "dvp_ecfft_check_tree_file": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "dvp_prover_open_cache_dir": (C.c_int, [C.c_char_p, u32, C.POINTER(vp)]),
     "dvp_prove_cache_dir": (C.c_int, [C.c_char_p, u64p, u32, u64p, u32, u8p]),
     "dvp_cache_dir_release": (None, [C.c_char_p]),

@@ -6,8 +6,12 @@ SRS_G_K_1 = "g_k_1"
 SRS_G_K_2 = "g_k_2"
 SRS_FILES = (SRS_G_M, SRS_G_Q, SRS_G_K_0, SRS_G_K_1, SRS_G_K_2)  # in dvp_prover_set_srs_* `which` order
 
-# The FFTR tree files (tree2n, tree2nd, treen, treend; src/tree_io.rs) are neither read nor written: twiddles are
-# regenerated on the device from the curve constants (src/ec_fft.rs:205-229).
+# The FFTR tree files (src/tree_io.rs; names src/artifacts.rs:30-57).  The prover regenerates its twiddles on the device from
+# the curve constants (src/ec_fft.rs:205-229) and reads none of them; prover_prepares_precomputes writes / checks TREE_2N.
+TREE_2N = "tree2n"
+TREE_2ND = "tree2nd"
+TREE_N = "treen"
+TREE_ND = "treend"
 Z_POLY = "z_poly"
 Z_POLYD = "z_polyd"
 BAR_WTS = "bar_wts"

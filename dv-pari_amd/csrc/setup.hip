@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -122,6 +123,13 @@ __global__ void __launch_bounds__(TPB) ks_check_monic(const Fr* __restrict__ co,
   const Fr c = co[(size_t)m + i];
   const bool ok = i == 0 ? fr_eq(c, fr_one_canon()) : fr_is_zero(c);
   if (!ok) atomicExch(bad, 1u);
+}
+
+// evaluate_vanishing_poly_at_domain's verdict (src/proving.rs:290-295): the evaluations on D (even leaves) must all be zero
+__global__ void __launch_bounds__(TPB) ks_first_nonzero_even(const Fr* __restrict__ ev, uint32_t m, unsigned int* __restrict__ first_bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  if (!fr_is_zero(ev[2 * (size_t)i])) atomicMin(first_bad, i);
 }
 
 struct File {
@@ -367,4 +375,213 @@ extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delt
 extern "C" int dvp_setup_cache_dir(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
                                    uint32_t n_public, int write_precomputes) {
   return dvp_setup_cache_dir_ex(tau, delta, epsilon, cache_dir, n_public, write_precomputes, nullptr, 0, nullptr, nullptr);
+}
+
+// ---- FFTR tree files from a regenerated tree, and prover_prepares_precomputes (src/proving.rs:225-325) ----------------------
+extern "C" int dvp_debug_ecfft_layer(const dvp_ecfft* c, uint32_t d, uint64_t* out);
+extern "C" int dvp_debug_ecfft_matrices(dvp_ecfft* c, int to_even, int which, uint64_t* out);
+extern "C" int dvp_ecfft_enter_dev(dvp_ecfft* c, const void* d_coeffs, void* d_out, void* stream);
+
+namespace {
+// Sections 0-2 of an FFTree as the reference holds them (what read_minimal_fftree_from_file loads, src/tree_io.rs:353-433):
+// BinaryTree<T> is a heap-ordered Vec -- entry 0 padding, a layer of k entries at [k, 2k).  For an N-leaf tree
+//   f                   2N elements: layer d of the isogeny chain (N >> d values) at [N >> d, 2 (N >> d))
+//   recombine/decompose N Mat2x2 each: layer d holds one matrix per pair at [(N >> d) / 2, N >> d); even positions are the pairs
+//                       of even leaves (extend(.., Moiety::S1) decomposes with them, the mirrored direction recombines with
+//                       them), odd positions the pairs of odd leaves; the last layer and entry 0 stay Mat2x2::identity.
+struct TreeSections {
+  std::vector<uint64_t> f, rec, dec;  // canonical limbs, 4 per element; a matrix = 4 elements row-major
+};
+int tree_sections_host(dvp_ecfft* t, TreeSections& s) {
+  const size_t N = t->n_leaves;
+  const int log_n = t->log_n;
+  s.f.assign(2 * N * 4, 0);
+  for (int d = 0; d <= log_n; ++d) DVP_TRY(dvp_debug_ecfft_layer(t, (uint32_t)d, s.f.data() + (N >> d) * 4));
+  s.rec.assign(N * 16, 0);
+  for (size_t i = 0; i < N; ++i) s.rec[i * 16] = s.rec[i * 16 + 12] = 1;  // identity
+  s.dec = s.rec;
+  if (log_n < 2) return DVP_OK;
+  const size_t n = N / 2;
+  std::vector<uint64_t> got((n - 1) * 16);
+  // (to_even, which = 0 decompose / 1 recombine) -> (section, parity of the position it fills)
+  static const struct { int to_even, which, parity; } plan[4] = {{0, 0, 0}, {1, 0, 1}, {1, 1, 0}, {0, 1, 1}};
+  for (const auto& pl : plan) {
+    DVP_TRY(dvp_debug_ecfft_matrices(t, pl.to_even, pl.which, got.data()));
+    std::vector<uint64_t>& dst = pl.which ? s.rec : s.dec;
+    for (int d = 0; d < log_n - 1; ++d) {
+      const size_t nd = n >> d, off = n - nd;  // nd pairs in this layer, nd / 2 per parity
+      for (size_t i = 0; i < nd / 2; ++i) memcpy(&dst[(nd + 2 * i + pl.parity) * 16], &got[(off + i) * 16], 128);
+    }
+  }
+  return DVP_OK;
+}
+bool file_exists(const std::string& p) {
+  struct stat sb;
+  return stat(p.c_str(), &sb) == 0;
+}
+int mkdir_p(const std::string& dir) {
+  std::string cur;
+  for (size_t i = 0; i <= dir.size(); ++i) {
+    if (i == dir.size() || dir[i] == '/') {
+      if (!cur.empty() && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return DVP_EIO;
+    }
+    if (i < dir.size()) cur.push_back(dir[i]);
+  }
+  return DVP_OK;
+}
+}  // namespace
+
+// write_fftree_to_file of a minimal tree (sections f, recombine_matrices, decompose_matrices) for the regenerated `tree`
+extern "C" int dvp_ecfft_write_tree_file(dvp_ecfft* tree, const char* path) {
+  if (!tree || !path) return DVP_EINVAL;
+  TreeSections s;
+  DVP_TRY(tree_sections_host(tree, s));
+  const uint8_t ids[3] = {0, 1, 2};
+  const uint64_t* data[3] = {s.f.data(), s.rec.data(), s.dec.data()};
+  const uint64_t N = tree->n_leaves;
+  const uint64_t elems[3] = {2 * N, 4 * N, 4 * N};
+  return dvp_fftr_write(path, 3, ids, data, elems);
+}
+
+// Compares a tree file with the regenerated `tree`: the leaves (second half of section f) must be identical; with matrices != 0
+// also the inner layers of f and both matrix sections, entry for entry.  DVP_OK = identical; DVP_EINVAL = differs (*bad_section =
+// 0/1/2, *bad_entry = first differing element of f / matrix of the section); DVP_EIO = unreadable or another shape.
+extern "C" int dvp_ecfft_check_tree_file(dvp_ecfft* tree, const char* path, int matrices, int* bad_section, int64_t* bad_entry) {
+  if (!tree || !path) return DVP_EINVAL;
+  if (bad_section) *bad_section = -1;
+  if (bad_entry) *bad_entry = -1;
+  const size_t N = tree->n_leaves;
+  TreeSections s;
+  if (matrices)
+    DVP_TRY(tree_sections_host(tree, s));
+  else {
+    s.f.assign(2 * N * 4, 0);
+    DVP_TRY(dvp_debug_ecfft_layer(tree, 0, s.f.data() + N * 4));
+  }
+  std::vector<uint64_t> got;
+  for (int sec = 0; sec < (matrices ? 3 : 1); ++sec) {
+    const std::vector<uint64_t>& want = sec == 0 ? s.f : sec == 1 ? s.rec : s.dec;
+    size_t cnt = 0;
+    DVP_TRY(dvp_fftr_read_fr(path, 0, (uint8_t)sec, nullptr, 0, &cnt));
+    if (cnt * 4 != want.size()) {
+      if (bad_section) *bad_section = sec;
+      return DVP_EIO;
+    }
+    got.resize(cnt * 4);
+    DVP_TRY(dvp_fftr_read_fr(path, 0, (uint8_t)sec, got.data(), cnt, &cnt));
+    const size_t lo = sec == 0 ? (matrices ? 1 : N) : 0;  // entry 0 of f is padding; leaves only without `matrices`
+    for (size_t e = lo; e < cnt; ++e)
+      if (memcmp(&got[e * 4], &want[e * 4], 32) != 0) {
+        if (bad_section) *bad_section = sec;
+        if (bad_entry) *bad_entry = (int64_t)(sec == 0 ? e : e / 4);
+        return DVP_EINVAL;
+      }
+  }
+  return DVP_OK;
+}
+
+// prover_prepares_precomputes(cache_dir, validate_precompute), src/proving.rs:225-325.
+//   z_poly must exist (its length fixes m; DVP_EIO otherwise); TREE_2N is read when present, else generated (minimal) and written;
+//   bar_wts / z_vals2inv are produced when missing -- here from the isogeny chain in milliseconds, where the reference builds
+//   treen / treend and evaluates z_poly on them (it also leaves those two tree files behind; this entry does not).
+//   validate_precompute: z_poly must not be all zero and must vanish on D (the reference's two asserts, :281-296 / :307-321);
+//   beyond the reference, files that were FOUND (tree2n, bar_wts, z_vals2inv) are compared with the regenerated values.
+// *report (optional): DVP_PREP_* bits of include/dvpari.h.  DVP_EINVAL = a validation failed (the bits say which).
+extern "C" int dvp_prover_prepares_precomputes(const char* cache_dir, int validate_precompute, uint32_t* report) {
+  if (!cache_dir) return DVP_EINVAL;
+  uint32_t rep = 0;
+  struct Rep { uint32_t* out; uint32_t* v; ~Rep() { if (out) *out = *v; } } rep_guard{report, &rep};
+  const std::string dir(cache_dir);
+  auto path = [&](const char* name) { return dir + "/" + name; };
+  DVP_TRY(mkdir_p(dir));
+  size_t nz = 0;
+  DVP_TRY(dvp_file_fr_vec_read(path("z_poly").c_str(), nullptr, 0, &nz));
+  if (nz < 3) return DVP_EINVAL;
+  const size_t m = nz - 1;
+  if (m & (m - 1)) return DVP_EINVAL;
+  uint32_t log_m = 0;
+  while (((size_t)1 << log_m) < m) ++log_m;
+  if (log_m > DVP_MAX_LOG2_CONSTRAINTS) return DVP_EINVAL;
+  std::vector<uint64_t> zpoly(nz * 4);
+  DVP_TRY(dvp_file_fr_vec_read(path("z_poly").c_str(), zpoly.data(), nz, &nz));
+  dvp_ecfft* tree = nullptr;
+  DVP_TRY(dvp_ecfft_create(log_m + 1, 0, 0, &tree));
+  struct TreeGuard { dvp_ecfft* t; ~TreeGuard() { if (t) dvp_ecfft_destroy(t); } } tree_guard{tree};
+  // ---- TREE_2N (load_tree, :250-275) ----
+  const std::string t2n = path("tree2n");
+  if (!file_exists(t2n)) {
+    DVP_TRY(dvp_ecfft_write_tree_file(tree, t2n.c_str()));
+    rep |= DVP_PREP_WROTE_TREE2N;
+  } else {
+    int sec = -1;
+    int64_t ent = -1;
+    const int rc = dvp_ecfft_check_tree_file(tree, t2n.c_str(), validate_precompute ? 1 : 0, &sec, &ent);
+    if (rc == DVP_EINVAL) {
+      rep |= DVP_PREP_BAD_TREE2N;
+      g_last_error_index = ent;
+    }
+    if (rc) return rc;
+  }
+  hipStream_t st = 0;
+  const dim3 gm((unsigned)cdiv(m, TPB)), bt(TPB);
+  // ---- bar_wts, z_vals2inv (compute_barycentric_weights / the inverted evaluations of z_poly on D', :284-304) ----
+  DevBuf bar, zinv;
+  DVP_TRY(bar.alloc(m * sizeof(Fr)));
+  DVP_TRY(zinv.alloc(m * sizeof(Fr)));
+  DVP_TRY(ecfft_domain_tables_dev(tree, 0, bar.as<Fr>(), zinv.as<Fr>(), st));
+  std::vector<uint64_t> host(m * 4), found(m * 4);
+  static const struct { const char* name; uint32_t wrote, bad; } files[2] = {{"bar_wts", DVP_PREP_WROTE_BAR_WTS, DVP_PREP_BAD_BAR_WTS},
+                                                                            {"z_vals2inv", DVP_PREP_WROTE_Z_VALS2INV, DVP_PREP_BAD_Z_VALS2INV}};
+  int verdict = DVP_OK;
+  for (int k = 0; k < 2; ++k) {
+    const std::string p = path(files[k].name);
+    const bool have = file_exists(p);
+    if (have && !validate_precompute) continue;
+    DVP_HIP(hipMemcpyAsync(host.data(), k ? zinv.p : bar.p, m * sizeof(Fr), hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+    if (!have) {
+      DVP_TRY(dvp_file_fr_vec_write(p.c_str(), host.data(), m));
+      rep |= files[k].wrote;
+      continue;
+    }
+    size_t cnt = 0;
+    DVP_TRY(dvp_file_fr_vec_read(p.c_str(), nullptr, 0, &cnt));
+    bool same = cnt == m;
+    if (same) {
+      DVP_TRY(dvp_file_fr_vec_read(p.c_str(), found.data(), m, &cnt));
+      same = memcmp(found.data(), host.data(), m * 32) == 0;
+    }
+    if (!same) {
+      rep |= files[k].bad;
+      verdict = DVP_EINVAL;
+    }
+  }
+  // ---- the vanishing polynomial (validate_precompute, :281-296 / :307-321) ----
+  if (zpoly[m * 4] != 1 || zpoly[m * 4 + 1] || zpoly[m * 4 + 2] || zpoly[m * 4 + 3]) rep |= DVP_PREP_Z_POLY_NOT_MONIC;
+  if (validate_precompute) {
+    bool all_zero = true;
+    for (uint64_t w : zpoly) all_zero = all_zero && w == 0;
+    if (all_zero) {
+      rep |= DVP_PREP_BAD_Z_POLY;
+      return DVP_EINVAL;  // "all polynomial coefficients were zero"
+    }
+    DevBuf co, ev, flag;
+    DVP_TRY(co.alloc(2 * m * sizeof(Fr)));
+    DVP_TRY(ev.alloc(2 * m * sizeof(Fr)));
+    DVP_TRY(flag.alloc(4));
+    DVP_HIP(hipMemsetAsync(co.p, 0, 2 * m * sizeof(Fr), st));
+    DVP_HIP(hipMemcpyAsync(co.p, zpoly.data(), nz * sizeof(Fr), hipMemcpyHostToDevice, st));
+    DVP_TRY(dvp_ecfft_enter_dev(tree, co.p, ev.p, st));
+    DVP_HIP(hipMemsetAsync(flag.p, 0xff, 4, st));
+    hipLaunchKernelGGL(ks_first_nonzero_even, gm, bt, 0, st, ev.as<Fr>(), (uint32_t)m, flag.as<unsigned int>());
+    unsigned int first_bad = 0;
+    DVP_HIP(hipMemcpyAsync(&first_bad, flag.p, 4, hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+    if (first_bad != 0xffffffffu) {
+      rep |= DVP_PREP_BAD_Z_POLY;  // "vanishing poly does not evaluate to zero at all points in domain"
+      g_last_error_index = first_bad;
+      return DVP_EINVAL;
+    }
+  }
+  return verdict;
 }

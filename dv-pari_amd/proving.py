@@ -74,33 +74,28 @@ def release_cache_dir(cache_dir=None):
     lib.dvp_cache_dir_release(None if cache_dir is None else os.fspath(cache_dir).encode())
 
 
-def prover_prepares_precomputes(cache_dir, validate_precompute: bool = False):
-    """prover_prepares_precomputes, src/proving.rs:225-325: needs z_poly in cache_dir (its length fixes m) and
-    produces bar_wts and z_vals2inv when they are missing -- here from the isogeny chain in milliseconds.  The GPU
-    prover itself regenerates all three on the device and reads none of these files; this exists so that a cache_dir
-    prepared here is complete for a reference prover as well.  validate_precompute checks that z_poly is the
-    vanishing polynomial of D (the reference evaluates it on D, :281-296)."""
+PREP_WROTE_TREE2N, PREP_WROTE_BAR_WTS, PREP_WROTE_Z_VALS2INV, PREP_Z_POLY_NOT_MONIC = 0x1, 0x2, 0x4, 0x8
+PREP_BAD_Z_POLY, PREP_BAD_BAR_WTS, PREP_BAD_Z_VALS2INV, PREP_BAD_TREE2N = 0x100, 0x200, 0x400, 0x800
+
+
+def prover_prepares_precomputes(cache_dir, validate_precompute: bool = False) -> int:
+    """prover_prepares_precomputes, src/proving.rs:225-325, through the C entry of the same name: needs z_poly in
+    cache_dir (its length fixes m), reads tree2n or writes a minimal one, produces bar_wts and z_vals2inv when they are
+    missing -- from the isogeny chain in milliseconds.  The GPU prover itself regenerates all of these on the device and
+    reads none of the files; this exists so that a cache_dir prepared here is complete for a reference prover as well.
+    validate_precompute: z_poly must vanish on D (the reference's asserts, :281-296) and every file found is compared
+    with the regenerated values.  Returns the PREP_* report bits; a failed validation raises ValueError naming the file."""
     import os
 
-    from . import artifacts as A, io_utils
-    from .ec_fft import FFTree, compute_vanishing_polynomial
-
-    zpoly = io_utils.read_fr_vec_from_file(os.path.join(cache_dir, A.Z_POLY))
-    m = zpoly.shape[0] - 1
-    assert m >= 2 and m & (m - 1) == 0, "z_poly must hold m+1 coefficients, m a power of two"
-    tree2n = FFTree(2 * m)
-    try:
-        if validate_precompute and not np.array_equal(zpoly, compute_vanishing_polynomial(tree2n, 0)):
-            raise ValueError("vanishing poly does not evaluate to zero at all points in domain")
-        bw_path, zi_path = os.path.join(cache_dir, A.BAR_WTS), os.path.join(cache_dir, A.Z_VALS2_INV)
-        if not (os.path.exists(bw_path) and os.path.exists(zi_path)):
-            bar, zinv = tree2n.domain_tables(0)
-            if not os.path.exists(bw_path):
-                io_utils.write_fr_vec_to_file(bw_path, bar)
-            if not os.path.exists(zi_path):
-                io_utils.write_fr_vec_to_file(zi_path, zinv)
-    finally:
-        tree2n.close()
+    rep = C.c_uint32(0)
+    rc = lib.dvp_prover_prepares_precomputes(os.fspath(cache_dir).encode(), int(bool(validate_precompute)), C.byref(rep))
+    bad = [n for n, b in (("z_poly", PREP_BAD_Z_POLY), ("bar_wts", PREP_BAD_BAR_WTS), ("z_vals2inv", PREP_BAD_Z_VALS2INV),
+                          ("tree2n", PREP_BAD_TREE2N)) if rep.value & b]
+    if bad:
+        msg = "vanishing poly does not evaluate to zero at all points in domain" if bad == ["z_poly"] else "differs from the regenerated values"
+        raise ValueError(f"{cache_dir}: {', '.join(bad)}: {msg} (first bad index {lib.dvp_last_error_index()})")
+    check(rc, "dvp_prover_prepares_precomputes")
+    return rep.value
 
 
 def transcript_challenge(commit_p: bytes, public_inputs) -> int:

@@ -101,8 +101,19 @@ def tree_sections(tree) -> dict:
 
 
 def write_minimal_tree_file(path, tree):
-    """the three sections FFTree::extend needs (src/tree_io.rs:353-433, test :481-502), from the regenerated tree"""
-    write_tree_file(path, tree_sections(tree))
+    """the three sections FFTree::extend needs (src/tree_io.rs:353-433, test :481-502), from the regenerated tree
+    (assembled natively: dvp_ecfft_write_tree_file; tree_sections above is the same layout in numpy, kept as its check)"""
+    check(lib.dvp_ecfft_write_tree_file(tree._h, os.fspath(path).encode()), f"dvp_ecfft_write_tree_file({path})")
+
+
+def check_tree_file_native(path, tree, matrices: bool = False):
+    """dvp_ecfft_check_tree_file: the comparison of check_tree_file below inside the library (what
+    dvp_prover_prepares_precomputes runs on a tree2n it finds); raises ValueError with the first difference"""
+    sec, ent = C.c_int(-1), C.c_int64(-1)
+    rc = lib.dvp_ecfft_check_tree_file(tree._h, os.fspath(path).encode(), int(matrices), C.byref(sec), C.byref(ent))
+    if rc == -1 and sec.value >= 0:  # DVP_EINVAL with a section: a difference, not a bad argument
+        raise ValueError(f"{path}: section {SECTION_NAMES[sec.value]} differs from the regenerated tree (first difference at entry {ent.value})")
+    check(rc, f"dvp_ecfft_check_tree_file({path})")
 
 
 def check_tree_file(path, tree, matrices: bool = False) -> dict:

@@ -285,6 +285,31 @@ int dvp_fftr_write(const char* path, uint32_t n_sections, const uint8_t* ids, co
 int dvp_setup_cache_dir(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
                         uint32_t n_public, int write_precomputes);
 
+/* prover_prepares_precomputes(cache_dir, validate_precompute) (src/proving.rs:225-325): cache_dir/z_poly must exist (its length
+ * fixes m; DVP_EIO when it does not, DVP_EINVAL when m is not a power of two); tree2n is read when present, else generated as a
+ * minimal tree (the sections FFTree::extend needs, src/tree_io.rs:353-433) and written; bar_wts and z_vals2inv are produced when
+ * missing (from the isogeny chain, in milliseconds -- the reference builds treen / treend and evaluates z_poly on them, and
+ * leaves those two tree files behind; this entry does not).  validate_precompute != 0: z_poly must not be all zero and must
+ * vanish on D (the reference's two asserts; DVP_EINVAL, dvp_last_error_index() = the first point of D where it does not) and,
+ * beyond the reference, every file that was FOUND (tree2n with its matrices, bar_wts, z_vals2inv) is compared with the
+ * regenerated values (DVP_EINVAL).  *report (optional) = DVP_PREP_* bits, set on every return. */
+#define DVP_PREP_WROTE_TREE2N 0x1u
+#define DVP_PREP_WROTE_BAR_WTS 0x2u
+#define DVP_PREP_WROTE_Z_VALS2INV 0x4u
+#define DVP_PREP_Z_POLY_NOT_MONIC 0x8u /* informational: c Z_D with c != 1 passes the reference's check too */
+#define DVP_PREP_BAD_Z_POLY 0x100u
+#define DVP_PREP_BAD_BAR_WTS 0x200u
+#define DVP_PREP_BAD_Z_VALS2INV 0x400u
+#define DVP_PREP_BAD_TREE2N 0x800u
+int dvp_prover_prepares_precomputes(const char* cache_dir, int validate_precompute, uint32_t* report);
+/* write_fftree_to_file (src/tree_io.rs:144-214) of the minimal tree of a regenerated `tree`: sections f, recombine_matrices,
+ * decompose_matrices in the reference's BinaryTree order (layout restated in csrc/setup.hip; third-party, see dvp_fftr_* above) */
+int dvp_ecfft_write_tree_file(dvp_ecfft* tree, const char* path);
+/* a (reference-built) tree file against the regenerated `tree`: the leaves -- and with matrices != 0 the inner layers of f and
+ * both matrix sections -- entry for entry.  DVP_OK identical; DVP_EINVAL differs (*bad_section 0/1/2, *bad_entry the first
+ * differing element of f / matrix; both optional); DVP_EIO unreadable or of another size */
+int dvp_ecfft_check_tree_file(dvp_ecfft* tree, const char* path, int matrices, int* bad_section, int64_t* bad_entry);
+
 /* The loading half of Proof::prove (src/proving.rs:435-470,509-511,666-672): reads cache_dir/r1cs_to_dvsnark and the
  * SRS vectors g_m, g_q, g_k_0, g_k_1, g_k_2 (src/artifacts.rs:18-27,76), decodes the points on the GPU
  * (DVP_EDECODE = the reference's assert!(valid)) and returns a ready prover; the witness length is |g_m|. */

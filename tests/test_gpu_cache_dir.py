@@ -112,17 +112,59 @@ def test_toy_cache_dir_end_to_end(dvp, tmp_path):
     with pytest.raises(dvp.DvpError) as e:
         dvp.proving.Proof.prove(cache, g.TOY_PUBLIC, bad)
     assert e.value.status == -3 and e.value.index == 2
-    # prover_prepares_precomputes regenerates the same files from z_poly alone, and validates z_poly
+    # prover_prepares_precomputes (src/proving.rs:225-325, the C entry) regenerates the same files from z_poly alone, writes the
+    # minimal tree2n, and validates z_poly and whatever it finds
+    P = dvp.proving
     before = {n: (cache / n).read_bytes() for n in (A.BAR_WTS, A.Z_VALS2_INV)}
     for n in before:
         os.remove(cache / n)
-    dvp.proving.prover_prepares_precomputes(cache, validate_precompute=True)
+    assert not (cache / A.TREE_2N).exists()
+    rep = P.prover_prepares_precomputes(cache, validate_precompute=True)
+    assert rep == P.PREP_WROTE_TREE2N | P.PREP_WROTE_BAR_WTS | P.PREP_WROTE_Z_VALS2INV
     assert {n: (cache / n).read_bytes() for n in before} == before
+    t16 = dvp.ec_fft.FFTree(16)
+    dvp.tree_io.check_tree_file(cache / A.TREE_2N, t16, matrices=True)  # the numpy restatement of the layout agrees
+    t16.close()
+    assert P.prover_prepares_precomputes(cache, validate_precompute=True) == 0  # everything found, everything validated
+    os.remove(cache / A.Z_VALS2_INV)
+    assert P.prover_prepares_precomputes(cache) == P.PREP_WROTE_Z_VALS2INV
+    assert (cache / A.Z_VALS2_INV).read_bytes() == before[A.Z_VALS2_INV]
+    # a damaged bar_wts / tree2n is found by validation only (the reference reads them unchecked)
+    bw = dvp.io_utils.read_fr_vec_from_file(cache / A.BAR_WTS)
+    bw[5, 0] ^= 1
+    dvp.io_utils.write_fr_vec_to_file(cache / A.BAR_WTS, bw)
+    assert P.prover_prepares_precomputes(cache) == 0
+    with pytest.raises(ValueError, match="bar_wts"):
+        P.prover_prepares_precomputes(cache, validate_precompute=True)
+    (cache / A.BAR_WTS).write_bytes(before[A.BAR_WTS])
+    good_tree = (cache / A.TREE_2N).read_bytes()
+    raw = bytearray(good_tree)
+    raw[-40] ^= 1  # inside the last matrix blob
+    (cache / A.TREE_2N).write_bytes(bytes(raw))
+    with pytest.raises((ValueError, dvp.DvpError)):
+        P.prover_prepares_precomputes(cache, validate_precompute=True)
+    (cache / A.TREE_2N).write_bytes(good_tree)
+    # z_poly: c * Z_D still vanishes on D (passes, flagged as not monic); one changed coefficient does not; all zero is refused;
+    # a missing file is an I/O error
     z = dvp.io_utils.read_fr_vec_from_file(cache / A.Z_POLY)
-    z[0, 0] ^= 1
+    z2 = to_limbs([(2 * v) % o.P for v in from_limbs(z)])
+    dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, z2)
+    assert P.prover_prepares_precomputes(cache, validate_precompute=True) == P.PREP_Z_POLY_NOT_MONIC
+    zb = z.copy()
+    zb[0, 0] ^= 1
+    dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, zb)
+    assert P.prover_prepares_precomputes(cache) == 0  # not validated: accepted, as in the reference
+    with pytest.raises(ValueError, match="vanishing poly does not evaluate to zero"):
+        P.prover_prepares_precomputes(cache, validate_precompute=True)
+    dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, np.zeros_like(z))
+    with pytest.raises(ValueError, match="z_poly"):
+        P.prover_prepares_precomputes(cache, validate_precompute=True)
+    os.remove(cache / A.Z_POLY)
+    with pytest.raises(dvp.DvpError) as e:
+        P.prover_prepares_precomputes(cache)
+    assert e.value.status == -6  # DVP_EIO
     dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, z)
-    with pytest.raises(ValueError):
-        dvp.proving.prover_prepares_precomputes(cache, validate_precompute=True)
+    assert P.prover_prepares_precomputes(cache, validate_precompute=True) == 0
     # a corrupted SRS point is refused at load time (assert!(valid), src/io_utils.rs:223)
     dvp.proving.release_cache_dir(cache)
     raw = bytearray((cache / A.SRS_G_Q).read_bytes())

@@ -145,6 +145,7 @@ def test_butterfly_matrices_and_minimal_tree_file(dvp, nat, tmp_path, log_n):
     path = tmp_path / "tree_oracle"
     dvp.tree_io.write_tree_file(path, want)
     info = dvp.tree_io.check_tree_file(path, t, matrices=True)
+    dvp.tree_io.check_tree_file_native(path, t, matrices=True)  # the same comparison inside the library
     assert [s[0] for s in info["sections"]] == ["f", "recombine_matrices", "decompose_matrices"]
     assert [s[1] for s in info["sections"]] == [8 + 29 * 2 * N, 8 + 29 * 4 * N, 8 + 29 * 4 * N]
     mine = tmp_path / "tree_device"
@@ -158,6 +159,13 @@ def test_butterfly_matrices_and_minimal_tree_file(dvp, nat, tmp_path, log_n):
         dvp.tree_io.write_tree_file(path, bad)
         with pytest.raises(ValueError, match=f"decompose_matrices differs.*entry {N // 2 + 3}"):
             dvp.tree_io.check_tree_file(path, t, matrices=True)
+        with pytest.raises(ValueError, match=f"decompose_matrices differs.*entry {N // 2 + 3}"):
+            dvp.tree_io.check_tree_file_native(path, t, matrices=True)
+        dvp.tree_io.check_tree_file_native(path, t, matrices=False)  # the leaves alone are intact
+        bad["f"][N + 5, 1] ^= np.uint64(4)  # leaf 5
+        dvp.tree_io.write_tree_file(path, bad)
+        with pytest.raises(ValueError, match=f"section f differs.*entry {N + 5}"):
+            dvp.tree_io.check_tree_file_native(path, t, matrices=False)
     t.close()
 
 

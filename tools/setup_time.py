@@ -23,6 +23,14 @@ for log_m in [int(x) for x in sys.argv[1:]] or [20]:
                 dvp.check(dvp.lib.dvp_setup_cache_dir(nat.ptr(t), nat.ptr(d), nat.ptr(e), os.fsencode(tmp), len(pub), pre), "dvp_setup_cache_dir")
                 torch.cuda.synchronize(); dt = time.perf_counter() - t1
                 print(f"  dvp_setup_cache_dir(write_precomputes={pre}) call {rep + 1}: {dt:.2f} s", flush=True)
+        # prover_prepares_precomputes (src/proving.rs:225-325) on the directory the setup left: first with bar_wts / z_vals2inv / tree2n
+        # missing (generated + written), then validating what it finds (the reference quotes "10-20 mins" for the trees at 2^23)
+        for n in (dvp.artifacts.BAR_WTS, dvp.artifacts.Z_VALS2_INV):
+            os.remove(os.path.join(tmp, n))
+        for label, validate in (("generate + write tree2n, bar_wts, z_vals2inv", False), ("validate everything found", True)):
+            t1 = time.perf_counter()
+            rep_bits = dvp.proving.prover_prepares_precomputes(tmp, validate_precompute=validate)
+            print(f"  dvp_prover_prepares_precomputes ({label}): {time.perf_counter() - t1:.2f} s (report 0x{rep_bits:x})", flush=True)
         sizes = {n: os.path.getsize(os.path.join(tmp, n)) for n in sorted(os.listdir(tmp))}
         print("  files (MB):", {k: round(v / 1e6, 1) for k, v in sizes.items()}, flush=True)
     finally:
