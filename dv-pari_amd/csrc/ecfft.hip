@@ -166,19 +166,19 @@ __global__ void __launch_bounds__(256) k_build_mats(const Fr* __restrict__ Ld, i
 // test (oracle extend / enter / exit element for element, FFTR sections, proofs) is unchanged.
 // Constants per pair (Montgomery form, pre-sliced): decompose (1 / (s0 - s1), -s0), recombine (s0, s1); layer d at offset
 // 2 (n - (n >> d)).  The true 2x2 matrices are still built on demand for dvp_debug_ecfft_matrices / FFTR tree files (k_build_mats).
-__global__ void __launch_bounds__(256) k_build_twiddles(const Fr* __restrict__ Ld, int sl, uint32_t nd, int src, int dst, Fr29* __restrict__ dec,
-                                                        Fr29* __restrict__ rec) {
+__global__ void __launch_bounds__(256) k_build_twiddles(const Fr* __restrict__ Ld, int sl, uint32_t nd, int src, int dst, Fr30* __restrict__ dec,
+                                                        Fr30* __restrict__ rec) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t h = nd >> 1;
   if (i >= h) return;
   {
     Fr s0 = Ld[(size_t)(2 * i + src) << sl];
     Fr s1 = Ld[(size_t)(2 * i + src + nd) << sl];
-    dec[2 * (size_t)i + 0] = fr29_from(fr_inv(fr_sub(s0, s1)));
-    dec[2 * (size_t)i + 1] = fr29_from(fr_neg(s0));
+    dec[2 * (size_t)i + 0] = fr30_const(fr_inv(fr_sub(s0, s1)));
+    dec[2 * (size_t)i + 1] = fr30_const(fr_neg(s0));
   }
-  rec[2 * (size_t)i + 0] = fr29_from(Ld[(size_t)(2 * i + dst) << sl]);
-  rec[2 * (size_t)i + 1] = fr29_from(Ld[(size_t)(2 * i + dst + nd) << sl]);
+  rec[2 * (size_t)i + 0] = fr30_const(Ld[(size_t)(2 * i + dst) << sl]);
+  rec[2 * (size_t)i + 1] = fr30_const(Ld[(size_t)(2 * i + dst + nd) << sl]);
 }
 // W_d[j] = v_d(point of position j in a block of nd values) * W_{d+1}[j mod (nd / 2)], bottom up; positions j < nd/2 sit at the
 // first point of pair j, the others at the second point of pair j - nd/2 (that is where the in-place butterflies leave them)
@@ -192,44 +192,78 @@ __global__ void __launch_bounds__(256) k_twist_layer(const Fr* __restrict__ Ld, 
   if (w_next) v = fr_mul(v, w_next[i]);
   w_cur[j] = v;
 }
-__global__ void __launch_bounds__(256) k_twist_finish(const Fr* __restrict__ w_src, const Fr* __restrict__ w_dst, uint32_t n, Fr29* __restrict__ win,
-                                                      Fr29* __restrict__ wout) {
+__global__ void __launch_bounds__(256) k_twist_finish(const Fr* __restrict__ w_src, const Fr* __restrict__ w_dst, uint32_t n, Fr30* __restrict__ win,
+                                                      Fr30* __restrict__ wout) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  win[j] = fr29_from(fr_inv(w_src[j]));
-  wout[j] = fr29_from(w_dst[j]);
+  win[j] = fr30_const(fr_inv(w_src[j]));
+  wout[j] = fr30_const(w_dst[j]);
 }
 
+// ---- the butterflies on lazy 30-bit-limb values (fr.cuh: Fr30) ---------------------------------------------------------------
+// Between the passes of an extend the data buffer holds Fr30 values (same 32 bytes as an Fr): the pass that carries the input twist
+// (`pre`, always the first) slices its canonical input, the pass that carries the output twist (`post`, always the last) reduces and
+// re-slices; everything in between is multiply-accumulate only.  Bounds (in units of p, fr.cuh): the input twist leaves < 1.01; a
+// decompose step gives Q1 < 1.4 and Q0 < bound(e0) + 1.01; a recombine step bound(Q0) + 1 + bound(Q1)/512: at most +1.13 per layer,
+// < 64 after the 2 x 27 layers of the largest tree -- the lent 128 p of fr30_sub_lazy always covers its subtrahend.
 struct Tw {
-  Fr29 a, b;
+  Fr30 a, b;
 };
-__device__ __forceinline__ Tw tw_load(const Fr29* __restrict__ t, uint32_t i) {
+__device__ __forceinline__ Tw tw_load(const Fr30* __restrict__ t, uint32_t i) {
   Tw r;
   r.a = t[2 * (size_t)i];
   r.b = t[2 * (size_t)i + 1];
   return r;
 }
-// (e0, e1) = (Q(s0), Q(s1)) -> (Q0, Q1); t = (1 / (s0 - s1), -s0)
-__device__ __forceinline__ void bf_dec(Fr& e0, Fr& e1, const Tw& t) {
-  const Fr q1 = fr_mul29(t.a, fr29_from(fr_sub(e0, e1)));
-  e0 = fr_muladd29(t.b, fr29_from(q1), fr29_from(e0));
+__device__ __forceinline__ Fr30 ld30(const Fr* p) {  // a value a previous pass stored in Fr30 form
+  const Fr v = *p;
+  Fr30 r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = v.v[i];
+  return r;
+}
+__device__ __forceinline__ void st30(Fr* p, const Fr30& a) {
+  Fr v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v.v[i] = a.l[i];
+  *p = v;
+}
+// two independent decompose steps: (e0, e1) = (Q(s0), Q(s1)) -> (Q0, Q1); t = (1 / (s0 - s1), -s0)
+__device__ __forceinline__ void bf_dec2(Fr30& a0, Fr30& a1, const Tw& ta, Fr30& b0, Fr30& b1, const Tw& tb) {
+  const Fr30 z = fr30_zero();
+  Fr30 qa, qb;
+  fr30_muladd_x2(ta.a, fr30_sub_lazy(a0, a1), z, tb.a, fr30_sub_lazy(b0, b1), z, qa, qb);
+  fr30_muladd_x2(ta.b, qa, a0, tb.b, qb, b0, a0, b0);
+  a1 = qa;
+  b1 = qb;
+}
+__device__ __forceinline__ void bf_dec(Fr30& e0, Fr30& e1, const Tw& t) {
+  const Fr30 q1 = fr30_muladd(t.a, fr30_sub_lazy(e0, e1), fr30_zero());
+  e0 = fr30_muladd(t.b, q1, e0);
   e1 = q1;
 }
-// (e0, e1) = (Q0, Q1) -> (Q(s0), Q(s1)); t = (s0, s1)
-__device__ __forceinline__ void bf_rec(Fr& e0, Fr& e1, const Tw& t) {
-  const Fr29 q0 = fr29_from(e0), q1 = fr29_from(e1);
-  e0 = fr_muladd29(t.a, q1, q0);
-  e1 = fr_muladd29(t.b, q1, q0);
+// (e0, e1) = (Q0, Q1) -> (Q(s0), Q(s1)); t = (s0, s1): the two products of one step are independent
+__device__ __forceinline__ void bf_rec(Fr30& e0, Fr30& e1, const Tw& t) { fr30_muladd_x2(t.a, e1, e0, t.b, e1, e0, e0, e1); }
+// the twists of the first / last pass, two values at a time
+__device__ __forceinline__ void tw_in2(const Fr30* __restrict__ w, uint32_t p0, uint32_t p1, const Fr& x0, const Fr& x1, Fr30& r0, Fr30& r1) {
+  const Fr30 z = fr30_zero();
+  fr30_muladd_x2(w[p0], fr30_from(x0), z, w[p1], fr30_from(x1), z, r0, r1);
 }
-__device__ __forceinline__ Fr tw_scale(const Fr29* __restrict__ w, uint32_t pos, const Fr& x) { return fr_mul29(w[pos], fr29_from(x)); }
+__device__ __forceinline__ void tw_out2(const Fr30* __restrict__ w, uint32_t p0, uint32_t p1, const Fr30& x0, const Fr30& x1, Fr& r0, Fr& r1) {
+  const Fr30 z = fr30_zero();
+  Fr30 y0, y1;
+  fr30_muladd_x2(w[p0], x0, z, w[p1], x1, z, y0, y1);
+  r0 = fr30_canon(y0);
+  r1 = fr30_canon(y1);
+}
 
 // One butterfly pass over `batch` vectors of n values.  Blocks of size 2h; pair (i, i+h) inside each block uses constants i of
 // this layer.  One thread = one pair for all batch vectors, so the constants are read once per pair and reused `batch` times.
 // pre / post (nullptr = none): the twists of the first / last pass of an extend, indexed by the position in the vector.
 template <int BATCH, bool DEC>
 __global__ void __launch_bounds__(256) k_butterfly(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
-                                                   const Fr29* __restrict__ tws, int lh, uint32_t n, const Fr29* __restrict__ pre,
-                                                   const Fr29* __restrict__ post, uint32_t nv /* values per vector (twist index range) */) {
+                                                   const Fr30* __restrict__ tws, int lh, uint32_t n, const Fr30* __restrict__ pre,
+                                                   const Fr30* __restrict__ post, uint32_t nv /* values per vector (twist index range) */) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (n >> 1)) return;
   uint32_t h = 1u << lh;
@@ -237,16 +271,23 @@ __global__ void __launch_bounds__(256) k_butterfly(const Fr* src /* == data, or 
   uint32_t i0 = ((tid >> lh) << (lh + 1)) | i;
   uint32_t i1 = i0 + h;
   const Tw t = tw_load(tws, i);
+  const uint32_t p0 = i0 & (nv - 1), p1 = i1 & (nv - 1);
 #pragma unroll
   for (int b = 0; b < BATCH; ++b) {
     Fr* v = data + (size_t)b * n;
     const Fr* u = src + (size_t)b * n;
-    Fr e0 = u[i0], e1 = u[i1];
-    if (pre) { e0 = tw_scale(pre, i0 & (nv - 1), e0); e1 = tw_scale(pre, i1 & (nv - 1), e1); }
+    Fr30 e0, e1;
+    if (pre) tw_in2(pre, p0, p1, u[i0], u[i1], e0, e1); else { e0 = ld30(u + i0); e1 = ld30(u + i1); }
     if (DEC) bf_dec(e0, e1, t); else bf_rec(e0, e1, t);
-    if (post) { e0 = tw_scale(post, i0 & (nv - 1), e0); e1 = tw_scale(post, i1 & (nv - 1), e1); }
-    v[i0] = e0;
-    v[i1] = e1;
+    if (post) {
+      Fr o0, o1;
+      tw_out2(post, p0, p1, e0, e1, o0, o1);
+      v[i0] = o0;
+      v[i1] = o1;
+    } else {
+      st30(v + i0, e0);
+      st30(v + i1, e1);
+    }
   }
 }
 
@@ -256,29 +297,13 @@ __global__ void __launch_bounds__(256) k_butterfly(const Fr* src /* == data, or 
 // layer d + 1 (j, shared by both of its pairs).  DEC = decompose order (wide layer first); recombine runs the narrow layer first.
 // BATCH vectors: lane = (quad of values, vector) with the vector index fastest, so the BATCH lanes that need the same constants
 // sit in the same wave and their loads are one request.
-template <int BATCH, bool DEC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_butterfly4(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
-                                                    const Fr29* __restrict__ tw_wide, const Fr29* __restrict__ tw_narrow, int lh2, uint32_t n,
-                                                    const Fr29* __restrict__ pre, const Fr29* __restrict__ post, uint32_t nv) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t tid = gid / BATCH, bv = gid - tid * BATCH;
-  if (tid >= (n >> 2)) return;
-  const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
-  const uint32_t j = tid & (h2 - 1);
-  const uint32_t i0 = ((tid >> lh2) << (lh2 + 2)) | j;
-  Fr* v = data + (size_t)bv * n + i0;
-  const Fr* u = src + (size_t)bv * n + i0;
-  Fr x0 = u[0], x1 = u[h2], x2 = u[h1], x3 = u[h1 + h2];
-  if (pre) {
-    const uint32_t p0 = i0 & (nv - 1);
-    x0 = tw_scale(pre, p0, x0); x1 = tw_scale(pre, p0 + h2, x1); x2 = tw_scale(pre, p0 + h1, x2); x3 = tw_scale(pre, p0 + h1 + h2, x3);
-  }
+template <bool DEC>
+__device__ __forceinline__ void radix4(Fr30& x0, Fr30& x1, Fr30& x2, Fr30& x3, const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow,
+                                       uint32_t j, uint32_t h2) {
   if (DEC) {
-    bf_dec(x0, x2, tw_load(tw_wide, j));
-    bf_dec(x1, x3, tw_load(tw_wide, j + h2));
+    bf_dec2(x0, x2, tw_load(tw_wide, j), x1, x3, tw_load(tw_wide, j + h2));
     const Tw c = tw_load(tw_narrow, j);
-    bf_dec(x0, x1, c);
-    bf_dec(x2, x3, c);
+    bf_dec2(x0, x1, c, x2, x3, c);
   } else {
     {
       const Tw c = tw_load(tw_narrow, j);
@@ -288,11 +313,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     bf_rec(x0, x2, tw_load(tw_wide, j));
     bf_rec(x1, x3, tw_load(tw_wide, j + h2));
   }
-  if (post) {
-    const uint32_t p0 = i0 & (nv - 1);
-    x0 = tw_scale(post, p0, x0); x1 = tw_scale(post, p0 + h2, x1); x2 = tw_scale(post, p0 + h1, x2); x3 = tw_scale(post, p0 + h1 + h2, x3);
+}
+template <int BATCH, bool DEC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) k_butterfly4(const Fr* src /* == data, or the untouched input of the first pass */, Fr* data,
+                                                    const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow, int lh2, uint32_t n,
+                                                    const Fr30* __restrict__ pre, const Fr30* __restrict__ post, uint32_t nv) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tid = gid / BATCH, bv = gid - tid * BATCH;
+  if (tid >= (n >> 2)) return;
+  const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
+  const uint32_t j = tid & (h2 - 1);
+  const uint32_t i0 = ((tid >> lh2) << (lh2 + 2)) | j;
+  Fr* v = data + (size_t)bv * n + i0;
+  const Fr* u = src + (size_t)bv * n + i0;
+  const uint32_t p0 = i0 & (nv - 1);
+  Fr30 x0, x1, x2, x3;
+  if (pre) {
+    tw_in2(pre, p0, p0 + h2, u[0], u[h2], x0, x1);
+    tw_in2(pre, p0 + h1, p0 + h1 + h2, u[h1], u[h1 + h2], x2, x3);
+  } else {
+    x0 = ld30(u); x1 = ld30(u + h2); x2 = ld30(u + h1); x3 = ld30(u + h1 + h2);
   }
-  v[0] = x0; v[h2] = x1; v[h1] = x2; v[h1 + h2] = x3;
+  radix4<DEC>(x0, x1, x2, x3, tw_wide, tw_narrow, j, h2);
+  if (post) {
+    Fr o0, o1, o2, o3;
+    tw_out2(post, p0, p0 + h2, x0, x1, o0, o1);
+    tw_out2(post, p0 + h1, p0 + h1 + h2, x2, x3, o2, o3);
+    v[0] = o0; v[h2] = o1; v[h1] = o2; v[h1 + h2] = o3;
+  } else {
+    st30(v, x0); st30(v + h2, x1); st30(v + h1, x2); st30(v + h1 + h2, x3);
+  }
 }
 
 // Fused bottom of an extend: the last `lb` decompose layers and the first `lb` recombine layers only mix
@@ -304,12 +354,12 @@ constexpr int FUSE_LOG = 11;
 constexpr uint32_t FUSE_ELEMS = 1u << FUSE_LOG;
 
 template <bool DEC>
-__device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ tws, int lh, uint32_t pairs) {
+__device__ __forceinline__ void lds_bfly(Fr30* x, const Fr30* __restrict__ tws, int lh, uint32_t pairs) {
   const uint32_t h = 1u << lh;
   for (uint32_t q = threadIdx.x; q < pairs; q += blockDim.x) {
     uint32_t i = q & (h - 1);
     uint32_t i0 = ((q >> lh) << (lh + 1)) | i, i1 = i0 + h;
-    Fr e0 = x[i0], e1 = x[i1];
+    Fr30 e0 = x[i0], e1 = x[i1];
     if (DEC) bf_dec(e0, e1, tw_load(tws, i)); else bf_rec(e0, e1, tw_load(tws, i));
     x[i0] = e0;
     x[i1] = e1;
@@ -319,46 +369,37 @@ __device__ __forceinline__ void lds_bfly(Fr* x, const Fr29* __restrict__ tws, in
 // two layers per barrier inside the block (the radix-4 step of k_butterfly4 on the LDS copy): half the barriers and half the LDS
 // round trips of the per-layer loop.  lh2 = log2 of the narrow layer's pair distance; wide layer first when DEC.
 template <bool DEC>
-__device__ __forceinline__ void lds_bfly4(Fr* x, const Fr29* __restrict__ tw_wide, const Fr29* __restrict__ tw_narrow, int lh2, uint32_t quads) {
+__device__ __forceinline__ void lds_bfly4(Fr30* x, const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow, int lh2, uint32_t quads) {
   const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
   for (uint32_t q = threadIdx.x; q < quads; q += blockDim.x) {
     const uint32_t j = q & (h2 - 1);
     const uint32_t i0 = ((q >> lh2) << (lh2 + 2)) | j;
-    Fr x0 = x[i0], x1 = x[i0 + h2], x2 = x[i0 + h1], x3 = x[i0 + h1 + h2];
-    if (DEC) {
-      bf_dec(x0, x2, tw_load(tw_wide, j));
-      bf_dec(x1, x3, tw_load(tw_wide, j + h2));
-      const Tw c = tw_load(tw_narrow, j);
-      bf_dec(x0, x1, c);
-      bf_dec(x2, x3, c);
-    } else {
-      {
-        const Tw c = tw_load(tw_narrow, j);
-        bf_rec(x0, x1, c);
-        bf_rec(x2, x3, c);
-      }
-      bf_rec(x0, x2, tw_load(tw_wide, j));
-      bf_rec(x1, x3, tw_load(tw_wide, j + h2));
-    }
+    Fr30 x0 = x[i0], x1 = x[i0 + h2], x2 = x[i0 + h1], x3 = x[i0 + h1 + h2];
+    radix4<DEC>(x0, x1, x2, x3, tw_wide, tw_narrow, j, h2);
     x[i0] = x0; x[i0 + h2] = x1; x[i0 + h1] = x2; x[i0 + h1 + h2] = x3;
   }
   __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr29* __restrict__ dec,
-               const Fr29* __restrict__ rec, uint32_t n, int ln, int lb, size_t total, const Fr29* __restrict__ pre, const Fr29* __restrict__ post) {
-  __shared__ Fr x[FUSE_ELEMS];
+k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr30* __restrict__ dec,
+               const Fr30* __restrict__ rec, uint32_t n, int ln, int lb, size_t total, const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
+  __shared__ Fr30 x[FUSE_ELEMS];
   const size_t base = (size_t)blockIdx.x * FUSE_ELEMS;
   const uint32_t elems = (uint32_t)min((size_t)FUSE_ELEMS, total - base);
   const uint32_t pos0 = (uint32_t)(base & (size_t)(n - 1));  // position of the block's first value inside its vector (n is a power of two)
-  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) {
-    Fr v = src[base + k];
-    if (pre) v = tw_scale(pre, (pos0 + k) & (n - 1), v);
-    x[k] = v;
+  // two values per thread and trip (k, k + elems / 2): their twist products are independent
+  const uint32_t half = elems >> 1;  // elems is even: a batch of vectors of n >= 2 values
+  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
+    if (pre)
+      tw_in2(pre, (pos0 + k) & (n - 1), (pos0 + k + half) & (n - 1), src[base + k], src[base + k + half], x[k], x[k + half]);
+    else {
+      x[k] = ld30(src + base + k);
+      x[k + half] = ld30(src + base + k + half);
+    }
   }
   __syncthreads();
-  auto tw_of = [&](const Fr29* b, int L) { return b + 2 * (size_t)(n - (n >> (ln - lb + L))); };
+  auto tw_of = [&](const Fr30* b, int L) { return b + 2 * (size_t)(n - (n >> (ln - lb + L))); };
   const bool whole = elems == FUSE_ELEMS || (elems & 3u) == 0;  // (a short last block still holds whole sub-blocks of every layer it runs)
   {
     int L = 0;  // decompose, sub-block size 2^(lb-L); two layers per barrier while two remain
@@ -373,10 +414,16 @@ k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-
       for (; L >= 1; L -= 2) lds_bfly4<false>(x, tw_of(rec, L - 1), tw_of(rec, L), lb - L - 1, elems >> 2);
     for (; L >= 0; --L) lds_bfly<false>(x, tw_of(rec, L), lb - L - 1, elems >> 1);
   }
-  for (uint32_t k = threadIdx.x; k < elems; k += blockDim.x) {
-    Fr v = x[k];
-    if (post) v = tw_scale(post, (pos0 + k) & (n - 1), v);
-    data[base + k] = v;
+  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
+    if (post) {
+      Fr o0, o1;
+      tw_out2(post, (pos0 + k) & (n - 1), (pos0 + k + half) & (n - 1), x[k], x[k + half], o0, o1);
+      data[base + k] = o0;
+      data[base + k + half] = o1;
+    } else {
+      st30(data + base + k, x[k]);
+      st30(data + base + k + half, x[k + half]);
+    }
   }
 }
 
@@ -431,11 +478,11 @@ static int build_matset(dvp_ecfft* c, int sl, int to_even, MatSet** out, hipStre
   uint32_t n = (c->n_leaves >> sl) >> 1;  // evaluations moved by extend on this subtree
   MatSet ms;
   if (n > 1) {
-    size_t bytes = (size_t)(n - 1) * 2 * sizeof(Fr29);
+    size_t bytes = (size_t)(n - 1) * 2 * sizeof(Fr30);
     DVP_HIP(hipMalloc((void**)&ms.dec, bytes));
     DVP_HIP(hipMalloc((void**)&ms.rec, bytes));
-    DVP_HIP(hipMalloc((void**)&ms.win, (size_t)n * sizeof(Fr29)));
-    DVP_HIP(hipMalloc((void**)&ms.wout, (size_t)n * sizeof(Fr29)));
+    DVP_HIP(hipMalloc((void**)&ms.win, (size_t)n * sizeof(Fr30)));
+    DVP_HIP(hipMalloc((void**)&ms.wout, (size_t)n * sizeof(Fr30)));
     int src = to_even ? 1 : 0, dst = to_even ? 0 : 1;
     int ln = 31 - __builtin_clz(n);
     for (int d = 0; d < ln; ++d) {
@@ -471,11 +518,6 @@ static int build_matset(dvp_ecfft* c, int sl, int to_even, MatSet** out, hipStre
   return DVP_OK;
 }
 
-template <int B>
-static void launch_bfly(const Fr* src, Fr* data, const Fr29* mats, int lh, uint32_t n, hipStream_t st) {
-  hipLaunchKernelGGL((k_butterfly<B>), dim3(cdiv(n >> 1, TPB)), dim3(TPB), 0, st, src, data, mats, lh, n);
-}
-
 // in-place extend of `batch` vectors of n = (N>>sl)/2 values
 int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) { return extend_from(c, sl, to_even, data, data, batch, st); }
 // the same out of place: `src` is read by the first pass only and left untouched (the prover keeps a, b, c on D for its K scalars;
@@ -495,12 +537,12 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   // The first launch multiplies its input by the source twist, the last one its output by the destination twist (see "TWISTED
   // butterflies" above); a pass knows which it is from `first` / the `last` flag of its caller.
   bool first = true;
-  auto pre_of = [&]() { const Fr29* r = first ? ms->win : nullptr; first = false; return r; };
-  auto pass = [&](const Fr29* base, int d, bool dec, bool last) {
-    const Fr29* tws = base + 2 * (size_t)(n - (n >> d));
+  auto pre_of = [&]() { const Fr30* r = first ? ms->win : nullptr; first = false; return r; };
+  auto pass = [&](const Fr30* base, int d, bool dec, bool last) {
+    const Fr30* tws = base + 2 * (size_t)(n - (n >> d));
     const int lh = ln - d - 1;
-    const Fr29* pre = pre_of();
-    const Fr29* post = last ? ms->wout : nullptr;
+    const Fr30* pre = pre_of();
+    const Fr30* post = last ? ms->wout : nullptr;
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g(cdiv(nn >> 1, TPB)), b(TPB);
 #define DVP_BF(B) \
@@ -511,12 +553,12 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
     src = data;
   };
   // two layers per pass (k_butterfly4) while two top layers remain; `wide` = layer d, `narrow` = layer d + 1
-  auto pass4 = [&](const Fr29* base, int d, bool dec, bool last) {
-    const Fr29* wide = base + 2 * (size_t)(n - (n >> d));
-    const Fr29* narrow = base + 2 * (size_t)(n - (n >> (d + 1)));
+  auto pass4 = [&](const Fr30* base, int d, bool dec, bool last) {
+    const Fr30* wide = base + 2 * (size_t)(n - (n >> d));
+    const Fr30* narrow = base + 2 * (size_t)(n - (n >> (d + 1)));
     const int lh2 = ln - d - 2;
-    const Fr29* pre = pre_of();
-    const Fr29* post = last ? ms->wout : nullptr;
+    const Fr30* pre = pre_of();
+    const Fr30* post = last ? ms->wout : nullptr;
     const dim3 g(cdiv((size_t)(n >> 2) * batch, TPB)), b(TPB);
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g1(cdiv(nn >> 2, TPB));

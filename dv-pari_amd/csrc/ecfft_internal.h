@@ -9,14 +9,15 @@
 
 using dvp::Fr;
 using dvp::Fr29;
+using dvp::Fr30;
 
 struct MatSet {
   // twisted-butterfly constants (ecfft.hip): (n-1) x 2 entries each (Montgomery form, pre-sliced), layer d at offset 2*(n - (n>>d)):
   // decompose (1 / (s0 - s1), -s0), recombine (s0, s1)
-  Fr29* dec = nullptr;
-  Fr29* rec = nullptr;
-  Fr29* win = nullptr;   // n entries: 1 / W^src(position): the input twist of an extend
-  Fr29* wout = nullptr;  // n entries: W^dst(position): its output twist
+  Fr30* dec = nullptr;
+  Fr30* rec = nullptr;
+  Fr30* win = nullptr;   // n entries: 1 / W^src(position): the input twist of an extend
+  Fr30* wout = nullptr;  // n entries: W^dst(position): its output twist
 };
 
 struct dvp_ecfft {

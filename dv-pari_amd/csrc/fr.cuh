@@ -258,6 +258,18 @@ DVP_HD Fr fr_dot2(const Fr29& a0, const Fr29& b0, const Fr29& a1, const Fr29& b1
 // addition rides in the column accumulators of the Montgomery product: 64 + 32 limb products, no modular addition.  The twisted ECFFT
 // butterflies (ecfft.hip) are two of these per pair, against two fr_dot2 (2 x 160 limb products) for the untwisted 2x2 matrices.
 // T = a b + c R + m p < p^2 + 2 p R gives T / R < 3p: two conditional subtractions.  c = nullptr-like zero limbs -> plain product.
+// One limb product accumulated: on the device an explicit v_mad_u64_u32 -- left to itself the compiler re-associates the column sums
+// into several partial chains and then pays a half-rate 64-bit add (v_lshl_add_u64) per joint, ~47 per product against 96 multiply-adds.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DVP_FR_NO_ASM_MAD)
+__device__ __forceinline__ uint64_t fr_mad64(uint32_t a, uint32_t b, uint64_t c) {
+  uint64_t d;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+  return d;
+}
+#else
+DVP_HD uint64_t fr_mad64(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+#endif
+
 DVP_HD Fr fr_muladd29(const Fr29& a, const Fr29& b, const Fr29& c) {
   constexpr uint32_t p[8] = DVP_FR_P29_LIMBS;
   uint32_t m[8], r[8];
@@ -265,21 +277,21 @@ DVP_HD Fr fr_muladd29(const Fr29& a, const Fr29& b, const Fr29& c) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) t += (uint64_t)a.l[j] * b.l[i - j];
+    for (int j = 0; j <= i; ++j) t = fr_mad64(a.l[j], b.l[i - j], t);
 #pragma unroll
     for (int j = 0; j < i; ++j)
-      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+      if (p[i - j] != 0) t = fr_mad64(m[j], p[i - j], t);
     m[i] = ((uint32_t)t * FR_N0_29) & FR_M29;
-    t += (uint64_t)m[i] * p[0];
+    t = fr_mad64(m[i], p[0], t);
     t >>= 29;
   }
 #pragma unroll
   for (int i = 8; i < 16; ++i) {
 #pragma unroll
-    for (int j = i - 7; j < 8; ++j) t += (uint64_t)a.l[j] * b.l[i - j];
+    for (int j = i - 7; j < 8; ++j) t = fr_mad64(a.l[j], b.l[i - j], t);
 #pragma unroll
     for (int j = i - 7; j < 8; ++j)
-      if (p[i - j] != 0) t += (uint64_t)m[j] * p[i - j];
+      if (p[i - j] != 0) t = fr_mad64(m[j], p[i - j], t);
     t += c.l[i - 8];
     r[i - 8] = (uint32_t)t & FR_M29;
     t >>= 29;
@@ -293,6 +305,166 @@ DVP_HD Fr fr_mul29(const Fr29& a, const Fr29& b) {
   for (int i = 0; i < 8; ++i) z.l[i] = 0;
   return fr_muladd29(a, b, z);
 }
+
+// ---- lazy 30-bit-limb arithmetic: the ECFFT butterflies (round 4) ------------------------------------------------------------
+// Inside an extend a value lives as 8 limbs of 30 bits (limb 7 keeps whatever is left), only CONGRUENT to the field element and
+// bounded by a few dozen p instead of reduced below p.  Montgomery radix R' = 2^240 = eight 30-bit limbs, so p / R' = 2^-9: a product
+// constant * x / R' + p is below p (1 + B / 512) for x < B p -- the multiplication itself pulls a value back to ~p, and an
+// accumulated addend only grows the bound by one p per layer.  Over the <= 2 x 27 layers of an extend every value stays below 64 p
+// < 2^238 < 2^240, so a butterfly needs NO conditional subtraction and no re-slicing between 32-bit and 29/30-bit limbs (the two
+// fully reduced 29-bit products they replace spent ~45 % of their instructions on exactly that).  A column of the schoolbook
+// product is <= 8 + 5 terms of 60 bits: < 0.54 * 2^64 in the worst case (tools checked with all-ones limbs), one 64-bit accumulator,
+// one v_mad_u64_u32 per limb product.  Constants (twiddles, twists) are canonical values times R' mod p, pre-sliced; the data keeps
+// whatever domain the caller uses.  The first pass of an extend slices its canonical input, the last one reduces (one conditional
+// subtraction: the output twist product is below 2p) and re-slices to Fr.
+struct Fr30 {
+  uint32_t l[8];
+};
+constexpr uint32_t FR_M30 = 0x3fffffffu;
+constexpr uint32_t FR_N0_30 = 0x0c382fe1u;  // -p^{-1} mod 2^30
+#define DVP_FR_P30_LIMBS \
+  { 0x3173abdfu, 0x3bec6b57u, 0x115bcd46u, 0x01a756eeu, 0x00000000u, 0x00000000u, 0x00000000u, 0x00200000u }
+// 128 p with 2^30 lent from every limb to the one below (limb i < 7: + 2^30, limb i > 0: - 1): e0 + this - e1 never borrows
+#define DVP_FR_128P30_LIMBS \
+  { 0x79d5ef80u, 0x7635abe1u, 0x6de6a376u, 0x53ab7721u, 0x40000002u, 0x3fffffffu, 0x3fffffffu, 0x0fffffffu }
+// 2^8 in Montgomery form (R = 2^232): fr_mul(x R, this) = x 2^240, the constant form of the 30-bit multiplier
+#define DVP_FR_2P8_MONT_LIMBS \
+  { 0x0a1beddfu, 0x78c56ef3u, 0x8d9c13f6u, 0xf2cbe5e9u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x0000007fu }
+
+DVP_HD Fr30 fr30_from(const Fr& a) {  // a < 2^240
+  Fr30 r;
+  r.l[0] = a.v[0] & FR_M30;
+  r.l[1] = ((a.v[0] >> 30) | (a.v[1] << 2)) & FR_M30;
+  r.l[2] = ((a.v[1] >> 28) | (a.v[2] << 4)) & FR_M30;
+  r.l[3] = ((a.v[2] >> 26) | (a.v[3] << 6)) & FR_M30;
+  r.l[4] = ((a.v[3] >> 24) | (a.v[4] << 8)) & FR_M30;
+  r.l[5] = ((a.v[4] >> 22) | (a.v[5] << 10)) & FR_M30;
+  r.l[6] = ((a.v[5] >> 20) | (a.v[6] << 12)) & FR_M30;
+  r.l[7] = (a.v[6] >> 18) | (a.v[7] << 14);
+  return r;
+}
+DVP_HD Fr fr30_to_fr(const Fr30& a) {  // plain re-slicing of a normalized value < 2^240
+  Fr r;
+  r.v[0] = a.l[0] | (a.l[1] << 30);
+  r.v[1] = (a.l[1] >> 2) | (a.l[2] << 28);
+  r.v[2] = (a.l[2] >> 4) | (a.l[3] << 26);
+  r.v[3] = (a.l[3] >> 6) | (a.l[4] << 24);
+  r.v[4] = (a.l[4] >> 8) | (a.l[5] << 22);
+  r.v[5] = (a.l[5] >> 10) | (a.l[6] << 20);
+  r.v[6] = (a.l[6] >> 12) | (a.l[7] << 18);
+  r.v[7] = a.l[7] >> 14;
+  return r;
+}
+// a Montgomery-form constant (x R, R = 2^232, fully reduced) -> the multiplier's constant form x R' mod p, sliced
+DVP_HD Fr30 fr30_const(const Fr& x_mont) {
+  constexpr uint32_t c[8] = DVP_FR_2P8_MONT_LIMBS;
+  Fr k;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k.v[i] = c[i];
+  return fr30_from(fr_mul(x_mont, k));
+}
+// e0 - e1 + 128 p, normalized (e1 < 128 p)
+DVP_HD Fr30 fr30_sub_lazy(const Fr30& e0, const Fr30& e1) {
+  constexpr uint32_t kp[8] = DVP_FR_128P30_LIMBS;
+  Fr30 d;
+  uint32_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t t = e0.l[i] + kp[i] + cy - e1.l[i];  // in [0, 2^32): the lent 2^30 covers e1's limb
+    d.l[i] = i < 7 ? (t & FR_M30) : t;
+    cy = t >> 30;
+  }
+  return d;
+}
+// Two INDEPENDENT products column by column: r_k = a_k b_k / R' + c_k (+ at most p), a_k a constant below p.  Interleaving the two
+// accumulator chains is what keeps the explicit v_mad_u64_u32 (fr_mad64) free: the instruction after one never reads its result.
+DVP_HD void fr30_muladd_x2(const Fr30& a0, const Fr30& b0, const Fr30& c0, const Fr30& a1, const Fr30& b1, const Fr30& c1, Fr30& r0, Fr30& r1) {
+  constexpr uint32_t p[8] = DVP_FR_P30_LIMBS;
+  uint32_t m0[8], m1[8];
+  Fr30 o0, o1;
+  uint64_t t0 = 0, t1 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      t0 = fr_mad64(a0.l[j], b0.l[i - j], t0);
+      t1 = fr_mad64(a1.l[j], b1.l[i - j], t1);
+    }
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      if (p[i - j] != 0) {
+        t0 = fr_mad64(m0[j], p[i - j], t0);
+        t1 = fr_mad64(m1[j], p[i - j], t1);
+      }
+    m0[i] = ((uint32_t)t0 * FR_N0_30) & FR_M30;
+    m1[i] = ((uint32_t)t1 * FR_N0_30) & FR_M30;
+    t0 = fr_mad64(m0[i], p[0], t0);
+    t1 = fr_mad64(m1[i], p[0], t1);
+    t0 >>= 30;
+    t1 >>= 30;
+  }
+#pragma unroll
+  for (int i = 8; i < 16; ++i) {
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j) {
+      t0 = fr_mad64(a0.l[j], b0.l[i - j], t0);
+      t1 = fr_mad64(a1.l[j], b1.l[i - j], t1);
+    }
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j)
+      if (p[i - j] != 0) {
+        t0 = fr_mad64(m0[j], p[i - j], t0);
+        t1 = fr_mad64(m1[j], p[i - j], t1);
+      }
+    t0 += c0.l[i - 8];
+    t1 += c1.l[i - 8];
+    o0.l[i - 8] = i < 15 ? ((uint32_t)t0 & FR_M30) : (uint32_t)t0;  // limb 7 keeps the rest (the value is below 2^240)
+    o1.l[i - 8] = i < 15 ? ((uint32_t)t1 & FR_M30) : (uint32_t)t1;
+    t0 >>= 30;
+    t1 >>= 30;
+  }
+  r0 = o0;
+  r1 = o1;
+}
+DVP_HD Fr30 fr30_zero() {
+  Fr30 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z.l[i] = 0;
+  return z;
+}
+// one product (the chain is serial: on the device every explicit multiply-add is then followed by a wait state; the kernels pair
+// their products through fr30_muladd_x2 wherever two are independent)
+DVP_HD Fr30 fr30_muladd(const Fr30& a, const Fr30& b, const Fr30& c) {
+  constexpr uint32_t p[8] = DVP_FR_P30_LIMBS;
+  uint32_t m[8];
+  Fr30 o;
+  uint64_t t = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) t = fr_mad64(a.l[j], b.l[i - j], t);
+#pragma unroll
+    for (int j = 0; j < i; ++j)
+      if (p[i - j] != 0) t = fr_mad64(m[j], p[i - j], t);
+    m[i] = ((uint32_t)t * FR_N0_30) & FR_M30;
+    t = fr_mad64(m[i], p[0], t);
+    t >>= 30;
+  }
+#pragma unroll
+  for (int i = 8; i < 16; ++i) {
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j) t = fr_mad64(a.l[j], b.l[i - j], t);
+#pragma unroll
+    for (int j = i - 7; j < 8; ++j)
+      if (p[i - j] != 0) t = fr_mad64(m[j], p[i - j], t);
+    t += c.l[i - 8];
+    o.l[i - 8] = i < 15 ? ((uint32_t)t & FR_M30) : (uint32_t)t;
+    t >>= 30;
+  }
+  return o;
+}
+// a lazy value below 2p (what the output twist leaves) -> canonical Fr
+DVP_HD Fr fr30_canon(const Fr30& a) { return fr_cond_sub_p(fr30_to_fr(a)); }
 
 DVP_HD Fr fr_sqr(const Fr& a) { return fr_mul(a, a); }
 DVP_HD Fr fr_to_mont(const Fr& a) { return fr_mul(a, fr_r2()); }
