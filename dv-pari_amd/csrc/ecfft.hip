@@ -352,6 +352,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 // total < 0.25 MB per tree and are served from L2.  `data` is the concatenation of the batch vectors.
 constexpr int FUSE_LOG = 11;
 constexpr uint32_t FUSE_ELEMS = 1u << FUSE_LOG;
+#ifndef DVP_FUSE_TPB
+#define DVP_FUSE_TPB 512
+#endif
+constexpr int FUSE_TPB = DVP_FUSE_TPB;  // 64 KB of LDS per workgroup: two workgroups per CU, FUSE_TPB / 128 waves per SIMD
 
 template <bool DEC>
 __device__ __forceinline__ void lds_bfly(Fr30* x, const Fr30* __restrict__ tws, int lh, uint32_t pairs) {
@@ -381,7 +385,7 @@ __device__ __forceinline__ void lds_bfly4(Fr30* x, const Fr30* __restrict__ tw_w
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(FUSE_TPB) __attribute__((amdgpu_waves_per_eu(FUSE_TPB / 128, FUSE_TPB / 128)))
 k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr30* __restrict__ dec,
                const Fr30* __restrict__ rec, uint32_t n, int ln, int lb, size_t total, const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
   __shared__ Fr30 x[FUSE_ELEMS];
@@ -580,7 +584,7 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   }
   {
     size_t total = (size_t)batch * n;
-    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(256), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total, pre_of(),
+    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(FUSE_TPB), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total, pre_of(),
                        top == 0 ? ms->wout : nullptr);
     src = data;
   }

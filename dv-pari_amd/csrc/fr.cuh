@@ -266,8 +266,17 @@ __device__ __forceinline__ uint64_t fr_mad64(uint32_t a, uint32_t b, uint64_t c)
   asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
   return d;
 }
+// one multiply-add of each of two independent chains in ONE asm statement (the compiler puts a wait state after every asm
+// statement that writes a VGPR, whatever follows it)
+__device__ __forceinline__ void fr_mad64_2(uint32_t a0, uint32_t b0, uint64_t& t0, uint32_t a1, uint32_t b1, uint64_t& t1) {
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1" : "+v"(t0), "+v"(t1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+}
 #else
 DVP_HD uint64_t fr_mad64(uint32_t a, uint32_t b, uint64_t c) { return c + (uint64_t)a * b; }
+DVP_HD void fr_mad64_2(uint32_t a0, uint32_t b0, uint64_t& t0, uint32_t a1, uint32_t b1, uint64_t& t1) {
+  t0 += (uint64_t)a0 * b0;
+  t1 += (uint64_t)a1 * b1;
+}
 #endif
 
 DVP_HD Fr fr_muladd29(const Fr29& a, const Fr29& b, const Fr29& c) {
@@ -386,36 +395,23 @@ DVP_HD void fr30_muladd_x2(const Fr30& a0, const Fr30& b0, const Fr30& c0, const
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) {
-      t0 = fr_mad64(a0.l[j], b0.l[i - j], t0);
-      t1 = fr_mad64(a1.l[j], b1.l[i - j], t1);
-    }
+    for (int j = 0; j <= i; ++j) fr_mad64_2(a0.l[j], b0.l[i - j], t0, a1.l[j], b1.l[i - j], t1);
 #pragma unroll
     for (int j = 0; j < i; ++j)
-      if (p[i - j] != 0) {
-        t0 = fr_mad64(m0[j], p[i - j], t0);
-        t1 = fr_mad64(m1[j], p[i - j], t1);
-      }
+      if (p[i - j] != 0) fr_mad64_2(m0[j], p[i - j], t0, m1[j], p[i - j], t1);
     m0[i] = ((uint32_t)t0 * FR_N0_30) & FR_M30;
     m1[i] = ((uint32_t)t1 * FR_N0_30) & FR_M30;
-    t0 = fr_mad64(m0[i], p[0], t0);
-    t1 = fr_mad64(m1[i], p[0], t1);
+    fr_mad64_2(m0[i], p[0], t0, m1[i], p[0], t1);
     t0 >>= 30;
     t1 >>= 30;
   }
 #pragma unroll
   for (int i = 8; i < 16; ++i) {
 #pragma unroll
-    for (int j = i - 7; j < 8; ++j) {
-      t0 = fr_mad64(a0.l[j], b0.l[i - j], t0);
-      t1 = fr_mad64(a1.l[j], b1.l[i - j], t1);
-    }
+    for (int j = i - 7; j < 8; ++j) fr_mad64_2(a0.l[j], b0.l[i - j], t0, a1.l[j], b1.l[i - j], t1);
 #pragma unroll
     for (int j = i - 7; j < 8; ++j)
-      if (p[i - j] != 0) {
-        t0 = fr_mad64(m0[j], p[i - j], t0);
-        t1 = fr_mad64(m1[j], p[i - j], t1);
-      }
+      if (p[i - j] != 0) fr_mad64_2(m0[j], p[i - j], t0, m1[j], p[i - j], t1);
     t0 += c0.l[i - 8];
     t1 += c1.l[i - 8];
     o0.l[i - 8] = i < 15 ? ((uint32_t)t0 & FR_M30) : (uint32_t)t0;  // limb 7 keeps the rest (the value is below 2^240)
