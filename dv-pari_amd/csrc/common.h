@@ -77,7 +77,7 @@ struct Tune {
   long long msm_aff_tpb = 256;  // DVP_MSM_AFF_TPB: workgroup size of the pair rounds (64, 128 or 256)
   long long msm_aff_bmin = 8;   // DVP_MSM_AFF_BMIN: fewest slots a round thread owns (small rounds then use fewer threads, each sharing its inversion among more additions)
   long long msm_aff_bmax = 48;  // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns
-  long long ecfft_radix4 = 1;   // DVP_ECFFT_RADIX4: the unfused top layers of an extend run two per pass (k_butterfly4); 0 = one per pass
+  long long ecfft_radix4 = 2;   // DVP_ECFFT_RADIX4: layers per pass of the unfused top of an extend: 2 = three (k_butterfly8, then k_butterfly4 / k_butterfly for what is left), 1 = two, 0 = one
   long long msm_accum_quad_max = 0;    // DVP_MSM_ACCUM_QUAD_MAX: reducer launches with at most this many tasks (upper bound) use a quad of lanes per task (0 = default)
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables

@@ -345,6 +345,73 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
   }
 }
 
+// THREE layers in one pass (radix 8) for the top of long vectors: with the lazy multiplier a two-layer pass is HBM-bound (192 MB of
+// data + up to 48 MB of constants in ~52 us at m = 2^20, batch 3), so a third layer per round trip is nearly free.  A thread owns the
+// eight values i0 + {0, h3, h2, h2 + h3, h1, h1 + h3, h1 + h2, h1 + h2 + h3} (h1 = 2 h2 = 4 h3 = the widest pair distance); constants:
+// four pairs of layer d (j, j + h3, j + h2, j + h2 + h3), two of layer d + 1 (j, j + h3), one of layer d + 2 (j).
+#ifndef DVP_BF8_WAVES
+#define DVP_BF8_WAVES 3
+#endif
+template <int BATCH, bool DEC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DVP_BF8_WAVES, DVP_BF8_WAVES))) k_butterfly8(const Fr* src, Fr* data, const Fr30* __restrict__ tw0, const Fr30* __restrict__ tw1,
+                                                    const Fr30* __restrict__ tw2, int lh3, uint32_t n, const Fr30* __restrict__ pre,
+                                                    const Fr30* __restrict__ post, uint32_t nv) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tid = gid / BATCH, bv = gid - tid * BATCH;
+  if (tid >= (n >> 3)) return;
+  const uint32_t h3 = 1u << lh3, h2 = h3 << 1, h1 = h3 << 2;
+  const uint32_t j = tid & (h3 - 1);
+  const uint32_t i0 = ((tid >> lh3) << (lh3 + 3)) | j;
+  Fr* v = data + (size_t)bv * n + i0;
+  const Fr* u = src + (size_t)bv * n + i0;
+  const uint32_t p0 = i0 & (nv - 1);
+  Fr30 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const uint32_t o0 = (k & 4 ? h1 : 0) + (k & 2 ? h2 : 0), o1 = o0 + h3;
+    if (pre) tw_in2(pre, p0 + o0, p0 + o1, u[o0], u[o1], x[k], x[k + 1]);
+    else { x[k] = ld30(u + o0); x[k + 1] = ld30(u + o1); }
+  }
+  if (DEC) {
+    bf_dec2(x[0], x[4], tw_load(tw0, j), x[1], x[5], tw_load(tw0, j + h3));
+    bf_dec2(x[2], x[6], tw_load(tw0, j + h2), x[3], x[7], tw_load(tw0, j + h2 + h3));
+    {
+      const Tw a = tw_load(tw1, j), b = tw_load(tw1, j + h3);
+      bf_dec2(x[0], x[2], a, x[1], x[3], b);
+      bf_dec2(x[4], x[6], a, x[5], x[7], b);
+    }
+    const Tw c = tw_load(tw2, j);
+    bf_dec2(x[0], x[1], c, x[2], x[3], c);
+    bf_dec2(x[4], x[5], c, x[6], x[7], c);
+  } else {
+    {
+      const Tw c = tw_load(tw2, j);
+      bf_rec(x[0], x[1], c); bf_rec(x[2], x[3], c); bf_rec(x[4], x[5], c); bf_rec(x[6], x[7], c);
+    }
+    {
+      const Tw a = tw_load(tw1, j), b = tw_load(tw1, j + h3);
+      bf_rec(x[0], x[2], a); bf_rec(x[1], x[3], b); bf_rec(x[4], x[6], a); bf_rec(x[5], x[7], b);
+    }
+    bf_rec(x[0], x[4], tw_load(tw0, j));
+    bf_rec(x[1], x[5], tw_load(tw0, j + h3));
+    bf_rec(x[2], x[6], tw_load(tw0, j + h2));
+    bf_rec(x[3], x[7], tw_load(tw0, j + h2 + h3));
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k += 2) {
+    const uint32_t o0 = (k & 4 ? h1 : 0) + (k & 2 ? h2 : 0), o1 = o0 + h3;
+    if (post) {
+      Fr r0, r1;
+      tw_out2(post, p0 + o0, p0 + o1, x[k], x[k + 1], r0, r1);
+      v[o0] = r0;
+      v[o1] = r1;
+    } else {
+      st30(v + o0, x[k]);
+      st30(v + o1, x[k + 1]);
+    }
+  }
+}
+
 // Fused bottom of an extend: the last `lb` decompose layers and the first `lb` recombine layers only mix
 // elements inside aligned blocks of 2^lb <= 2048 values, so a workgroup keeps 2048 consecutive values
 // (64 KB) in LDS and runs all 2*lb butterfly layers on them in ONE launch and ONE HBM round trip (the
@@ -573,14 +640,40 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
 #undef DVP_BF4
     src = data;
   };
+  // three layers per pass (k_butterfly8): layers d (widest), d + 1, d + 2
+  auto pass8 = [&](const Fr30* base, int d, bool dec, bool last) {
+    const Fr30* t0 = base + 2 * (size_t)(n - (n >> d));
+    const Fr30* t1 = base + 2 * (size_t)(n - (n >> (d + 1)));
+    const Fr30* t2 = base + 2 * (size_t)(n - (n >> (d + 2)));
+    const int lh3 = ln - d - 3;
+    const Fr30* pre = pre_of();
+    const Fr30* post = last ? ms->wout : nullptr;
+    const dim3 g(cdiv((size_t)(n >> 3) * batch, TPB)), b(TPB);
+    const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
+    const dim3 g1(cdiv(nn >> 3, TPB));
+#define DVP_BF8(B, GRID) \
+  do { if (dec) hipLaunchKernelGGL((k_butterfly8<B, true>), GRID, b, 0, st, src, data, t0, t1, t2, lh3, nn, pre, post, n); \
+       else hipLaunchKernelGGL((k_butterfly8<B, false>), GRID, b, 0, st, src, data, t0, t1, t2, lh3, nn, pre, post, n); } while (0)
+    if (batch == 4) DVP_BF8(4, g); else if (batch == 3) DVP_BF8(3, g); else if (batch == 2) DVP_BF8(2, g); else DVP_BF8(1, g1);
+#undef DVP_BF8
+    src = data;
+  };
   const int lb = ln < FUSE_LOG ? ln : FUSE_LOG;  // layers handled inside LDS
   const int top = ln - lb;
-  const bool radix4 = tune().ecfft_radix4 != 0;
+  // the top layers in groups of 3 (radix 8), then one group of 2 or 1; the recombine direction mirrors the decompose's grouping
+  const int radix = (int)tune().ecfft_radix4;  // 0: one layer per pass, 1: two, 2 (default): three
+  std::vector<int> groups;
+  for (int left = top; left > 0;) {
+    const int g = radix >= 2 && left >= 3 ? 3 : (radix >= 1 && left >= 2 ? 2 : 1);
+    groups.push_back(g);
+    left -= g;
+  }
   {
     int d = 0;
-    if (radix4)
-      for (; d + 1 < top; d += 2) pass4(ms->dec, d, true, false);
-    for (; d < top; ++d) pass(ms->dec, d, true, false);
+    for (int g : groups) {
+      if (g == 3) pass8(ms->dec, d, true, false); else if (g == 2) pass4(ms->dec, d, true, false); else pass(ms->dec, d, true, false);
+      d += g;
+    }
   }
   {
     size_t total = (size_t)batch * n;
@@ -589,11 +682,12 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
     src = data;
   }
   {
-    int d = top - 1;
-    if (radix4 && (top & 1)) { pass(ms->rec, d, false, d == 0); --d; }  // the odd layer is the innermost one, as in the decompose
-    if (radix4)
-      for (; d >= 1; d -= 2) pass4(ms->rec, d - 1, false, d - 1 == 0);
-    for (; d >= 0; --d) pass(ms->rec, d, false, d == 0);
+    int d = top;
+    for (size_t k = groups.size(); k-- > 0;) {
+      const int g = groups[k];
+      d -= g;
+      if (g == 3) pass8(ms->rec, d, false, d == 0); else if (g == 2) pass4(ms->rec, d, false, d == 0); else pass(ms->rec, d, false, d == 0);
+    }
   }
   DVP_HIP(hipGetLastError());
   return DVP_OK;
