@@ -33,6 +33,7 @@
 #include "common.h"
 #include "k233.cuh"
 #include "tau.cuh"
+#include "codec.cuh"
 
 namespace dvp {
 
@@ -1093,8 +1094,11 @@ __global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uin
 // the levels of one 256-thread block (64 quads, one addition per quad and pass).  buf: 2 * cnt Ld of scratch.
 // n_narrow == -3: signed aligned windows over the binary digits (the default fixed-base flavour, W = 1): key = |digit|, so the
 // result is sum_t 2^t A[1 + t], t < c - 1, plus 2^(c-1) x bucket 0 (doublings instead of Frobenius powers).
+// out_enc (optional): the result's 30-byte encoding under `rule` as well (what k_encode_point would make of out_xy): the affine
+// conversion and the encoding's 1 / x share ONE inversion, 1 / (X Z) -- a proof's two commitments are encoded right here instead
+// of after a host round trip, a launch and a second 45 us inversion chain.
 __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
-                                                 uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf) {
+                                                 uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf, uint8_t* __restrict__ out_enc, int rule) {
   extern __shared__ char lds_raw[];
   GfLdsQ L = gf_ldsq_init(lds_raw);
   const uint32_t cnt0 = (uint32_t)(W * c);
@@ -1141,10 +1145,27 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   const bool fin = !ld_is_inf(p);
   a.x = gf_zero();
   a.y = gf_zero();
+  Gf w = gf_zero();
   if (fin) {
-    Gf zi = gf_inv_fast(p.Z, T, L);
-    a.x = gf_mul(p.X, zi, L);
-    a.y = gf_mul(p.Y, gf_sqr(zi), L);
+    if (out_enc && !gf_is_zero(p.X)) {
+      // x = X / Z, y = Y / Z^2, y / x = Y / (X Z): everything from inv = 1 / (X Z)
+      const Gf inv = gf_inv_fast(gf_mul(p.X, p.Z, L), T, L);
+      const Gf zi = gf_mul(inv, p.X, L);
+      a.x = gf_mul(p.X, zi, L);
+      a.y = gf_mul(p.Y, gf_sqr(zi), L);
+      const Gf lam1 = gf_add(gf_add(a.x, gf_mul(p.Y, inv, L)), gf_one());
+      w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
+      if (rule) w = codec_present(w, rule, T);
+    } else {
+      Gf zi = gf_inv_fast(p.Z, T, L);
+      a.x = gf_mul(p.X, zi, L);
+      a.y = gf_mul(p.Y, gf_sqr(zi), L);
+      if (out_enc) {  // x = 0 (the point of order two): the same formula as k_encode_point, where 1 / 0 reads 0
+        const Gf lam1 = gf_add(gf_add(a.x, gf_mul(a.y, gf_inv_fast(a.x, T, L), L)), gf_one());
+        w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
+        if (rule) w = codec_present(w, rule, T);
+      }
+    }
   }
   if (threadIdx.x != 0) return;
 #pragma unroll
@@ -1153,6 +1174,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
     out_xy[8 + k] = a.y.w[k];
   }
   *out_inf = fin ? 0u : 1u;
+  if (out_enc) store30(out_enc, w, rule);
 }
 
 // sum of n affine points (the partial MSM results of n GPUs or ranks) -> affine: one quad of lanes, n - 1 mixed
@@ -1365,9 +1387,10 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 // fx == nullptr: one-shot MSM over (d_scalars, d_bases).  fx != nullptr: fixed-base mode, the scalars
 // d_scalars[0..n) belong to bases i0 .. i0+n of the pre-rotated table and d_inf is already offset by i0.
 static int msm_core(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, const MsmFixedCtx* fx, uint32_t i0,
-                    void* d_out_xy, void* d_out_inf, hipStream_t st) {
+                    void* d_out_xy, void* d_out_inf, hipStream_t st, void* d_out_enc = nullptr /* + the result's 30-byte encoding */) {
   if (n == 0) {
     DVP_HIP(hipMemsetAsync(d_out_xy, 0, 64, st));
+    if (d_out_enc) DVP_HIP(hipMemsetAsync(d_out_enc, 0, 30, st));
     uint32_t one = 1;
     DVP_HIP(hipMemcpyAsync(d_out_inf, &one, 4, hipMemcpyHostToDevice, st));
     DVP_HIP(hipStreamSynchronize(st));
@@ -1705,7 +1728,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
   (void)cntT;
   hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
-                     (uint32_t*)d_out_inf);
+                     (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0);
   ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
@@ -1839,6 +1862,16 @@ int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf
                   void* d_out_inf, hipStream_t st) {
   if (!c || lo > hi || hi > c->n_total) return DVP_EINVAL;
   return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st);
+}
+// the same with the result's 30-byte encoding written to d_out_enc by the tail kernel itself
+int msm_fixed_dev_enc(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
+                      void* d_out_inf, void* d_out_enc, hipStream_t st) {
+  if (!c || lo > hi || hi > c->n_total) return DVP_EINVAL;
+  return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st, d_out_enc);
+}
+int msm_affine_dev_enc(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf,
+                       void* d_out_enc, hipStream_t st) {
+  return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st, d_out_enc);
 }
 
 }  // namespace dvp

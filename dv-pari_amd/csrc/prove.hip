@@ -48,6 +48,10 @@ void msm_fixed_destroy(MsmFixedCtx* c);
 int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* signed_flavour);
 const void* msm_fixed_table_ptr(const MsmFixedCtx* c);
+int msm_fixed_dev_enc(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
+                      void* d_out_inf, void* d_out_enc, hipStream_t st);
+int msm_affine_dev_enc(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf,
+                       void* d_out_enc, hipStream_t st);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
 
@@ -393,6 +397,7 @@ struct dvp_prover {
   uint32_t* pts_inf32 = nullptr;
   uint8_t* pts_inf8 = nullptr;
   uint8_t* enc = nullptr;               // 60 bytes
+  bool enc_fused[2] = {false, false};   // enc + 30 * which already holds the encoding of pts[which] (written by the MSM's own tail kernel)
   Fr ctop_host[2];                      // layer log_m leaves (collapse points of D, D'), Montgomery
   // last-proof intermediates kept for parity tests
   Fr alpha_canon, abir0_host[4];
@@ -775,7 +780,8 @@ extern "C" int dvp_prove_quotient(dvp_prover* p, void* stream) {
 // which = 0: <[w | q2], [g_m | g_q]> (n_wires + m terms; commit_p = msm_q + msm_gm, src/proving.rs:463,512,515)
 // which = 1: <[k_a | k_b | k_r], [g_k_0 | g_k_1 | g_k_2]> (4m terms, src/proving.rs:666-680)
 // restricted to the index range [lo, hi): the per-GPU shard of the sum.
-extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
+// d_out_enc (optional): the MSM's tail kernel also writes the 30-byte encoding of its result there
+static int prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* d_out_enc, void* stream) {
   if (!p || (which != 0 && which != 1) || !d_out_xy || !d_out_inf) return DVP_EINVAL;
   size_t total = which ? 4 * (size_t)p->m : (size_t)p->n_wires + p->m;
   if (lo > hi || hi > total) return DVP_EINVAL;
@@ -800,9 +806,13 @@ extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_
       p->fx_hi[which] = hi;
     }
     const size_t o = p->fx_lo[which];
-    return msm_fixed_dev(p->fx[which], sc + lo, inf + lo, (uint32_t)(lo - o), (uint32_t)(hi - o), d_out_xy, d_out_inf, (hipStream_t)stream);
+    return msm_fixed_dev_enc(p->fx[which], sc + lo, inf + lo, (uint32_t)(lo - o), (uint32_t)(hi - o), d_out_xy, d_out_inf, d_out_enc, (hipStream_t)stream);
   }
-  return msm_affine_dev(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, (hipStream_t)stream);
+  return msm_affine_dev_enc(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, d_out_enc, (hipStream_t)stream);
+}
+extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
+  if (p && (which == 0 || which == 1) && d_out_xy == (void*)(p->pts + which)) p->enc_fused[which] = false;  // the point changes, its encoding does not follow
+  return prover_msm_partial(p, which, lo, hi, d_out_xy, d_out_inf, nullptr, stream);
 }
 
 // ---- in-library multi-GPU (dvp_set_devices) ------------------------------------------------------------------------
@@ -942,10 +952,17 @@ static int prove_msm(dvp_prover* p, int which, void* d_out_xy, void* d_out_inf, 
   const std::vector<int> devs = mgpu_devices();
   if (devs.size() > 1) {
     if (devs != p->shard_devices) DVP_TRY(shards_build(p, devs));
+    p->enc_fused[which] = false;
     return mgpu_msm(p, which, d_out_xy, d_out_inf, (hipStream_t)stream);
   }
   if (!p->shards.empty()) shards_release(p);
-  return dvp_prover_msm_partial(p, which, 0, dvp_prover_msm_size(p, which), d_out_xy, d_out_inf, stream);
+  // the whole sum on this device, into the prover's own slot: let the tail kernel encode it too (dvp_prove_challenge / _finish then
+  // skip their k_encode_point: one launch, one host round trip and one inversion chain less per commitment)
+  const bool own = d_out_xy == (void*)(p->pts + which) && d_out_inf == (void*)(p->pts_inf32 + which);
+  p->enc_fused[which] = false;
+  DVP_TRY(prover_msm_partial(p, which, 0, dvp_prover_msm_size(p, which), d_out_xy, d_out_inf, own ? p->enc + 30 * which : nullptr, stream));
+  p->enc_fused[which] = own;
+  return DVP_OK;
 }
 // window size / window count the fixed-base context of MSM `which` settled on (0,0 before its first use)
 extern "C" int dvp_prover_msm_plan(const dvp_prover* p, int which, int* c_bits, int* windows) {
@@ -988,7 +1005,8 @@ extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const
   dim3 gm(cdiv(m, PT)), bt(PT);
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
-  DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  if (!(d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0])) DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  p->enc_fused[0] = false;
   DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
   uint8_t ch[32];
@@ -1025,7 +1043,8 @@ extern "C" int dvp_prove_challenge_partial(dvp_prover* p, const void* d_commit_x
   dim3 bt(PT);
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
-  DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  if (!(d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0])) DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  p->enc_fused[0] = false;
   DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
   uint8_t ch[32];
@@ -1094,7 +1113,8 @@ extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void*
   hipStream_t st = (hipStream_t)stream;
   if (d_kzg_xy != p->pts + 1) DVP_HIP(hipMemcpyAsync(p->pts + 1, d_kzg_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_kzg_inf != p->pts_inf32 + 1) DVP_HIP(hipMemcpyAsync(p->pts_inf32 + 1, d_kzg_inf, 4, hipMemcpyDeviceToDevice, st));
-  DVP_TRY(encode_point_dev(p->pts + 1, p->pts_inf32 + 1, p->enc + 30, st));
+  if (!(d_kzg_xy == p->pts + 1 && d_kzg_inf == p->pts_inf32 + 1 && p->enc_fused[1])) DVP_TRY(encode_point_dev(p->pts + 1, p->pts_inf32 + 1, p->enc + 30, st));
+  p->enc_fused[1] = false;
   DVP_HIP(hipMemcpyAsync(p->fin_host, p->abir0, FIN_BYTES, hipMemcpyDeviceToHost, st));  // pinned: one DMA, no staging
   DVP_HIP(hipStreamSynchronize(st));
   unsigned long long f[2];
