@@ -1387,10 +1387,13 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 // fx == nullptr: one-shot MSM over (d_scalars, d_bases).  fx != nullptr: fixed-base mode, the scalars
 // d_scalars[0..n) belong to bases i0 .. i0+n of the pre-rotated table and d_inf is already offset by i0.
 static int msm_core(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, const MsmFixedCtx* fx, uint32_t i0,
-                    void* d_out_xy, void* d_out_inf, hipStream_t st, void* d_out_enc = nullptr /* + the result's 30-byte encoding */) {
+                    void* d_out_xy, void* d_out_inf, hipStream_t st, void* d_out_enc = nullptr /* + the result's 30-byte encoding */,
+                    void* h_copy = nullptr, const void* d_copy = nullptr, size_t copy_bytes = 0 /* a device block the caller wants on the
+                    host (pinned) when this call returns: it rides on the MSM's own final synchronisation */) {
   if (n == 0) {
     DVP_HIP(hipMemsetAsync(d_out_xy, 0, 64, st));
     if (d_out_enc) DVP_HIP(hipMemsetAsync(d_out_enc, 0, 30, st));
+    if (h_copy) DVP_HIP(hipMemcpyAsync(h_copy, d_copy, copy_bytes, hipMemcpyDeviceToHost, st));
     uint32_t one = 1;
     DVP_HIP(hipMemcpyAsync(d_out_inf, &one, 4, hipMemcpyHostToDevice, st));
     DVP_HIP(hipStreamSynchronize(st));
@@ -1734,6 +1737,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipGetLastError());
   // the scalar-range flag is the only thing that needs the host
   unsigned long long e;
+  if (h_copy) DVP_HIP(hipMemcpyAsync(h_copy, d_copy, copy_bytes, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemcpyAsync(&e, err, 8, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
   if (e != ~0ull) {
@@ -1864,14 +1868,15 @@ int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf
   return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st);
 }
 // the same with the result's 30-byte encoding written to d_out_enc by the tail kernel itself
+// (h_copy, d_copy, copy_bytes): a device block copied to pinned host memory before the call's own final synchronisation
 int msm_fixed_dev_enc(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
-                      void* d_out_inf, void* d_out_enc, hipStream_t st) {
+                      void* d_out_inf, void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st) {
   if (!c || lo > hi || hi > c->n_total) return DVP_EINVAL;
-  return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st, d_out_enc);
+  return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st, d_out_enc, h_copy, d_copy, copy_bytes);
 }
 int msm_affine_dev_enc(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf,
-                       void* d_out_enc, hipStream_t st) {
-  return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st, d_out_enc);
+                       void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st) {
+  return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st, d_out_enc, h_copy, d_copy, copy_bytes);
 }
 
 }  // namespace dvp

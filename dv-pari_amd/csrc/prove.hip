@@ -49,9 +49,9 @@ int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* signed_flavour);
 const void* msm_fixed_table_ptr(const MsmFixedCtx* c);
 int msm_fixed_dev_enc(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
-                      void* d_out_inf, void* d_out_enc, hipStream_t st);
+                      void* d_out_inf, void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st);
 int msm_affine_dev_enc(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf,
-                       void* d_out_enc, hipStream_t st);
+                       void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
 
@@ -398,6 +398,7 @@ struct dvp_prover {
   uint8_t* pts_inf8 = nullptr;
   uint8_t* enc = nullptr;               // 60 bytes
   bool enc_fused[2] = {false, false};   // enc + 30 * which already holds the encoding of pts[which] (written by the MSM's own tail kernel)
+                                        // AND fin_host mirrors [abir0 | flags | enc] as of that MSM's end (copied before its final sync)
   Fr ctop_host[2];                      // layer log_m leaves (collapse points of D, D'), Montgomery
   // last-proof intermediates kept for parity tests
   Fr alpha_canon, abir0_host[4];
@@ -806,9 +807,11 @@ static int prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, vo
       p->fx_hi[which] = hi;
     }
     const size_t o = p->fx_lo[which];
-    return msm_fixed_dev_enc(p->fx[which], sc + lo, inf + lo, (uint32_t)(lo - o), (uint32_t)(hi - o), d_out_xy, d_out_inf, d_out_enc, (hipStream_t)stream);
+    return msm_fixed_dev_enc(p->fx[which], sc + lo, inf + lo, (uint32_t)(lo - o), (uint32_t)(hi - o), d_out_xy, d_out_inf, d_out_enc,
+                             d_out_enc ? p->fin_host : nullptr, p->abir0, FIN_BYTES, (hipStream_t)stream);
   }
-  return msm_affine_dev_enc(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, d_out_enc, (hipStream_t)stream);
+  return msm_affine_dev_enc(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, d_out_enc, d_out_enc ? p->fin_host : nullptr, p->abir0, FIN_BYTES,
+                            (hipStream_t)stream);
 }
 extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
   if (p && (which == 0 || which == 1) && d_out_xy == (void*)(p->pts + which)) p->enc_fused[which] = false;  // the point changes, its encoding does not follow
@@ -1005,10 +1008,14 @@ extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const
   dim3 gm(cdiv(m, PT)), bt(PT);
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
-  if (!(d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0])) DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  if (d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0]) {
+    memcpy(p->commit_p_host, p->fin_host + 4 * sizeof(Fr) + 16, 30);  // encoded by the MSM's tail, on the host since the MSM's own sync
+  } else {
+    DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+    DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+  }
   p->enc_fused[0] = false;
-  DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipStreamSynchronize(st));
   uint8_t ch[32];
   transcript_challenge(p->commit_p_host, p->pub_host.data(), p->n_pub, ch);
   Fr alpha;
@@ -1043,10 +1050,14 @@ extern "C" int dvp_prove_challenge_partial(dvp_prover* p, const void* d_commit_x
   dim3 bt(PT);
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
-  if (!(d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0])) DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+  if (d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0]) {
+    memcpy(p->commit_p_host, p->fin_host + 4 * sizeof(Fr) + 16, 30);  // encoded by the MSM's tail, on the host since the MSM's own sync
+  } else {
+    DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
+    DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
+    DVP_HIP(hipStreamSynchronize(st));
+  }
   p->enc_fused[0] = false;
-  DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipStreamSynchronize(st));
   uint8_t ch[32];
   transcript_challenge(p->commit_p_host, p->pub_host.data(), p->n_pub, ch);
   Fr alpha;
@@ -1113,10 +1124,12 @@ extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void*
   hipStream_t st = (hipStream_t)stream;
   if (d_kzg_xy != p->pts + 1) DVP_HIP(hipMemcpyAsync(p->pts + 1, d_kzg_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_kzg_inf != p->pts_inf32 + 1) DVP_HIP(hipMemcpyAsync(p->pts_inf32 + 1, d_kzg_inf, 4, hipMemcpyDeviceToDevice, st));
-  if (!(d_kzg_xy == p->pts + 1 && d_kzg_inf == p->pts_inf32 + 1 && p->enc_fused[1])) DVP_TRY(encode_point_dev(p->pts + 1, p->pts_inf32 + 1, p->enc + 30, st));
+  if (!(d_kzg_xy == p->pts + 1 && d_kzg_inf == p->pts_inf32 + 1 && p->enc_fused[1])) {
+    DVP_TRY(encode_point_dev(p->pts + 1, p->pts_inf32 + 1, p->enc + 30, st));
+    DVP_HIP(hipMemcpyAsync(p->fin_host, p->abir0, FIN_BYTES, hipMemcpyDeviceToHost, st));  // pinned: one DMA, no staging
+    DVP_HIP(hipStreamSynchronize(st));
+  }  // else: the K MSM's tail encoded kzg_k and fin_host was filled before that MSM's final sync (a0 b0 i0 r0 and the flags were final by then)
   p->enc_fused[1] = false;
-  DVP_HIP(hipMemcpyAsync(p->fin_host, p->abir0, FIN_BYTES, hipMemcpyDeviceToHost, st));  // pinned: one DMA, no staging
-  DVP_HIP(hipStreamSynchronize(st));
   unsigned long long f[2];
   memcpy(p->abir0_host, p->fin_host, 4 * sizeof(Fr));
   memcpy(f, p->fin_host + 4 * sizeof(Fr), 16);
