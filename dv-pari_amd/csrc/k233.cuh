@@ -155,6 +155,41 @@ GF_DEV void ld_madd_ip(Ld& p, const Aff& q, const LT& L) {
   p.X = X3;
   p.Z = Z3;
 }
+// p + q from two AFFINE points, both finite and p.x != q.x (the caller sends everything else down ld_madd_ip): the mixed
+// addition with Z1 = 1, where three of its eight products are products by one -- 5M + 3S, and the same (X, Y, Z) as
+// ld_madd_ip(ld_from_aff(p), q) word for word.
+template <class LT>
+GF_DEV void ld_add_aff_aff(const Aff& p, const Aff& q, Ld& r, const LT& L) {
+  const Gf A = gf_add(p.y, q.y), B = gf_add(p.x, q.x);
+  const Gf Z3 = gf_sqr(B);
+  Gf D, E;
+  gf_mul2(Z3, A, B, L, D, E);  // B^3, A B
+  const Gf X3 = gf_add(gf_add(gf_sqr(A), D), E);
+  const Gf F = gf_add(X3, gf_mul(q.x, Z3, L));
+  const Gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(Z3), L);
+  r.Y = gf_add(gf_mul(gf_add(E, Z3), F, L), G);
+  r.X = X3;
+  r.Z = Z3;
+}
+// p + q for a FINITE p and a finite affine q with p != +-q: the body of ld_madd_ip without its exceptional branches (a kernel
+// that keeps them pays their registers on every lane).  Returns false -- p untouched -- when p == +-q.
+template <class LT>
+GF_DEV bool ld_madd_fast(Ld& p, const Aff& q, const LT& L) {
+  const Gf A = gf_add(p.Y, gf_mul(q.y, gf_sqr(p.Z), L));
+  const Gf B = gf_add(p.X, gf_mul(q.x, p.Z, L));
+  if (gf_is_zero(B)) return false;
+  const Gf C = gf_mul(B, p.Z, L);
+  Gf D, E;
+  gf_mul2(gf_sqr(B), A, C, L, D, E);
+  const Gf Z3 = gf_sqr(C);
+  const Gf X3 = gf_add(gf_add(gf_sqr(A), D), E);
+  const Gf F = gf_add(X3, gf_mul(q.x, Z3, L));
+  const Gf G = gf_mul(gf_add(q.x, q.y), gf_sqr(Z3), L);
+  p.Y = gf_add(gf_mul(gf_add(E, Z3), F, L), G);
+  p.X = X3;
+  p.Z = Z3;
+  return true;
+}
 template <class LT>
 GF_DEV Ld ld_madd(const Ld& p, const Aff& q, const LT& L) {
   Ld r = p;

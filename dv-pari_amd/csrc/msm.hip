@@ -730,6 +730,72 @@ k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const 
   }
 }
 
+// ---- what the pair rounds leave, one thread per BUCKET (fixed-base sizes: the rounds stop with 1-4 points per bucket) ----
+// k_accum_affine gives every chunk of K entries a task and runs it as a serial chain of general mixed additions at two waves
+// per SIMD (253 VGPRs: the exceptional branches of ld_madd_ip), behind a scan and a binary search per task and in front of a
+// gather into the bucket array.  With the signed windows the load is bimodal -- the narrow windows reach only the lower half of
+// the keys, which end the rounds with three points per bucket where the upper half has one -- so contiguous keys do the same
+// work and a thread per bucket diverges no more than a thread per task did.  Here: the first two entries are two AFFINE
+// points, so the mixed addition's Z1 = 1 and three of its eight products vanish (ld_add_aff_aff, 5M + 3S); further entries go
+// through the mixed addition stripped of its exceptional branches (ld_madd_fast), straight into the bucket array (two waves
+// per SIMD: 222 VGPRs; at three the loop spills 240 B per lane and the heavy half of the keys -- 1 024 workgroups -- is 1.33
+// chip-fulls instead of exactly two: measured equal).  A bucket that meets an exceptional pair (an infinity marker first, equal x) goes on a list that k_bucket_rest
+// redoes from its first entry with the general formulas.  No task scan, no search, no gather.
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_bucket_pairs(const Aff* __restrict__ pts, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t nkeys,
+               Ld* __restrict__ A, uint32_t* __restrict__ rest_n, uint32_t* __restrict__ rest) {
+  extern __shared__ char lds_raw[];
+  GfLdsK L = gf_ldsk_init(lds_raw);
+  const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= nkeys) return;
+  const uint32_t c = cnt[key];
+  if (c == 0) {
+    A[key] = ld_infinity();
+    return;
+  }
+  const uint32_t o = off[key];
+  const Aff p = pts[o];
+  if (c == 1) {
+    A[key] = gf_is_zero(p.x) ? ld_infinity() : ld_from_aff(p);  // x == 0 marks infinity
+    return;
+  }
+  Aff q = pts[o + 1];
+  bool ok = !(gf_is_zero(p.x) || gf_is_zero(q.x) || gf_eq(p.x, q.x));
+  Ld r;
+  if (ok) {
+    ld_add_aff_aff(p, q, r, L);
+#pragma unroll 1
+    for (uint32_t t = 2; t < c && ok; ++t) {
+      q = pts[o + t];
+      if (gf_is_zero(q.x)) continue;
+      ok = ld_madd_fast(r, q, L);
+    }
+  }
+  if (ok)
+    A[key] = r;
+  else
+    rest[atomicAdd(rest_n, 1u)] = key;
+}
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_bucket_rest(const Aff* __restrict__ pts, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+              const uint32_t* __restrict__ rest_n, const uint32_t* __restrict__ rest, Ld* __restrict__ A) {
+  extern __shared__ char lds_raw[];
+  GfLdsK L = gf_ldsk_init(lds_raw);
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= *rest_n) return;
+  const uint32_t key = rest[tid];
+  const uint32_t c = cnt[key], o = off[key];
+  const Aff first = pts[o];
+  Ld acc = gf_is_zero(first.x) ? ld_infinity() : ld_from_aff(first);
+#pragma unroll 1
+  for (uint32_t t = 1; t < c; ++t) {
+    const Aff q = pts[o + t];
+    if (gf_is_zero(q.x)) continue;
+    ld_madd_ip(acc, q, L);
+  }
+  A[key] = acc;
+}
+
 // ---- multi-squaring tables for the fast inversion (gf233.cuh) ----------------------------------------
 __global__ void __launch_bounds__(256)
 k_build_sqr_tables(Gf* __restrict__ t29, Gf* __restrict__ t58, Gf* __restrict__ t116, Gf* __restrict__ th) {
@@ -1428,7 +1494,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
                           (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false>, (const void*)k_merge<true>,
                           (const void*)k_affine_round<true, false>, (const void*)k_affine_round<false, false>, (const void*)k_affine_round<true, true>,
-                          (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail};
+                          (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail,
+                          (const void*)k_bucket_pairs, (const void*)k_bucket_rest};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
       DVP_HIP(attr_err);
@@ -1480,6 +1547,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_prefix = carve(affine_mode ? (affA_n + 256) * sizeof(Gf) : 16);  // one prefix product per output slot (+ the B - 1 <= 254 slots the last thread's rows may overhang)
   size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
+  size_t o_rest = carve(((size_t)p.nkeys + 1) * 4);  // k_bucket_pairs' list of buckets with more than two entries
   size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
   DVP_TRY(g_ws.ensure(o, g_ws_need[cur_dev]));
   char* base = (char*)g_ws.p;
@@ -1511,6 +1579,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   Gf* prefix = (Gf*)(base + o_prefix);
   uint2* gdesc = (uint2*)(base + o_gdesc);
   Ld* tail = (Ld*)(base + o_tail);
+  auto* rest_list = (uint32_t*)(base + o_rest);
   const uint32_t nk = p.nkeys;
 
   ProfScope ps_total(PROF_MSM_TOTAL, st);
@@ -1559,7 +1628,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   // ---- bucket accumulation: batched-affine pair rounds while a round still carries >= aff_min additions,
   // then the projective fan-in-K reducer on what is left (it has a short critical path and balances skew)
   uint32_t* d_max = (uint32_t*)(err + 1);
-  DVP_HIP(hipMemsetAsync(d_max, 0, 4, st));
+  uint32_t* rest_n = d_max + 1;  // entries of k_bucket_pairs' list
+  DVP_HIP(hipMemsetAsync(d_max, 0, 8, st));
   hipLaunchKernelGGL(k_max_u32, dim3(64), dim3(256), 0, st, cnt, nk, d_max);
   DVP_TRY(g_ws.ensure_aux());
   DVP_HIP(hipEventRecord(g_ws.ev, st));
@@ -1674,6 +1744,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       hipLaunchKernelGGL(k_bucket_gather_items, dim3(cdiv(nk, 256)), dim3(256), 0, st, bases0, items, cnt, off, nk, bkt, sign_mask);
     else
       hipLaunchKernelGGL(k_bucket_gather_aff, dim3(cdiv(nk, 256)), dim3(256), 0, st, pts_in, pc[cur], po[cur], nk, bkt);
+  } else if (ra > 0 && rem_max <= (uint64_t)(tn.msm_bucket_pairs_max >= 0 ? tn.msm_bucket_pairs_max : 0)) {
+    // a handful of points per bucket left: one thread per bucket; buckets that meet an exceptional pair are redone from a list
+    hipLaunchKernelGGL(k_bucket_pairs, dim3(cdiv(nk, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, pc[cur], po[cur], nk, bkt, rest_n, rest_list);
+    hipLaunchKernelGGL(k_bucket_rest, dim3(cdiv(nk, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, pc[cur], po[cur], rest_n, rest_list, bkt);
   } else {
     // level 1: mixed additions from affine inputs
     int nxt = (cur + 1) % 3;

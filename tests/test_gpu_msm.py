@@ -221,6 +221,39 @@ def test_msm_heavy_skew_2_18(dvp):
     assert np_to_pt(xy, is_inf) == co.k233_mulgen(np_dot_mod(s, k))
 
 
+def test_bucket_reduction_exceptional_pairs(dvp):
+    """what the pair rounds leave (k_bucket_pairs / k_bucket_rest): bases drawn from eight points and their negatives,
+    scalars from five values, so that the buckets the rounds hand over hold equal points (P + P), opposite points
+    (P - P) and the infinity markers earlier rounds made of them -- the pairs the fast formulas refuse and the list
+    redoes.  Fixed-base and one-shot, the rounds stopped at several depths, against the fan-in-K reducer route
+    (DVP_MSM_BUCKET_PAIRS_MAX=0) and the oracle."""
+    rnd = random.Random(777)
+    n = 4096
+    k8 = [rnd.randrange(1, o.P) for _ in range(8)]
+    p8 = [co.k233_mulgen(x) for x in k8]
+    vals = [rnd.randrange(o.P) for _ in range(4)] + [1]
+    pts, ks, sv = [], [], []
+    for i in range(n):
+        j, neg = rnd.randrange(8), rnd.random() < 0.5
+        pts.append(o.k233_neg(p8[j]) if neg else p8[j])
+        ks.append(o.P - k8[j] if neg else k8[j])
+        sv.append(rnd.choice(vals))
+    bases, s = pts_to_np(pts), to_limbs(sv)
+    exp = co.k233_mulgen(sum(a * b for a, b in zip(sv, ks)) % o.P)
+    lo, hi = 100, 3000
+    exp_part = co.k233_mulgen(sum(a * b for a, b in zip(sv[lo:hi], ks[lo:hi])) % o.P)
+    for c in (8, 11):
+        with dvp.tune(DVP_MSM_FIXED_C=c):
+            fb = dvp.curve.FixedBaseMsm(bases)
+        for aff_min in (32, 512, 4096):
+            for pairs_max in (0, 12, 100000):
+                with dvp.tune(DVP_MSM_AFF_MIN=aff_min, DVP_MSM_BUCKET_PAIRS_MAX=pairs_max, DVP_MSM_C=c):
+                    assert np_to_pt(*fb.run(s)) == exp, (c, aff_min, pairs_max)
+                    assert np_to_pt(*fb.run(s[lo:hi], lo, hi)) == exp_part, (c, aff_min, pairs_max)
+                    assert gpu_msm(dvp, s, bases) == exp, (c, aff_min, pairs_max)
+        fb.close()
+
+
 def test_points_add_like_curvepoint_add(dvp):
     """CurvePoint::add (src/curve.rs:84-90): generic, doubling, P + (-P), neutral on either side -- vs the oracle group law"""
     import pyref as o2
