@@ -686,7 +686,25 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
 // need_extend == 0: the caller's MSM shards lie inside [w] and [k_a | k_b] only, which need neither q2 nor r2, so the
 // three extends and the quotient are skipped (multi-GPU load balancing, distributed.py::shard_plan).  q2 / r2 and the
 // k_r part of the second MSM's scalars are then NOT valid on this prover until the next full begin.
+static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_extend, void* stream, bool defer_unsat);
 extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream) {
+  return prove_begin_impl(p, d_assignment, need_extend, stream, false);
+}
+// the host's look at the unsatisfied-row flag (assert_eq!(a*b, c+i), src/proving.rs:389-395)
+static int prove_check_unsat(dvp_prover* p, hipStream_t st) {
+  unsigned long long f0[2];
+  DVP_HIP(hipMemcpyAsync(f0, p->flags, 16, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  if (f0[0] != ~0ull) {
+    g_last_error_index = (int64_t)f0[0];
+    return DVP_EUNSAT;
+  }
+  return DVP_OK;
+}
+// defer_unsat (dvp_prove_dev only): the flag is NOT waited for here -- the commitment MSM does not need the host to know it, and its
+// own final synchronisation brings the flag block along (one host round trip less per proof; an unsatisfied witness then costs an
+// MSM before it is reported)
+static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_extend, void* stream, bool defer_unsat) {
   if (!p || !d_assignment || !prover_ready(p)) return DVP_EINVAL;
   p->last_begin_extended = false;  // set by dvp_prove_quotient once every extended vector is in place
   p->ext_filled = 0;
@@ -709,14 +727,8 @@ extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, 
     DVP_TRY(dvp_prove_extend_vectors(p, (1u << prover_n_ext(p)) - 1, stream));
     DVP_TRY(dvp_prove_quotient(p, stream));
   }
-  unsigned long long f0[2];
-  DVP_HIP(hipMemcpyAsync(f0, p->flags, 16, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipStreamSynchronize(st));
-  if (f0[0] != ~0ull) {
-    g_last_error_index = (int64_t)f0[0];
-    return DVP_EUNSAT;  // assert_eq!(a*b, c+i), src/proving.rs:389-395
-  }
-  return DVP_OK;
+  if (defer_unsat) return DVP_OK;
+  return prove_check_unsat(p, st);
 }
 
 // ---- the extends by VECTOR (option A) ------------------------------------------------------------------------
@@ -1150,8 +1162,21 @@ extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t pr
   if (!p || !d_assignment || !proof) return DVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(PROF_PROVE_TOTAL, st);
-  DVP_TRY(dvp_prove_begin(p, d_assignment, stream));
-  DVP_TRY(prove_msm(p, 0, p->pts, p->pts_inf32, stream));
+  DVP_TRY(prove_begin_impl(p, d_assignment, 1, stream, true));
+  {
+    const int rc = prove_msm(p, 0, p->pts, p->pts_inf32, stream);
+    if (rc == DVP_OK && p->enc_fused[0]) {  // fin_host = [a0 b0 i0 r0 | flags | encodings] as of the MSM's end
+      unsigned long long f0;
+      memcpy(&f0, p->fin_host + 4 * sizeof(Fr), 8);
+      if (f0 != ~0ull) {
+        g_last_error_index = (int64_t)f0;
+        return DVP_EUNSAT;
+      }
+    } else {  // sharded MSM (no block on the host), or an MSM error: the unsatisfied row is reported first, as before
+      DVP_TRY(prove_check_unsat(p, st));
+      DVP_TRY(rc);
+    }
+  }
   DVP_TRY(dvp_prove_challenge(p, p->pts, p->pts_inf32, stream));
   DVP_TRY(prove_msm(p, 1, p->pts + 1, p->pts_inf32 + 1, stream));
   ps.stop();
