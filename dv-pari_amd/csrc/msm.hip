@@ -101,20 +101,10 @@ k_recode(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, 
 // windows (key = |d_w|; |d_w| = 2^(c-1), probability 2^-c, shares key 0, whose bucket the tail weighs by 2^(c-1)), the sign
 // travels with the entry (FXW_NEG) and is applied when the point is loaded.  W = ceil(234 / c) windows take a canonical scalar
 // (< 2^232) including the last carry.  No tau-adic expansion: a few shifts per window.
-__global__ void __launch_bounds__(256)
-k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow,
-                uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t s[9];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
-  s[8] = 0;
-  bool skip = inf && inf[i];
-  if (!tau_scalar_is_canonical(s)) {
-    atomicMin(err, (unsigned long long)i);
-    skip = true;
-  }
+// the entry words of one scalar, window by window: f(w, word), word == 0 where the window contributes nothing.  Returns the last carry
+// (zero for a canonical scalar: the widths add up to >= 234).
+template <class F>
+__device__ __forceinline__ uint32_t fx_recode_signed_each(const uint32_t* s /* 9 words, s[8] = 0 */, int c, int W, int n_narrow, F&& f) {
   // the n_narrow LOW windows are c - 1 bits wide, the rest c (widths evened out so that the 234 bits fill every window: a short
   // top window would send every scalar into a handful of buckets)
   uint32_t carry = 0;
@@ -139,9 +129,32 @@ k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict_
     } else if (d) {
       word = FXW_VALID | ((uint32_t)w << FXW_ROW_SHIFT) | (d & ((1u << (c - 1)) - 1));  // a full-width d == 2^(c-1) -> key 0
     }
-    words[(size_t)w * n + i] = skip ? 0u : word;
+    f(w, word);
   }
-  if (carry && !skip) atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: the widths add up to >= 234
+  return carry;
+}
+// loads scalar i; false = it contributes no entries (neutral base, or not canonical -- `report` then records its index)
+__device__ __forceinline__ bool fx_load_scalar(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t i, uint32_t* s,
+                                               unsigned long long* __restrict__ err, bool report) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = scalars[(size_t)i * 8 + k];
+  s[8] = 0;
+  bool skip = inf && inf[i];
+  if (!tau_scalar_is_canonical(s)) {
+    if (report) atomicMin(err, (unsigned long long)i);
+    skip = true;
+  }
+  return !skip;
+}
+__global__ void __launch_bounds__(256)
+k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow,
+                uint32_t* __restrict__ words, unsigned long long* __restrict__ err) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[9];
+  const bool live = fx_load_scalar(scalars, inf, i, s, err, true);
+  const uint32_t carry = fx_recode_signed_each(s, c, W, n_narrow, [&](int w, uint32_t word) { words[(size_t)w * n + i] = live ? word : 0u; });
+  if (carry && live) atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen: the widths add up to >= 234
 }
 
 // ---- exclusive scan of u32 (3 kernels; up to 4096*1024 elements) ---------------------------------
@@ -538,6 +551,85 @@ k_part_scatter_staged(const uint32_t* __restrict__ digits, size_t total, uint32_
   }
   __syncthreads();
   const uint32_t mask = (1u << FX_LO) - 1;
+  for (uint32_t pos = t; pos < tot; pos += SORT_TPB) {
+    uint32_t d = st_d[pos], dst = gdst[d >> FX_LO] + pos;
+    plo[dst] = (uint16_t)(d & mask);
+    pid[dst] = st_id[pos];
+  }
+}
+
+// ---- level 1 of the signed flavour straight from the scalars (round 4) -------------------------------------------------------
+// k_recode_signed wrote W entry words per scalar (4 B each) that k_part_hist and the level-1 scatter then read back: 12 B of HBM
+// traffic per entry for a few shifts' worth of work.  Here a block owns S = FX_CHUNK / W consecutive SCALARS (all their windows:
+// <= FX_CHUNK entries) and both level-1 kernels recompute the words from the 32-byte scalar.  Which entries share a chunk changes,
+// the sorted order inside a bucket with it -- the bucket's SUM does not.
+__global__ void __launch_bounds__(SORT_TPB)
+k_part_hist_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow, uint32_t S,
+                   FxBits fb, uint32_t* __restrict__ phist, unsigned long long* __restrict__ err) {
+  __shared__ uint32_t h[FX_NP_MAX];
+  const uint32_t FX_NP = fb.np();
+  const int FX_LO = fb.lo;
+  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) h[k] = 0;
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * S, hi = min(n, lo + S);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += SORT_TPB) {
+    uint32_t s[9];
+    if (!fx_load_scalar(scalars, inf, i, s, err, true)) continue;
+    const uint32_t carry = fx_recode_signed_each(s, c, W, n_narrow, [&](int, uint32_t word) {
+      if (word) atomicAdd(&h[fxw_key(word) >> FX_LO], 1u);
+    });
+    if (carry) atomicMin(err, (unsigned long long)i | (1ull << 62));  // cannot happen
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) phist[(size_t)blockIdx.x * FX_NP + k] = h[k];
+}
+template <bool STAGED>
+__global__ void __launch_bounds__(SORT_TPB)
+k_part_scatter_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow, uint32_t S,
+                      uint32_t n_total, uint32_t i0, FxBits fb, const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pbase,
+                      const uint32_t* __restrict__ pstart, uint16_t* __restrict__ plo, uint32_t* __restrict__ pid) {
+  extern __shared__ uint32_t lds_st[];
+  uint32_t* cur = lds_st;             // [FX_NP_MAX]
+  uint32_t* gdst = cur + FX_NP_MAX;   // [FX_NP_MAX] STAGED: destination of staged position 0 of the bin
+  uint32_t* sh = gdst + FX_NP_MAX;    // [SORT_TPB]
+  uint32_t* st_d = sh + SORT_TPB;     // [FX_CHUNK]
+  uint32_t* st_id = st_d + FX_CHUNK;  // [FX_CHUNK]
+  const uint32_t FX_NP = fb.np(), t = threadIdx.x;
+  const int FX_LO = fb.lo;
+  const size_t hb = (size_t)blockIdx.x * FX_NP;
+  const uint32_t mask = (1u << FX_LO) - 1;
+  uint32_t tot = 0;
+  if (STAGED) {
+    uint32_t h = t < FX_NP ? phist[hb + t] : 0;
+    uint32_t ex = block_scan_tpb(h, sh, &tot);
+    if (t < FX_NP) {
+      cur[t] = ex;
+      gdst[t] = pstart[t] + pbase[hb + t] - ex;
+    }
+  } else {
+    for (uint32_t k = t; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + pbase[hb + k];
+  }
+  __syncthreads();
+  const uint32_t lo = blockIdx.x * S, hi = min(n, lo + S);
+  for (uint32_t i = lo + t; i < hi; i += SORT_TPB) {
+    uint32_t s[9];
+    if (!fx_load_scalar(scalars, inf, i, s, nullptr, false)) continue;
+    fx_recode_signed_each(s, c, W, n_narrow, [&](int w, uint32_t word) {
+      if (!word) return;
+      const uint32_t key = fxw_key(word);
+      const uint32_t id = ((uint32_t)w * n_total + i0 + i) | ((word & FXW_NEG) ? ITEM_NEG : 0u);
+      const uint32_t pos = atomicAdd(&cur[key >> FX_LO], 1u);
+      if (STAGED) {
+        st_d[pos] = key;
+        st_id[pos] = id;
+      } else {
+        plo[pos] = (uint16_t)(key & mask);
+        pid[pos] = id;
+      }
+    });
+  }
+  if (!STAGED) return;
+  __syncthreads();
   for (uint32_t pos = t; pos < tot; pos += SORT_TPB) {
     uint32_t d = st_d[pos], dst = gdst[d >> FX_LO] + pos;
     plo[dst] = (uint16_t)(d & mask);
@@ -1490,6 +1582,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_part_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE1_LDS);
       if (attr_err == hipSuccess)
+        attr_err = hipFuncSetAttribute((const void*)k_part_scatter_signed<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE1_LDS);
+      if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
                           (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false>, (const void*)k_merge<true>,
@@ -1519,8 +1613,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
   size_t o_err = carve(16);
   size_t o_digits = carve(fx ? 16 : (size_t)p.W * n * 2);
-  const uint32_t fx_nblk = cdiv(p.e_max, FX_CHUNK);
-  size_t o_digits32 = carve(fx ? p.e_max * 4 : 16);
+  // signed flavour: level 1 of the sort reads the scalars themselves (k_part_hist_signed), a block per fx_S scalars
+  const bool fused1 = fx && fx->signed_digits && tune().msm_sort_fused != 0;
+  const uint32_t fx_S = fused1 ? (FX_CHUNK / (uint32_t)p.W > 0 ? FX_CHUNK / (uint32_t)p.W : 1u) : 0u;
+  const uint32_t fx_nblk = fused1 ? cdiv(n, fx_S) : cdiv(p.e_max, FX_CHUNK);
+  size_t o_digits32 = carve(fx && !fused1 ? p.e_max * 4 : 16);
   size_t o_plo = carve(fx ? p.e_max * 2 : 16);
   size_t o_pid = carve(fx ? p.e_max * 4 : 16);
   size_t o_phist = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
@@ -1585,7 +1682,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
-  if (fx && fx->signed_digits)
+  if (fused1)
+    ;  // no entry words in HBM: both level-1 kernels recompute them
+  else if (fx && fx->signed_digits)
     hipLaunchKernelGGL(k_recode_signed, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
                        p.c, p.W, p.n_narrow, digits32, err);
   else if (fx)
@@ -1596,12 +1695,22 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                        (uint32_t)n, p.c, p.W, p.n_narrow, digits, err);
   if (fx) {
     const uint32_t gmax = fx_nblk + FX_NP;  // upper bound on the number of level-2 chunks
-    hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
+    if (fused1)
+      hipLaunchKernelGGL(k_part_hist_signed, dim3(fx_nblk), dim3(SORT_TPB), 0, st, (const uint32_t*)d_scalars, (const uint8_t*)d_inf, (uint32_t)n,
+                         p.c, p.W, p.n_narrow, fx_S, fb, phist, err);
+    else
+      hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
     hipLaunchKernelGGL(k_part_scan, dim3(FX_NP), dim3(256), 0, st, phist, fx_nblk, fb, pbase, pcount);
     hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(FX_NP_MAX), 0, st, pcount, fb, pstart, cstart);
     const bool staged1 = FX_NP >= 64;           // few partitions: direct stores already coalesce
     const bool staged2 = fb.lo <= 10;           // one bin per thread in the block scan
-    if (staged1)
+    if (fused1 && staged1)
+      hipLaunchKernelGGL(k_part_scatter_signed<true>, dim3(fx_nblk), dim3(SORT_TPB), FX_STAGE1_LDS, st, (const uint32_t*)d_scalars,
+                         (const uint8_t*)d_inf, (uint32_t)n, p.c, p.W, p.n_narrow, fx_S, fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
+    else if (fused1)
+      hipLaunchKernelGGL(k_part_scatter_signed<false>, dim3(fx_nblk), dim3(SORT_TPB), (2 * FX_NP_MAX + SORT_TPB) * 4, st, (const uint32_t*)d_scalars,
+                         (const uint8_t*)d_inf, (uint32_t)n, p.c, p.W, p.n_narrow, fx_S, fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
+    else if (staged1)
       hipLaunchKernelGGL(k_part_scatter_staged, dim3(fx_nblk), dim3(SORT_TPB), FX_STAGE1_LDS, st, digits32, p.e_max, (uint32_t)n,
                          fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
     else

@@ -204,6 +204,16 @@ def test_fixed_base_msm_context(dvp, hint, slide):
     for pt in parts:
         acc = o.k233_add(acc, pt)
     assert acc == expect(0, n)  # the shards add up to the whole (what the all-gather + local add relies on)
+    # a scalar >= p is refused with its index, whichever kernel recodes (level 1 of the sort reads the scalars itself by default)
+    bad = s.copy()
+    bad[4321] = to_limbs([o.P])[0]
+    for fused in (0, 1):
+        with dvp.tune(DVP_MSM_SORT_FUSED=fused):
+            with pytest.raises(dvp.DvpError) as ei:
+                fb.run(bad)
+            assert ei.value.status == -1 and ei.value.index == 4321
+            xy, is_inf = fb.run(s)
+            assert np_to_pt(xy, is_inf) == expect(0, n)
 
 
 def test_msm_heavy_skew_2_18(dvp):
@@ -313,7 +323,7 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     for c, slide in [(c, 0) for c in range(8, 22)] + [(c, 3) for c in range(8, 21)]:
         with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1,
                       DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
-                      DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48])):
+                      DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48]), DVP_MSM_SORT_FUSED=c & 1):
             fb = dvp.curve.FixedBaseMsm(bases)
             if slide == 0:  # 234 bits in ceil(234 / c) windows evened out; all windows narrow = the plan of c - 1 (19 -> 18, 21 -> 20)
                 ce = c
