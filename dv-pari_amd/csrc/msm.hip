@@ -1399,6 +1399,23 @@ struct MsmWorkspace {
   hipEvent_t ev = nullptr;
   hipEvent_t ev_heavy = nullptr;  // end of this workspace's last run of pair rounds (HeavyGate)
   uint32_t* pinned = nullptr;
+  // round bookkeeping (counts, offsets, descriptors of the later pair rounds) runs on a side stream while the first round fills
+  // the chip: ev_pre = the first round's offsets are in place, ev_side[r] = round r may start
+  hipStream_t side = nullptr;
+  hipEvent_t ev_pre = nullptr;
+  std::vector<hipEvent_t> ev_side;
+  int ensure_side(size_t rounds) {
+    if (!side) {
+      DVP_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+      DVP_HIP(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
+    }
+    while (ev_side.size() < rounds) {
+      hipEvent_t b = nullptr;
+      DVP_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      ev_side.push_back(b);
+    }
+    return DVP_OK;
+  }
   int ensure_aux() {
     if (aux) return DVP_OK;
     DVP_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
@@ -1642,7 +1659,30 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_affA = carve(affine_mode ? affA_n * sizeof(Aff) : 16);
   size_t o_affB = carve(affine_mode ? affB_n * sizeof(Aff) : 16);
   size_t o_prefix = carve(affine_mode ? (affA_n + 256) * sizeof(Gf) : 16);  // one prefix product per output slot (+ the B - 1 <= 254 slots the last thread's rows may overhang)
-  size_t o_gdesc = carve(affine_mode ? (affA_n + 64) * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
+  // pair rounds the SIZE rule allows (the largest bucket, which only the device knows, may stop them sooner): rounds run while a
+  // round still carries >= aff_min additions
+  const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
+  // entries that really exist: the overflow windows are empty in practice
+  const size_t e_est = (size_t)n * (size_t)((fx && fx->signed_digits) ? p.W : (234 + p.c - 1) / p.c);
+  int ra_plan = 0;
+  while (affine_mode && ra_plan < 40 && (e_est >> (ra_plan + 1)) >= aff_min) ++ra_plan;
+  // bookkeeping of ALL later rounds behind the first one (side stream, see below): every round keeps its own counts / offsets /
+  // descriptors, so nothing the side stream writes is ever read by a round still in flight
+  const bool pipelined = affine_mode && tn.msm_round_pipeline != 0 && ra_plan >= 2 && e_est >= 4 * (size_t)p.nkeys;
+  std::vector<size_t> desc_at((size_t)ra_plan + 1, 0);  // round r's descriptors start at gdesc + desc_at[r] (r >= 1)
+  size_t desc_n = affA_n + 64;
+  if (pipelined) {
+    size_t cap_r = p.e_max + p.nkeys, at = 0;
+    for (int r = 0; r < ra_plan; ++r) {
+      const size_t out_max = cap_r / 2 + p.nkeys + 1;
+      if (r >= 1) { desc_at[r] = at; at += out_max + 64; }
+      cap_r = out_max;
+    }
+    if (at > desc_n) desc_n = at;
+  }
+  size_t o_gdesc = carve(affine_mode ? desc_n * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
+  size_t o_rp = carve(pipelined ? (size_t)ra_plan * 2 * ((size_t)p.nkeys + 1) * 4 : 16);  // (counts, offsets) of rounds 1 .. ra_plan
+  size_t o_bsum2 = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);                            // scan scratch of the side stream
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_rest = carve(((size_t)p.nkeys + 1) * 4);  // k_bucket_pairs' list of buckets with more than two entries
   size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
@@ -1675,10 +1715,44 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   Aff* affB = (Aff*)(base + o_affB);
   Gf* prefix = (Gf*)(base + o_prefix);
   uint2* gdesc = (uint2*)(base + o_gdesc);
+  auto* rp = (uint32_t*)(base + o_rp);
+  auto* bsum2 = (uint32_t*)(base + o_bsum2);
   Ld* tail = (Ld*)(base + o_tail);
   auto* rest_list = (uint32_t*)(base + o_rest);
   const uint32_t nk = p.nkeys;
 
+  // counts / offsets of round r's outputs (r >= 1) from those of its inputs, and its slot descriptors, on stream s
+  auto bookkeep = [&](int r, const uint32_t* ic, const uint32_t* io, uint32_t* oc, uint32_t* oo, uint2* dsc, hipStream_t s, uint32_t* bs) -> int {
+    DVP_TRY(scan_exclusive_div(ic, 2u, oc, oo, nk, bs, s));
+    // descriptors: lanes per bucket by the average bucket size of this round
+    const size_t per_key = (e_est >> (r + 1)) / nk;
+#define DVP_DESC_LAUNCH(LPK) hipLaunchKernelGGL((k_round_desc<LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, s, ic, io, oo, nk, dsc)
+    if (per_key >= 48) DVP_DESC_LAUNCH(64); else if (per_key >= 8) DVP_DESC_LAUNCH(16); else DVP_DESC_LAUNCH(4);
+#undef DVP_DESC_LAUNCH
+    return DVP_OK;
+  };
+  // Round bookkeeping off the critical path (round 4).  A pair round's counts, offsets and slot descriptors depend on the bucket
+  // COUNTS only, never on the points.  With `pipelined` a side stream prepares ALL rounds -- each into arrays of its own -- as soon
+  // as the sort has scanned the counts, i.e. while the sort's last scatter (0.13-0.27 ms, HBM-bound) still runs, and the rounds then
+  // follow each other back to back (three 5 us scan launches and a descriptor kernel per round used to sit between them: ~0.35 ms
+  // per proof).  NOT while a pair round runs: a round is an exact number of chip-fulls, and a few workgroups of another kernel
+  // holding wave slots when it is dispatched push some of its workgroups into an extra pass (measured: +0.4 ms per MSM).
+  // (rc(r), ro(r)) = counts / offsets of round r's INPUT; round 0's are the sort's.
+  auto rc = [&](int r) -> uint32_t* { return r == 0 ? cnt : rp + (size_t)(2 * (r - 1)) * ((size_t)nk + 1); };
+  auto ro = [&](int r) -> uint32_t* { return r == 0 ? off : rp + (size_t)(2 * (r - 1) + 1) * ((size_t)nk + 1); };
+  int prepared = 0;  // pipelined: the bookkeeping of rounds < prepared is enqueued on the side stream (ev_side[0] = all of it is done)
+  auto prepare_rounds = [&]() -> int {  // call once (cnt, off) are final on `st`
+    if (!pipelined) return DVP_OK;
+    DVP_TRY(g_ws.ensure_side(1));
+    DVP_HIP(hipEventRecord(g_ws.ev_pre, st));
+    DVP_HIP(hipStreamWaitEvent(g_ws.side, g_ws.ev_pre, 0));
+    // round 0: even-aligned buckets -- the sorted item list is the descriptor array, the output offsets are the items' halved
+    hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, g_ws.side, rc(0), ro(0), nk, rc(1), ro(1));
+    for (int q = 1; q < ra_plan; ++q) DVP_TRY(bookkeep(q, rc(q), ro(q), rc(q + 1), ro(q + 1), gdesc + desc_at[q], g_ws.side, bsum2));
+    DVP_HIP(hipEventRecord(g_ws.ev_side[0], g_ws.side));
+    prepared = ra_plan;
+    return DVP_OK;
+  };
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
   DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
@@ -1719,6 +1793,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
     hipLaunchKernelGGL(k_hist_scan2, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, cstart, fb, chunk_off, cnt);
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
+    DVP_TRY(prepare_rounds());
     if (staged2)
       hipLaunchKernelGGL(k_scatter_local2_staged, dim3(gmax), dim3(SORT_TPB), FX_STAGE2_LDS, st, plo, pid, pstart, cstart, fb, off,
                          chunk_off, hist16, items);
@@ -1730,6 +1805,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
     hipLaunchKernelGGL(k_hist_scan, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, nchunks, p.c, p.W, chunk_off, cnt);
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
+    DVP_TRY(prepare_rounds());
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
     hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   }
@@ -1744,9 +1820,6 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   DVP_HIP(hipEventRecord(g_ws.ev, st));
   DVP_HIP(hipStreamWaitEvent(g_ws.aux, g_ws.ev, 0));
   DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
-  const size_t aff_min = (size_t)(tn.msm_aff_min > 0 ? tn.msm_aff_min : 1);
-  // entries that really exist: the overflow windows are empty in practice
-  const size_t e_est = (size_t)n * (size_t)((fx && fx->signed_digits) ? p.W : (234 + p.c - 1) / p.c);
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -1769,31 +1842,16 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const uint32_t aff_bmin = tn.msm_aff_bmin >= 1 && (uint32_t)tn.msm_aff_bmin <= aff_bmax_only ? (uint32_t)tn.msm_aff_bmin : 1u;
   const uint32_t aff_bmax = aff_bmax_only | (aff_bmin << 8);
   const bool wt_on = g_wave_trace.load() != nullptr;
-  auto launch_round = [&](int r) -> int {
-    int nxt = (cur + 1) % 3;
-    const bool items_are_desc = r == 0;  // even-aligned buckets: the sorted item list is the descriptor array
-    if (items_are_desc)
-      hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
-    else
-      DVP_TRY(scan_exclusive_div(pc[cur], 2u, pc[nxt], po[nxt], nk, bsum, st));
+  // the round itself: d_total = the scanned output count (ooff[nkeys]), dsc = one (a, b) descriptor per output slot
+  auto launch_round = [&](int r, const uint32_t* d_total, const uint2* dsc) -> int {
     size_t out_max = cap / 2 + nk + 1;
     Aff* outp = (r & 1) ? affB : affA;
-    // descriptors: lanes per bucket by the average bucket size of this round
-    const size_t per_key = (e_est >> (r + 1)) / nk;
-#define DVP_DESC_LAUNCH(LPK) \
-  hipLaunchKernelGGL((k_round_desc<LPK>), dim3(cdiv((size_t)nk * LPK, 256)), dim3(256), 0, st, pc[cur], po[cur], po[nxt], nk, gdesc)
-    if (!items_are_desc) {  // round 0 needs none
-      if (per_key >= 48) DVP_DESC_LAUNCH(64); else if (per_key >= 8) DVP_DESC_LAUNCH(16); else DVP_DESC_LAUNCH(4);
-    }
-#undef DVP_DESC_LAUNCH
     // grid: upper bound on the threads the device-side choice of B can ask for (R chip-fulls, see k_affine_round)
     const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax_only);
     const uint32_t grid = r_max * (aff_cap / aff_tpb) + 1;
-    const uint32_t* d_total = po[nxt] + nk;  // ooff[nkeys]
     {
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st, (uint64_t)n);  // r == 0 is the dominant kernel: it gathers the bases
       WaveTrace wt{g_wave_trace.load(), g_wave_trace_cap, g_wave_trace_tag.fetch_add(wt_on ? 1u : 0u)};
-      const uint2* dsc = items_are_desc ? (const uint2*)items : (const uint2*)gdesc;
       if (r == 0 && wt.buf)
         hipLaunchKernelGGL((k_affine_round<true, true>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask, wt);
       else if (r == 0)
@@ -1806,6 +1864,20 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     }
     pts_in = outp;
     cap = out_max;
+    return DVP_OK;
+  };
+  auto run_round = [&](int r) -> int {
+    if (pipelined) {  // r < ra_plan always (ra <= ra_plan); everything a round needs was prepared behind the sort
+      if (r == 0) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));
+      DVP_TRY(launch_round(r, ro(r + 1) + nk, r == 0 ? (const uint2*)items : (const uint2*)(gdesc + desc_at[r])));
+      return DVP_OK;
+    }
+    const int nxt = (cur + 1) % 3;
+    if (r == 0)
+      hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
+    else
+      DVP_TRY(bookkeep(r, pc[cur], po[cur], pc[nxt], po[nxt], gdesc, st, bsum));
+    DVP_TRY(launch_round(r, po[nxt] + nk, r == 0 ? (const uint2*)items : (const uint2*)gdesc));
     cur = nxt;
     return DVP_OK;
   };
@@ -1819,7 +1891,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     if (g_heavy[cur_dev].last && g_heavy[cur_dev].last != g_ws.ev_heavy) DVP_HIP(hipStreamWaitEvent(st, g_heavy[cur_dev].last, 0));
   }
   if (affine_mode && (e_est >> 1) >= aff_min && e_est >= 4 * (size_t)nk) {
-    DVP_TRY(launch_round(0));
+    DVP_TRY(run_round(0));
     launched = 1;
   }
   DVP_HIP(hipStreamSynchronize(g_ws.aux));  // the caller's stream keeps running round 0 meanwhile
@@ -1843,8 +1915,14 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   };
   if (r_evt >= 0 && r_evt < launched) DVP_TRY(gate_event());
   for (int r = launched; r < ra; ++r) {
-    DVP_TRY(launch_round(r));
+    DVP_TRY(run_round(r));
     if (r == r_evt) DVP_TRY(gate_event());
+  }
+  if (pipelined && prepared) {
+    // what the rounds left is described by the arrays of round `ra`: they head the ring of three the reducer works in
+    if (!launched) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));  // (not reached: a pipelined MSM always starts its first round early)
+    pc[0] = rc(ra); po[0] = ro(ra);
+    cur = 0;
   }
   if (heavy.owns_lock()) heavy.unlock();
   uint64_t rem_max = ((uint64_t)max_cnt + ((uint64_t)1 << ra) - 1) >> ra;  // largest bucket after the affine rounds

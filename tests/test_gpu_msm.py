@@ -257,7 +257,7 @@ def test_bucket_reduction_exceptional_pairs(dvp):
             fb = dvp.curve.FixedBaseMsm(bases)
         for aff_min in (32, 512, 4096):
             for pairs_max in (0, 12, 100000):
-                with dvp.tune(DVP_MSM_AFF_MIN=aff_min, DVP_MSM_BUCKET_PAIRS_MAX=pairs_max, DVP_MSM_C=c):
+                with dvp.tune(DVP_MSM_AFF_MIN=aff_min, DVP_MSM_BUCKET_PAIRS_MAX=pairs_max, DVP_MSM_C=c, DVP_MSM_ROUND_PIPELINE=int(aff_min != 512)):
                     assert np_to_pt(*fb.run(s)) == exp, (c, aff_min, pairs_max)
                     assert np_to_pt(*fb.run(s[lo:hi], lo, hi)) == exp_part, (c, aff_min, pairs_max)
                     assert gpu_msm(dvp, s, bases) == exp, (c, aff_min, pairs_max)
@@ -323,7 +323,7 @@ def test_fixed_base_vs_one_shot_randomised(dvp):
     for c, slide in [(c, 0) for c in range(8, 22)] + [(c, 3) for c in range(8, 21)]:
         with dvp.tune(DVP_MSM_FIXED_C=c, DVP_MSM_ALIGNED_SIGNED=0 if slide == 3 else 1,
                       DVP_MSM_AFF_MIN=rnd.choice([16, 256, 4096, 1 << 19]),
-                      DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48]), DVP_MSM_SORT_FUSED=c & 1):
+                      DVP_MSM_AFF_BMAX=rnd.choice([2, 7, 48]), DVP_MSM_SORT_FUSED=c & 1, DVP_MSM_ROUND_PIPELINE=(c >> 1) & 1):
             fb = dvp.curve.FixedBaseMsm(bases)
             if slide == 0:  # 234 bits in ceil(234 / c) windows evened out; all windows narrow = the plan of c - 1 (19 -> 18, 21 -> 20)
                 ce = c
