@@ -242,6 +242,68 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q, const LT& L) {
   return r;
 }
 
+// ---- lambda-projective coordinates (Oliveira, Lopez, Aranha, Rodriguez-Henriquez 2013): (X, L, Z) with x = X / Z and
+// lambda = x + y / x = L / Z, kept in an Ld whose Y field holds L; Z == 0 is the point at infinity.  Full addition 11M + 2S against
+// Lopez-Dahab's 13M + 5S, doubling 4M + 4S against 3M + 5S: what the merge tree runs on (2^(c+1) full additions per MSM, no
+// doublings); the tail goes back to Lopez-Dahab for its doublings.  Formulas for a = 0, checked against the big-int group law
+// (tools/lambda_check.py: addition, doubling and both conversions on the big-int oracle; every MSM test runs through the tree).
+// With x_i = X_i / Z_i, lambda_i = L_i / Z_i:  A = L1 Z2 + L2 Z1, U = X1 Z2, V = X2 Z1, B = (U + V)^2,
+//   X3 = (A U)(A V),  Z3 = (A B Z2) Z1,  L3 = (A V + B)^2 + (A B Z2)(L1 + Z1);
+// doubling: T = L^2 + L Z,  X3 = T^2,  Z3 = T Z^2,  L3 = (X Z)^2 + X3 + T (L Z) + Z3.
+template <class LT>
+GF_DEV void lam_from_ld(Ld& p, const LT& L) {  // (X, Y, Z) -> (X^2, X^2 + Y, X Z); infinity (Z = 0) stays infinity
+  const Gf xs = gf_sqr(p.X);
+  p.Z = gf_mul(p.X, p.Z, L);
+  p.Y = gf_add(xs, p.Y);
+  p.X = xs;
+}
+template <class LT>
+GF_DEV void lam_to_ld(Ld& p, const LT& L) {  // y = x (lambda + x): (X, L, Z) -> (X, X (L + X), Z)
+  p.Y = gf_mul(p.X, gf_add(p.Y, p.X), L);
+}
+template <class LT>
+GF_DEV void lam_dbl_ip(Ld& p, const LT& L) {
+  Gf lz, xz;
+  gf_mul2(p.Y, p.X, p.Z, L, lz, xz);
+  const Gf T = gf_add(gf_sqr(p.Y), lz);  // L^2 + L Z (+ a Z^2, a = 0)
+  const Gf X3 = gf_sqr(T);
+  Gf Z3, tlz;
+  gf_mul2(gf_sqr(p.Z), lz, T, L, Z3, tlz);
+  p.Y = gf_add(gf_add(gf_sqr(xz), X3), gf_add(tlz, Z3));
+  p.X = X3;
+  p.Z = Z3;
+}
+// p += q.  Returns false -- p untouched -- when p == q (both finite): the CALLER doubles, from a copy it re-reads: an inlined
+// doubling here keeps all of p alive across the whole addition and costs 460 B of scratch per lane in k_merge.
+template <class LT>
+GF_DEV bool lam_add_ip(Ld& p, const Ld& q, const LT& L) {
+  if (gf_is_zero(q.Z)) return true;
+  if (gf_is_zero(p.Z)) {
+    p.X = q.X; p.Y = q.Y; p.Z = q.Z;
+    return true;
+  }
+  Gf l1, U, l2, V;
+  gf_mul2(p.Y, p.X, q.Z, L, l1, U);  // L1 Z2, X1 Z2
+  gf_mul2(q.Y, q.X, p.Z, L, l2, V);  // L2 Z1, X2 Z1
+  const Gf A = gf_add(l1, l2), D = gf_add(U, V);
+  if (gf_is_zero(D)) {  // same x
+    if (gf_is_zero(A)) return false;  // same lambda: p == q
+    p.X = gf_one(); p.Y = gf_one(); p.Z = gf_zero();  // p == -q
+    return true;
+  }
+  // order: what needs q.Z, p.Y and p.Z first, so that only U, V, A, B and two results are live across the last products
+  const Gf B = gf_sqr(D);
+  const Gf ABZ2 = gf_mul(gf_mul(B, A, L), q.Z, L);
+  Gf T1, Z3;
+  gf_mul2(gf_add(p.Y, p.Z), p.Z, ABZ2, L, T1, Z3);
+  Gf AV, AU;
+  gf_mul2(V, U, A, L, AV, AU);
+  p.X = gf_mul(AU, AV, L);
+  p.Y = gf_add(gf_sqr(gf_add(AV, B)), T1);
+  p.Z = Z3;
+  return true;
+}
+
 // Frobenius tau(x,y) = (x^2,y^2), applied k times
 GF_DEV Ld ld_frob_n(Ld p, int k) {
 #pragma unroll 1

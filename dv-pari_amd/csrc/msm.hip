@@ -1220,8 +1220,12 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 // level j: blocks of 2^(j+1) buckets; slot s <= j: A[base+s] += A[base+2^j+s]; slot j+1 <- T_right
 // QUAD: the deep levels have far fewer additions than the chip has lanes and are pure latency; there the four lanes
 // of a quad share one addition (gf233.cuh, quad-cooperative product), 2.2x shorter per level.
-template <bool QUAD>
-__global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+// Round 4: the tree runs in lambda-projective coordinates (k233.cuh: 11M + 2S per full addition against 13M + 5S).  Level 0
+// reads every bucket exactly once (as the left or the right operand of its pair) and converts it on the way in -- (X, Y, Z) ->
+// (X^2, X^2 + Y, X Z), 1M + 1S -- so the right operand, which stays in place as D_0 of its block, is written back converted;
+// k_tail converts what it reads back to Lopez-Dahab (1M) for its doublings.
+template <bool QUAD, bool FIRST>
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(QUAD ? 1 : 2, 2))) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (QUAD) tid >>= 2;
@@ -1231,15 +1235,30 @@ __global__ void __launch_bounds__(EC_TPB) k_merge(Ld* __restrict__ A, int j, uin
   Ld l = A[base + s], r = A[base + ((size_t)1 << j) + s];
   if (QUAD) {
     GfLdsQ L = gf_ldsq_init(lds_raw);
-    ld_add_ip(l, r, L);
-    if (L.r == 0) {
-      if (s == 0 && j >= 2) A[base + 1 + j] = r;
-      A[base + s] = l;
+    if (FIRST) {  // j == 0
+      lam_from_ld(l, L);
+      lam_from_ld(r, L);
     }
+    if (L.r == 0 && s == 0 && j != 1) A[base + 1 + j] = r;  // j = 0: the converted right operand; j = 1: T_right is in place already
+    if (!lam_add_ip(l, r, L)) {  // l == r (equal bucket sums: equal bases and scalars): double a copy read back
+      __threadfence_block();
+      l = A[base + s];
+      if (FIRST) lam_from_ld(l, L);
+      lam_dbl_ip(l, L);
+    }
+    if (L.r == 0) A[base + s] = l;
   } else {
     GfLdsK L = gf_ldsk_init(lds_raw);
-    if (s == 0 && j >= 2) A[base + 1 + j] = r;
-    ld_add_ip(l, r, L);
+    if (FIRST) {
+      lam_from_ld(l, L);
+      lam_from_ld(r, L);
+    }
+    if (s == 0 && j != 1) A[base + 1 + j] = r;
+    if (!lam_add_ip(l, r, L)) {
+      l = A[base + s];
+      if (FIRST) lam_from_ld(l, L);
+      lam_dbl_ip(l, L);
+    }
     A[base + s] = l;
   }
 }
@@ -1268,6 +1287,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
     // the merge turned slot 0 into the total)
     for (uint32_t pt = threadIdx.x >> 2; pt < cnt0; pt += EC_TPB / 4) {
       Ld p = pt + 1 < cnt0 ? A[1 + pt] : buf[2 * cnt0];
+      if (pt + 1 < cnt0) lam_to_ld(p, L);  // the merge tree's lambda-projective output; bucket 0 was saved before the tree (Lopez-Dahab)
 #pragma unroll 1
       for (uint32_t k = 0; k < pt; ++k) p = ld_dbl(p, L);
       if (L.r == 0) in[pt] = p;
@@ -1277,6 +1297,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
       uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
       int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
       Ld p = A[((size_t)w << c) + 1 + t];
+      p.Y = gf_mul(p.X, gf_add(p.Y, p.X));  // lambda-projective (the merge tree's output) -> Lopez-Dahab: Y = X (L + X)
       p.X = gf_sqr_n_fast(p.X, k, T);
       p.Y = gf_sqr_n_fast(p.Y, k, T);
       p.Z = gf_sqr_n_fast(p.Z, k, T);
@@ -1603,7 +1624,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
-                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false>, (const void*)k_merge<true>,
+                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false, false>, (const void*)k_merge<true, false>, (const void*)k_merge<false, true>, (const void*)k_merge<true, true>,
                           (const void*)k_affine_round<true, false>, (const void*)k_affine_round<false, false>, (const void*)k_affine_round<true, true>,
                           (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail,
                           (const void*)k_bucket_pairs, (const void*)k_bucket_rest};
@@ -1982,10 +2003,14 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   for (int j = 0; j < merge_levels; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
-    if (total <= quad_max)
-      hipLaunchKernelGGL(k_merge<true>, dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
+    if (total <= quad_max && j == 0)
+      hipLaunchKernelGGL((k_merge<true, true>), dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
+    else if (total <= quad_max)
+      hipLaunchKernelGGL((k_merge<true, false>), dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
+    else if (j == 0)
+      hipLaunchKernelGGL((k_merge<false, true>), dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
     else
-      hipLaunchKernelGGL(k_merge<false>, dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
+      hipLaunchKernelGGL((k_merge<false, false>), dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
   }
   const int w_tail = fx ? 1 : p.W;  // fixed-base mode has a single bucket set
   uint32_t cntT = (uint32_t)(w_tail * p.c);

@@ -356,3 +356,55 @@ def test_cpu_prove_end_to_end_vs_pyref_2_5():
     assert commit == co.xsk233_encode(co.k233_mulgen(pr["dl_commit_p"])) and kzg == co.xsk233_encode(co.k233_mulgen(pr["dl_kzg"]))
     assert (a0, b0) == (pr["a0"], pr["b0"])
     assert o.verify_dl(trap, pub, pr["dl_commit_p"], pr["dl_kzg"], a0, b0, pr["alpha"])
+
+
+def test_lambda_projective_formulas():
+    """the merge tree's coordinates (csrc/k233.cuh: lam_add_ip, lam_dbl_ip, lam_from_ld, lam_to_ld) restated on the big-int field
+    and checked against the oracle's affine group law: (X, L, Z) with x = X / Z, lambda = x + y / x = L / Z; a = 0"""
+    M, S, I = o.gf_mul, o.gf_sqr, o.gf_inv
+    rnd = random.Random(1)
+
+    def to_l(pt, z):
+        x, y = pt
+        return (M(x, z), M(x ^ M(y, I(x)), z), z)
+
+    def from_l(P):
+        X, L, Z = P
+        if Z == 0:
+            return None
+        zi = I(Z)
+        x, lam = M(X, zi), M(L, zi)
+        return (x, M(lam ^ x, x))
+
+    def ladd(P, Q):
+        X1, L1, Z1 = P
+        X2, L2, Z2 = Q
+        A, U, V = M(L1, Z2) ^ M(L2, Z1), M(X1, Z2), M(X2, Z1)
+        if U == V:
+            return ldbl(P) if A == 0 else (1, 1, 0)
+        B = S(U ^ V)
+        AV, ABZ2 = M(A, V), M(M(A, B), Z2)
+        return (M(M(A, U), AV), S(AV ^ B) ^ M(ABZ2, L1 ^ Z1), M(ABZ2, Z1))
+
+    def ldbl(P):
+        X, L, Z = P
+        T = S(L) ^ M(L, Z)
+        X3, Z3 = S(T), M(T, S(Z))
+        return (X3, S(M(X, Z)) ^ X3 ^ M(T, M(L, Z)) ^ Z3, Z3)
+
+    G = o.G_STD
+    for t in range(6):
+        p1, p2 = o.k233_mul(rnd.randrange(1, o.P), G), o.k233_mul(rnd.randrange(1, o.P), G)
+        z1, z2 = rnd.getrandbits(232) | 1, rnd.getrandbits(232) | 1
+        P1, P2 = to_l(p1, z1), to_l(p2, z2)
+        assert from_l(ladd(P1, P2)) == o.k233_add(p1, p2)
+        assert from_l(ldbl(P1)) == o.k233_dbl(p1)
+        assert from_l(ladd(P1, to_l(p1, z2))) == o.k233_dbl(p1)          # equal points in different representations
+        assert from_l(ladd(P1, to_l(o.k233_neg(p1), z2))) is None          # opposite points
+        # Lopez-Dahab (X, Y, Z), x = X / Z, y = Y / Z^2  ->  (X^2, X^2 + Y, X Z), and back: (X, X (L + X), Z)
+        X, Y, Z = M(p1[0], z1), M(p1[1], S(z1)), z1
+        lam = (S(X), S(X) ^ Y, M(X, Z))
+        assert from_l(lam) == p1
+        Xb, Yb, Zb = lam[0], M(lam[0], lam[1] ^ lam[0]), lam[2]
+        zi = I(Zb)
+        assert (M(Xb, zi), M(Yb, S(zi))) == p1
