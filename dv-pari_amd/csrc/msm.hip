@@ -942,6 +942,9 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
 // slot k+2 and the operands of slot k+1 are in flight while slot k multiplies, so the random 64-byte gathers of the
 // bases (HBM misses in the first round: the pre-rotated table is 5 GB) are off the critical path.
 constexpr uint32_t AFF_NONE = 0xffffffffu;
+// slot descriptor of the rounds after the first: the slot adds points i and i + 1 of the previous round's output (DESC_PAIR set) or
+// passes point i on (a bucket's odd leftover); i < 2^31.  The first round reads the sorted item list as (a, b) pairs instead.
+constexpr uint32_t DESC_PAIR = 0x80000000u;
 
 // Both sorts lay every bucket out from an EVEN position of the item list (scan of the counts rounded up to
 // even); an odd bucket's spare slot gets AFF_NONE.  The list read as uint2 pairs is then exactly the descriptor array of
@@ -963,21 +966,93 @@ k_round0_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
   if (k < nkeys) ocnt[k] = (cnt[k] + 1) >> 1;
 }
 
+// ---- the bookkeeping of ALL pair rounds at once (round 4) --------------------------------------------------------------------
+// Round r's input counts are c_r = ceil(c_{r-1} / 2) of the sort's counts c_0, its offsets their exclusive scan: R scans that depend
+// on nothing but c_0, so one three-launch scan carries all of them (a column of R running sums per key) where the rounds used to
+// pay three launches each.  rp: (c_r, o_r) for r = 1 .. R, each nkeys + 1 words (o_r[nkeys] = total), at rp + 2 (r - 1) (nkeys + 1).
+__global__ void __launch_bounds__(SCAN_TPB) k_mscan_local(const uint32_t* __restrict__ cnt0, uint32_t m, int R, uint32_t* __restrict__ rp,
+                                                          uint32_t* __restrict__ bs /* [R][nb] */) {
+  __shared__ uint32_t sh[SCAN_TPB];
+  const uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
+  uint32_t v[SCAN_EPT];
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k) v[k] = (base + k < m) ? cnt0[base + k] : 0;
+  for (int r = 1; r <= R; ++r) {
+    uint32_t* c = rp + (size_t)(2 * (r - 1)) * ((size_t)m + 1);
+    uint32_t* o = c + ((size_t)m + 1);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; ++k) {
+      v[k] = (v[k] + 1u) >> 1;
+      s += v[k];
+    }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(s, &tot, sh);
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; ++k) {
+      if (base + k < m) {
+        c[base + k] = v[k];
+        o[base + k] = ex;
+      }
+      ex += v[k];
+    }
+    if (threadIdx.x == 0) bs[(size_t)(r - 1) * gridDim.x + blockIdx.x] = tot;
+  }
+}
+__global__ void __launch_bounds__(SCAN_TPB) k_mscan_bsums(uint32_t* __restrict__ bs, uint32_t nb, uint32_t m, uint32_t* __restrict__ rp) {
+  __shared__ uint32_t sh[SCAN_TPB];
+  const int r = blockIdx.x + 1;
+  uint32_t* row = bs + (size_t)(r - 1) * nb;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += SCAN_TPB) {
+    uint32_t idx = base + threadIdx.x;
+    uint32_t v = idx < nb ? row[idx] : 0;
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan(v, &tot, sh);
+    if (idx < nb) row[idx] = ex + carry;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) rp[(size_t)(2 * (r - 1) + 1) * ((size_t)m + 1) + m] = carry;  // o_r[nkeys]
+}
+__global__ void __launch_bounds__(SCAN_TPB) k_mscan_add(uint32_t* __restrict__ rp, const uint32_t* __restrict__ bs, uint32_t m, int R) {
+  const uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
+  for (int r = 1; r <= R; ++r) {
+    uint32_t* o = rp + (size_t)(2 * (r - 1) + 1) * ((size_t)m + 1);
+    const uint32_t add = bs[(size_t)(r - 1) * gridDim.x + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; ++k)
+      if (base + k < m) o[base + k] += add;
+  }
+}
+// slot descriptors of rounds 1 .. R - 1 in one launch: LPK lanes per bucket walk its outputs round by round
+// (round r pairs the outputs of round r - 1: inputs at o_r[key] + 2 j, + 1; outputs at o_(r+1)[key] + j)
+struct DescPlan {
+  unsigned long long at[40];  // round r's descriptors start at desc + at[r]
+};
+template <int LPK>
+__global__ void __launch_bounds__(1024)
+k_round_desc_all(const uint32_t* __restrict__ rp, uint32_t nkeys, int R, DescPlan plan, uint32_t* __restrict__ desc) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t key = gid / LPK, lane = gid % LPK;
+  if (key >= nkeys) return;
+  const size_t stride = (size_t)nkeys + 1;
+  for (int r = 1; r < R; ++r) {
+    const uint32_t* c = rp + (size_t)(2 * (r - 1)) * stride;
+    const uint32_t cr = c[key], o = c[stride + key], oo = c[3 * stride + key], nout = (cr + 1) >> 1;
+    uint32_t* d = desc + plan.at[r];
+    for (uint32_t j = lane; j < nout; j += LPK) d[oo + j] = (o + 2 * j) | ((2 * j + 1 < cr) ? DESC_PAIR : 0u);
+  }
+}
+
 template <int LPK>
 __global__ void __launch_bounds__(256)
 k_round_desc(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ ooff /* scan of ceil(cnt/2), nkeys+1 */,
-             uint32_t nkeys, uint2* __restrict__ desc) {
+             uint32_t nkeys, uint32_t* __restrict__ desc) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t key = gid / LPK, lane = gid % LPK;
   if (key >= nkeys) return;
   const uint32_t c = cnt[key], o = off[key], oo = ooff[key], nout = (c + 1) >> 1;
-  for (uint32_t j = lane; j < nout; j += LPK) {
-    const uint32_t i0 = o + 2 * j;
-    uint2 d;
-    d.x = i0;
-    d.y = (2 * j + 1 < c) ? i0 + 1 : AFF_NONE;
-    desc[oo + j] = d;
-  }
+  for (uint32_t j = lane; j < nout; j += LPK) desc[oo + j] = (o + 2 * j) | ((2 * j + 1 < c) ? DESC_PAIR : 0u);
 }
 
 // Thread t of T = ceil(total / B) owns output slots s = k*T + t, k < B (lane-consecutive slots: coalesced
@@ -1057,7 +1132,10 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
   auto ld_desc = [&](int k) -> uint2 {
     if (k < 0 || k >= B) return none;
     const uint32_t sk = (uint32_t)k * nthr + tid;
-    return sk < total ? desc[sk] : none;
+    if (sk >= total) return none;
+    if (FIRST) return desc[sk];
+    const uint32_t d = ((const uint32_t*)desc)[sk], a = d & ~DESC_PAIR;  // later rounds: one word per slot
+    return make_uint2(a, (d & DESC_PAIR) ? a + 1 : AFF_NONE);
   };
   const Gf one = gf_one();
   // pass 1: denominators and running product (x-coordinates only; y is touched when x1 == x2)
@@ -1701,9 +1779,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     }
     if (at > desc_n) desc_n = at;
   }
-  size_t o_gdesc = carve(affine_mode ? desc_n * sizeof(uint2) : 16);  // one (a, b) descriptor per output slot
+  size_t o_gdesc = carve(affine_mode ? desc_n * sizeof(uint32_t) : 16);  // one descriptor word per output slot
   size_t o_rp = carve(pipelined ? (size_t)ra_plan * 2 * ((size_t)p.nkeys + 1) * 4 : 16);  // (counts, offsets) of rounds 1 .. ra_plan
-  size_t o_bsum2 = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);                            // scan scratch of the side stream
+  size_t o_bsum2 = carve(((size_t)(ra_plan > 0 ? ra_plan : 1) * ((size_t)p.nkeys / SCAN_BLK + 1) + 8) * 4);  // scan scratch of the side stream: a row of block sums per round
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_rest = carve(((size_t)p.nkeys + 1) * 4);  // k_bucket_pairs' list of buckets with more than two entries
   size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
@@ -1735,7 +1813,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   Aff* affA = (Aff*)(base + o_affA);
   Aff* affB = (Aff*)(base + o_affB);
   Gf* prefix = (Gf*)(base + o_prefix);
-  uint2* gdesc = (uint2*)(base + o_gdesc);
+  uint32_t* gdesc = (uint32_t*)(base + o_gdesc);  // one word per output slot (rounds after the first)
   auto* rp = (uint32_t*)(base + o_rp);
   auto* bsum2 = (uint32_t*)(base + o_bsum2);
   Ld* tail = (Ld*)(base + o_tail);
@@ -1743,7 +1821,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const uint32_t nk = p.nkeys;
 
   // counts / offsets of round r's outputs (r >= 1) from those of its inputs, and its slot descriptors, on stream s
-  auto bookkeep = [&](int r, const uint32_t* ic, const uint32_t* io, uint32_t* oc, uint32_t* oo, uint2* dsc, hipStream_t s, uint32_t* bs) -> int {
+  auto bookkeep = [&](int r, const uint32_t* ic, const uint32_t* io, uint32_t* oc, uint32_t* oo, uint32_t* dsc, hipStream_t s, uint32_t* bs) -> int {
     DVP_TRY(scan_exclusive_div(ic, 2u, oc, oo, nk, bs, s));
     // descriptors: lanes per bucket by the average bucket size of this round
     const size_t per_key = (e_est >> (r + 1)) / nk;
@@ -1762,15 +1840,28 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto rc = [&](int r) -> uint32_t* { return r == 0 ? cnt : rp + (size_t)(2 * (r - 1)) * ((size_t)nk + 1); };
   auto ro = [&](int r) -> uint32_t* { return r == 0 ? off : rp + (size_t)(2 * (r - 1) + 1) * ((size_t)nk + 1); };
   int prepared = 0;  // pipelined: the bookkeeping of rounds < prepared is enqueued on the side stream (ev_side[0] = all of it is done)
-  auto prepare_rounds = [&]() -> int {  // call once (cnt, off) are final on `st`
+  auto prepare_rounds = [&]() -> int {  // call once the sort's counts (cnt) are final on `st`
     if (!pipelined) return DVP_OK;
     DVP_TRY(g_ws.ensure_side(1));
     DVP_HIP(hipEventRecord(g_ws.ev_pre, st));
     DVP_HIP(hipStreamWaitEvent(g_ws.side, g_ws.ev_pre, 0));
-    // round 0: even-aligned buckets -- the sorted item list is the descriptor array, the output offsets are the items' halved
-    hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, g_ws.side, rc(0), ro(0), nk, rc(1), ro(1));
-    for (int q = 1; q < ra_plan; ++q) DVP_TRY(bookkeep(q, rc(q), ro(q), rc(q + 1), ro(q + 1), gdesc + desc_at[q], g_ws.side, bsum2));
+    // (c_r, o_r), r = 1 .. ra_plan, in one three-launch scan (round 0's outputs included: its even-aligned buckets make the sorted
+    // item list the descriptor array, and the scan of ceil(c_0 / 2) is that list's offsets halved), then every round's descriptors
+    const uint32_t nb = cdiv(nk, SCAN_BLK);
+    hipLaunchKernelGGL(k_mscan_local, dim3(nb), dim3(SCAN_TPB), 0, g_ws.side, cnt, nk, ra_plan, rp, bsum2);
+    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, g_ws.side, bsum2, nb, nk, rp);
+    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, g_ws.side, rp, bsum2, nk, ra_plan);
+    DescPlan plan;
+    for (int q = 0; q < 40; ++q) plan.at[q] = q < ra_plan ? desc_at[q] : 0;
+    const size_t per_key = (e_est >> 2) / nk;  // round 1's outputs per bucket
+    if (per_key >= 48)
+      hipLaunchKernelGGL((k_round_desc_all<64>), dim3(cdiv((size_t)nk * 64, 1024)), dim3(1024), 0, g_ws.side, rp, nk, ra_plan, plan, gdesc);
+    else if (per_key >= 8)
+      hipLaunchKernelGGL((k_round_desc_all<16>), dim3(cdiv((size_t)nk * 16, 1024)), dim3(1024), 0, g_ws.side, rp, nk, ra_plan, plan, gdesc);
+    else
+      hipLaunchKernelGGL((k_round_desc_all<4>), dim3(cdiv((size_t)nk * 4, 1024)), dim3(1024), 0, g_ws.side, rp, nk, ra_plan, plan, gdesc);
     DVP_HIP(hipEventRecord(g_ws.ev_side[0], g_ws.side));
+    DVP_HIP(hipGetLastError());
     prepared = ra_plan;
     return DVP_OK;
   };
@@ -1813,8 +1904,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                          pstart, plo, pid);
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
     hipLaunchKernelGGL(k_hist_scan2, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, cstart, fb, chunk_off, cnt);
+    DVP_TRY(prepare_rounds());  // needs the counts only
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
-    DVP_TRY(prepare_rounds());
     if (staged2)
       hipLaunchKernelGGL(k_scatter_local2_staged, dim3(gmax), dim3(SORT_TPB), FX_STAGE2_LDS, st, plo, pid, pstart, cstart, fb, off,
                          chunk_off, hist16, items);
@@ -1825,8 +1916,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
     hipLaunchKernelGGL(k_hist_scan, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, nchunks, p.c, p.W, chunk_off, cnt);
+    DVP_TRY(prepare_rounds());  // needs the counts only
     DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
-    DVP_TRY(prepare_rounds());
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
     hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   }
@@ -1890,7 +1981,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto run_round = [&](int r) -> int {
     if (pipelined) {  // r < ra_plan always (ra <= ra_plan); everything a round needs was prepared behind the sort
       if (r == 0) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));
-      DVP_TRY(launch_round(r, ro(r + 1) + nk, r == 0 ? (const uint2*)items : (const uint2*)(gdesc + desc_at[r])));
+      DVP_TRY(launch_round(r, ro(r + 1) + nk, r == 0 ? (const uint2*)items : (const uint2*)(const void*)(gdesc + desc_at[r])));
       return DVP_OK;
     }
     const int nxt = (cur + 1) % 3;
@@ -1898,7 +1989,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
     else
       DVP_TRY(bookkeep(r, pc[cur], po[cur], pc[nxt], po[nxt], gdesc, st, bsum));
-    DVP_TRY(launch_round(r, po[nxt] + nk, r == 0 ? (const uint2*)items : (const uint2*)gdesc));
+    DVP_TRY(launch_round(r, po[nxt] + nk, r == 0 ? (const uint2*)items : (const uint2*)(const void*)gdesc));
     cur = nxt;
     return DVP_OK;
   };
