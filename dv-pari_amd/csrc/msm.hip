@@ -1768,6 +1768,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   // bookkeeping of ALL later rounds behind the first one (side stream, see below): every round keeps its own counts / offsets /
   // descriptors, so nothing the side stream writes is ever read by a round still in flight
   const bool pipelined = affine_mode && tn.msm_round_pipeline != 0 && ra_plan >= 2 && e_est >= 4 * (size_t)p.nkeys;
+  const bool side_stream = pipelined && tn.msm_round_pipeline == 1;
   std::vector<size_t> desc_at((size_t)ra_plan + 1, 0);  // round r's descriptors start at gdesc + desc_at[r] (r >= 1)
   size_t desc_n = affA_n + 64;
   if (pipelined) {
@@ -1830,37 +1831,46 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
 #undef DVP_DESC_LAUNCH
     return DVP_OK;
   };
-  // Round bookkeeping off the critical path (round 4).  A pair round's counts, offsets and slot descriptors depend on the bucket
-  // COUNTS only, never on the points.  With `pipelined` a side stream prepares ALL rounds -- each into arrays of its own -- as soon
-  // as the sort has scanned the counts, i.e. while the sort's last scatter (0.13-0.27 ms, HBM-bound) still runs, and the rounds then
-  // follow each other back to back (three 5 us scan launches and a descriptor kernel per round used to sit between them: ~0.35 ms
-  // per proof).  NOT while a pair round runs: a round is an exact number of chip-fulls, and a few workgroups of another kernel
-  // holding wave slots when it is dispatched push some of its workgroups into an extra pass (measured: +0.4 ms per MSM).
+  // Round bookkeeping in one piece (round 4).  A pair round's counts, offsets and slot descriptors depend on the bucket COUNTS only,
+  // never on the points, so all rounds are prepared at once -- arrays per round, four launches (k_mscan_*, k_round_desc_all) -- as
+  // soon as the sort has its counts, and the rounds then follow each other back to back (three 5 us scan launches and a descriptor
+  // kernel per round used to sit between them).  Where the four launches run (Tune::msm_round_pipeline):
+  //   2 (default)  on the caller's stream, before the sort's last scatter;
+  //   1            on a side stream beside that scatter (HBM-bound).  One proof at a time the two are equal within noise (bench.py's
+  //                configuration: 21.0-21.2 ms either way; only with every proof on the NULL stream did the side stream measure
+  //                0.1-0.17 ms better), and with two proofs in flight the side stream costs 1 ms per proof (21.0 against 19.4):
+  //                its workgroups land in the OTHER proof's pair rounds.  NEVER beside this MSM's own first round: a round is an
+  //                exact number of chip-fulls, and a few foreign workgroups holding wave slots when it is dispatched push some of
+  //                its workgroups into an extra pass (measured: +0.4 ms per MSM).
   // (rc(r), ro(r)) = counts / offsets of round r's INPUT; round 0's are the sort's.
   auto rc = [&](int r) -> uint32_t* { return r == 0 ? cnt : rp + (size_t)(2 * (r - 1)) * ((size_t)nk + 1); };
   auto ro = [&](int r) -> uint32_t* { return r == 0 ? off : rp + (size_t)(2 * (r - 1) + 1) * ((size_t)nk + 1); };
   int prepared = 0;  // pipelined: the bookkeeping of rounds < prepared is enqueued on the side stream (ev_side[0] = all of it is done)
   auto prepare_rounds = [&]() -> int {  // call once the sort's counts (cnt) are final on `st`
     if (!pipelined) return DVP_OK;
-    DVP_TRY(g_ws.ensure_side(1));
-    DVP_HIP(hipEventRecord(g_ws.ev_pre, st));
-    DVP_HIP(hipStreamWaitEvent(g_ws.side, g_ws.ev_pre, 0));
+    hipStream_t bk = st;  // Tune::msm_round_pipeline == 2: the same four launches on the caller's stream
+    if (side_stream) {
+      DVP_TRY(g_ws.ensure_side(1));
+      DVP_HIP(hipEventRecord(g_ws.ev_pre, st));
+      DVP_HIP(hipStreamWaitEvent(g_ws.side, g_ws.ev_pre, 0));
+      bk = g_ws.side;
+    }
     // (c_r, o_r), r = 1 .. ra_plan, in one three-launch scan (round 0's outputs included: its even-aligned buckets make the sorted
     // item list the descriptor array, and the scan of ceil(c_0 / 2) is that list's offsets halved), then every round's descriptors
     const uint32_t nb = cdiv(nk, SCAN_BLK);
-    hipLaunchKernelGGL(k_mscan_local, dim3(nb), dim3(SCAN_TPB), 0, g_ws.side, cnt, nk, ra_plan, rp, bsum2);
-    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, g_ws.side, bsum2, nb, nk, rp);
-    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, g_ws.side, rp, bsum2, nk, ra_plan);
+    hipLaunchKernelGGL(k_mscan_local, dim3(nb), dim3(SCAN_TPB), 0, bk, cnt, nk, ra_plan, rp, bsum2);
+    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, bk, bsum2, nb, nk, rp);
+    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, bk, rp, bsum2, nk, ra_plan);
     DescPlan plan;
     for (int q = 0; q < 40; ++q) plan.at[q] = q < ra_plan ? desc_at[q] : 0;
     const size_t per_key = (e_est >> 2) / nk;  // round 1's outputs per bucket
     if (per_key >= 48)
-      hipLaunchKernelGGL((k_round_desc_all<64>), dim3(cdiv((size_t)nk * 64, 1024)), dim3(1024), 0, g_ws.side, rp, nk, ra_plan, plan, gdesc);
+      hipLaunchKernelGGL((k_round_desc_all<64>), dim3(cdiv((size_t)nk * 64, 1024)), dim3(1024), 0, bk, rp, nk, ra_plan, plan, gdesc);
     else if (per_key >= 8)
-      hipLaunchKernelGGL((k_round_desc_all<16>), dim3(cdiv((size_t)nk * 16, 1024)), dim3(1024), 0, g_ws.side, rp, nk, ra_plan, plan, gdesc);
+      hipLaunchKernelGGL((k_round_desc_all<16>), dim3(cdiv((size_t)nk * 16, 1024)), dim3(1024), 0, bk, rp, nk, ra_plan, plan, gdesc);
     else
-      hipLaunchKernelGGL((k_round_desc_all<4>), dim3(cdiv((size_t)nk * 4, 1024)), dim3(1024), 0, g_ws.side, rp, nk, ra_plan, plan, gdesc);
-    DVP_HIP(hipEventRecord(g_ws.ev_side[0], g_ws.side));
+      hipLaunchKernelGGL((k_round_desc_all<4>), dim3(cdiv((size_t)nk * 4, 1024)), dim3(1024), 0, bk, rp, nk, ra_plan, plan, gdesc);
+    if (side_stream) DVP_HIP(hipEventRecord(g_ws.ev_side[0], g_ws.side));
     DVP_HIP(hipGetLastError());
     prepared = ra_plan;
     return DVP_OK;
@@ -1980,7 +1990,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   };
   auto run_round = [&](int r) -> int {
     if (pipelined) {  // r < ra_plan always (ra <= ra_plan); everything a round needs was prepared behind the sort
-      if (r == 0) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));
+      if (r == 0 && side_stream) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));
       DVP_TRY(launch_round(r, ro(r + 1) + nk, r == 0 ? (const uint2*)items : (const uint2*)(const void*)(gdesc + desc_at[r])));
       return DVP_OK;
     }
@@ -2032,7 +2042,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   if (pipelined && prepared) {
     // what the rounds left is described by the arrays of round `ra`: they head the ring of three the reducer works in
-    if (!launched) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));  // (not reached: a pipelined MSM always starts its first round early)
+    if (!launched && side_stream) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_side[0], 0));  // (not reached: a pipelined MSM always starts its first round early)
     pc[0] = rc(ra); po[0] = ro(ra);
     cur = 0;
   }
