@@ -304,12 +304,16 @@ def main():
         # the same proof through the host-pointer seam (dvp_prove = Proof::prove's signature, src/proving.rs:426: witness in
         # host memory, +32 B/wire of H2D)
         pv.prove(pub, prv)
-        t1 = time.perf_counter()
         reps = max(3, args.steps // 2)
         pub_l, prv_l = w_host[1:1 + len(pub)], w_host[1 + len(pub):]
+        host_times = []
         for _ in range(reps):
+            t1 = time.perf_counter()
             p2 = pv.prove(pub_l, prv_l)
-        host_ms = (time.perf_counter() - t1) / reps * 1e3
+            host_times.append((time.perf_counter() - t1) * 1e3)
+        # median: the 32 MB copy out of pageable host memory now and then takes tens of ms (one call in ~50: the runtime's staging),
+        # which says nothing about the seam
+        host_ms = sorted(host_times)[len(host_times) // 2]
         assert p2 == proof
         # the two ceilings of the dominant kernel: the multiplier alone, and random 64-byte gathers out of the table the
         # K-MSM's first pair round reads (the larger of the two tables)
