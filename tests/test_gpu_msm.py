@@ -264,6 +264,26 @@ def test_bucket_reduction_exceptional_pairs(dvp):
         fb.close()
 
 
+def test_merge_tree_equal_and_opposite_buckets(dvp):
+    """the merge tree's exceptional additions (k_merge, lambda-projective: equal operands are doubled from a copy read back,
+    opposite ones give infinity): bases P, P, Q, -Q with scalars 2, 3, 4, 5 put the SAME point into buckets 2 and 3 and opposite
+    points into buckets 4 and 5, which level 0 adds -- with few buckets (one quad per addition) and with 2^17 (one lane per
+    addition); then the same with the pairs one level up (scalars 4, 6 / 8, 10: buckets (4,5)+(6,7) and (8,9)+(10,11))"""
+    kp, kq = 0x1234567, 0x7654321
+    P, Q = co.k233_mulgen(kp), co.k233_mulgen(kq)
+    bases = pts_to_np([P, P, Q, o.k233_neg(Q)])
+    for sv in ([2, 3, 4, 5], [4, 6, 8, 10], [1, 1, 3, 3], [6, 7, 1 << 100, (1 << 100) + 1]):
+        exp = co.k233_mulgen(((sv[0] + sv[1]) * kp + (sv[2] - sv[3]) * kq) % o.P)
+        for c in (8, 18):
+            with dvp.tune(DVP_MSM_FIXED_C=c):
+                fb = dvp.curve.FixedBaseMsm(bases)
+            assert np_to_pt(*fb.run(to_limbs(sv))) == exp, (sv, c)
+            fb.close()
+        for c in (4, 12):
+            with dvp.tune(DVP_MSM_C=c):
+                assert gpu_msm(dvp, to_limbs(sv), bases) == exp, (sv, c)
+
+
 def test_points_add_like_curvepoint_add(dvp):
     """CurvePoint::add (src/curve.rs:84-90): generic, doubling, P + (-P), neutral on either side -- vs the oracle group law"""
     import pyref as o2
