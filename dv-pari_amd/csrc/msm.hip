@@ -160,21 +160,38 @@ k_recode_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict_
 // ---- exclusive scan of u32 (3 kernels; up to 4096*1024 elements) ---------------------------------
 constexpr int SCAN_TPB = 256, SCAN_EPT = 4, SCAN_BLK = SCAN_TPB * SCAN_EPT;
 
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* sh) {
-  // sh: 256 entries
-  int t = threadIdx.x;
-  sh[t] = v;
-  __syncthreads();
-  for (int o = 1; o < SCAN_TPB; o <<= 1) {
-    uint32_t x = (t >= o) ? sh[t - o] : 0;
-    __syncthreads();
-    sh[t] += x;
-    __syncthreads();
+// Exclusive scan of one value per thread over a block of NW waves (<= 16): wave-level inclusive scans by shuffles, the wave totals
+// scanned by the first wave, two barriers (+ one so that `sh` can be reused at once).  The first version was Hillis-Steele over the
+// whole block in LDS -- two barriers per doubling step, 16-20 barriers of 16 waves for a 1024-thread block -- and those barriers
+// were most of the 19 us a staged-scatter block took.  sh: >= 32 words.
+template <int NW>
+__device__ __forceinline__ uint32_t block_scan_waves(uint32_t v, uint32_t* total, uint32_t* sh) {
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, o);
+    if (lane >= o) x += y;
   }
-  uint32_t incl = sh[t];
-  *total = sh[SCAN_TPB - 1];
+  if (lane == 63) sh[w] = x;
   __syncthreads();
-  return incl - v;
+  if (w == 0) {
+    uint32_t z = lane < NW ? sh[lane] : 0u;
+#pragma unroll
+    for (int o = 1; o < NW; o <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)z, o);
+      if (lane >= o) z += y;
+    }
+    if (lane < NW) sh[16 + lane] = z;
+  }
+  __syncthreads();
+  const uint32_t base = w ? sh[16 + w - 1] : 0u;
+  *total = sh[16 + NW - 1];
+  __syncthreads();
+  return base + x - v;
+}
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* total, uint32_t* sh) {
+  return block_scan_waves<SCAN_TPB / 64>(v, total, sh);  // sh: 256 entries
 }
 
 // PAD2: every count is rounded up to even first (fixed-base sort: buckets then start at even positions of the sorted
@@ -500,19 +517,7 @@ k_scatter_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ 
 // histogram), then copies the staged chunk out in order: consecutive lanes hold consecutive entries of one bin, whose
 // destinations are consecutive, so every bin leaves as one coalesced run instead of as single-entry sector writes.
 __device__ __forceinline__ uint32_t block_scan_tpb(uint32_t v, uint32_t* sh, uint32_t* total) {
-  const int t = threadIdx.x;
-  sh[t] = v;
-  __syncthreads();
-  for (int o = 1; o < SORT_TPB; o <<= 1) {
-    uint32_t x = t >= o ? sh[t - o] : 0;
-    __syncthreads();
-    sh[t] += x;
-    __syncthreads();
-  }
-  uint32_t incl = sh[t];
-  *total = sh[SORT_TPB - 1];
-  __syncthreads();
-  return incl - v;
+  return block_scan_waves<SORT_TPB / 64>(v, total, sh);
 }
 constexpr unsigned FX_STAGE1_LDS = (2 * FX_NP_MAX + SORT_TPB + 2 * FX_CHUNK) * 4;
 constexpr unsigned FX_STAGE2_LDS = (2 * FX_NP_MAX + SORT_TPB + FX_CHUNK) * 4 + FX_CHUNK * 2;
