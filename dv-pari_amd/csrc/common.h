@@ -82,6 +82,7 @@ struct Tune {
   long long msm_bucket_pairs_max = 12;  // DVP_MSM_BUCKET_PAIRS_MAX: what the pair rounds leave goes through k_bucket_pairs / k_bucket_rest (one thread per bucket) when no bucket holds more points than this; above it, and with 0, through the fan-in-K reducer
   long long msm_sort_fused = 1;  // DVP_MSM_SORT_FUSED: level 1 of the signed flavour's sort recomputes the entry words from the scalars (0 = k_recode_signed writes them to HBM first)
   long long msm_round_pipeline = 2;  // DVP_MSM_ROUND_PIPELINE: bookkeeping of the pair rounds (counts / offsets / descriptors): 2 = all rounds at once, four launches on the caller's stream before the first round (default); 1 = the same on a side stream behind the sort's last scatter (equal one proof at a time, 1 ms slower with two in flight); 0 = per round, between the rounds
+  long long msm_hex_max = -1;   // DVP_MSM_HEX_MAX: merge levels up to this many additions use a row of 16 lanes each (-1 = default, 0 = never)
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables
   long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)

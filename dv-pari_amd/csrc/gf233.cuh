@@ -292,6 +292,94 @@ GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLdsQ& c) {
   return gf_mul_tab(a, c);
 }
 
+// ---- sixteen lanes per product (round 4: the deepest merge levels and the doubling tail) ----------------------------------------
+// A lone wave issues one VALU instruction every ~4.5 cycles whatever its lanes do, so a dependent product costs its INSTRUCTION
+// COUNT: ~450 for the quad form.  Here the 16 lanes of a DPP row hold the same operands and lane h = 4 kg + jg scans the comb
+// digits 3 kg .. 3 kg + 2 of the two words 2 jg, 2 jg + 1 of a only -- 6 lookups instead of 24 -- into a 10-word partial sum that sits
+// 9 kg bits and 2 jg words up.  The partial sums of equal jg are XOR-reduced over kg with two row rotations (by 4 and by 8 lanes) per
+// word; the four jg partials, which differ by whole words, are gathered with quad broadcasts at compile-time word offsets.  ~290
+// instructions; every lane of the row ends up with the product.  Each lane still keeps its own table copy (the LDS layout of the
+// quad form), and every lane of a row must be active.
+struct GfLdsH {
+  GfLds l;
+  uint32_t r;  // lane within its row of 16
+};
+GF_DEV GfLdsH gf_ldsh_init(char* lds_base) {
+  GfLdsH q;
+  q.l = gf_lds_init(lds_base);
+  q.r = threadIdx.x & 15u;
+  return q;
+}
+template <int CTRL>
+GF_DEV uint32_t gf_dpp(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xF, 0xF, true);
+}
+GF_DEV void gf_tab_build(const GfLdsH& c, const Gf& b) { gf_tab_build(c.l, b); }
+GF_DEV Gf gf_mul_tab(const Gf& a, const GfLdsH& c) {
+  const uint32_t kg = c.r >> 2, jg = c.r & 3u;
+  // the lane's two words of a, selected with masks (a ternary chain becomes an indexed load from a scratch copy of a)
+  const uint32_t m0 = 0u - (uint32_t)(jg == 0u), m1 = 0u - (uint32_t)(jg == 1u), m2 = 0u - (uint32_t)(jg == 2u), m3 = 0u - (uint32_t)(jg == 3u);
+  const uint32_t aw0 = (a.w[0] & m0) | (a.w[2] & m1) | (a.w[4] & m2) | (a.w[6] & m3);
+  const uint32_t aw1 = (a.w[1] & m0) | (a.w[3] & m1) | (a.w[5] & m2) | (a.w[7] & m3);
+  uint32_t acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0;
+#pragma unroll
+  for (int t = 2; t >= 0; --t) {
+    if (t != 2) {
+#pragma unroll
+      for (int i = 9; i > 0; --i) acc[i] = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], 29);
+      acc[0] <<= 3;
+    }
+    const uint32_t bit = 9u * kg + 3u * (uint32_t)t;                    // 3k; k = 11 (kg = 3, t = 2) does not exist
+    const uint32_t mask = (t == 2 && kg == 3u) ? 0u : 0x1C00u;
+    const uint32_t ad0 = (((aw0 >> (bit & 31u)) << 10) & mask) | c.l.lane_base;
+    const uint32_t ad1 = (((aw1 >> (bit & 31u)) << 10) & mask) | c.l.lane_base;
+    const gf_u32x4 lo0 = *(const gf_u32x4*)(c.l.lds + ad0), hi0 = *(const gf_u32x4*)(c.l.lds + ad0 + 8192);
+    const gf_u32x4 lo1 = *(const gf_u32x4*)(c.l.lds + ad1), hi1 = *(const gf_u32x4*)(c.l.lds + ad1 + 8192);
+    asm volatile("" ::: "memory");
+    acc[0] ^= lo0.x; acc[1] ^= lo0.y ^ lo1.x; acc[2] ^= lo0.z ^ lo1.y; acc[3] ^= lo0.w ^ lo1.z;
+    acc[4] ^= hi0.x ^ lo1.w; acc[5] ^= hi0.y ^ hi1.x; acc[6] ^= hi0.z ^ hi1.y; acc[7] ^= hi0.w ^ hi1.z;
+    acc[8] ^= hi1.w;
+  }
+  // the partial sum of group kg sits 9 kg bits up
+  const uint32_t sh = 32u - 9u * kg;
+  const bool k0 = kg == 0u;
+#pragma unroll
+  for (int i = 9; i > 0; --i) {
+    const uint32_t v = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], sh);
+    acc[i] = k0 ? acc[i] : v;
+  }
+  acc[0] = k0 ? acc[0] : (acc[0] << (9u * kg));
+  // over kg: lanes h, h + 4, h + 8, h + 12 of the row
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    acc[i] ^= gf_dpp<0x124>(acc[i]);  // row_ror:4
+    acc[i] ^= gf_dpp<0x128>(acc[i]);  // row_ror:8
+  }
+  // over jg: the partial of lane q of each quad sits 2 q words up
+  uint32_t f[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) f[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    f[i] ^= gf_dpp<0x00>(acc[i]);      // quad_perm [0,0,0,0]
+    f[2 + i] ^= gf_dpp<0x55>(acc[i]);  // [1,1,1,1]
+    f[4 + i] ^= gf_dpp<0xAA>(acc[i]);  // [2,2,2,2]
+    f[6 + i] ^= gf_dpp<0xFF>(acc[i]);  // [3,3,3,3]
+  }
+  return gf_reduce16(f);
+}
+GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLdsH& c) {
+  gf_tab_build(c.l, b);
+  return gf_mul_tab(a, c);
+}
+GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLdsH& c, Gf& r1, Gf& r2) {
+  gf_tab_build(c.l, b);
+  r1 = gf_mul_tab(a1, c);
+  r2 = gf_mul_tab(a2, c);
+}
+
 // two products against the same operand b: the table of b is built once
 GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLds& c, Gf& r1, Gf& r2) {
   gf_tab_build(c, b);

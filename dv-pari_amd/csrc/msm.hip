@@ -28,6 +28,7 @@
 #include <atomic>
 #include <chrono>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -741,6 +742,7 @@ k_dbl_table(const Aff* __restrict__ bases, uint32_t n, int c, int W, int n_narro
 constexpr int EC_TPB = 256;
 constexpr unsigned EC_LDS = (EC_TPB / 64) * GF_LDSK_BYTES_PER_WAVE;
 constexpr unsigned EC_LDS_Q = (EC_TPB / 64) * GF_LDS_BYTES_PER_WAVE;
+constexpr uint32_t MERGE_HEX_MAX = 8192;    // additions per level up to which 16 lanes per addition win: one chip-full of rows at two waves per SIMD (measured: 0 / 4096 / 8192 -> 21.01 / 20.94 / 20.87 ms per proof)
 constexpr uint32_t MERGE_QUAD_MAX = 16384;  // additions per level up to which 4 lanes per addition win (measured: 35 us vs 41 us at 16384)
 
 // ---- segmented reduction by fan-in K ----------------------------------------------------------------
@@ -1307,43 +1309,35 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 // reads every bucket exactly once (as the left or the right operand of its pair) and converts it on the way in -- (X, Y, Z) ->
 // (X^2, X^2 + Y, X Z), 1M + 1S -- so the right operand, which stays in place as D_0 of its block, is written back converted;
 // k_tail converts what it reads back to Lopez-Dahab (1M) for its doublings.
-template <bool QUAD, bool FIRST>
-__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(QUAD ? 1 : 2, 2))) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+// GROUP = lanes per addition: 1 (wide levels, Karatsuba multiplier), 4 (a quad, <= MERGE_QUAD_MAX additions) or 16 (a DPP row,
+// <= MERGE_HEX_MAX additions: the deepest levels are pure latency and a lone wave pays per instruction, gf233.cuh)
+template <class LT> struct MergeMul;
+template <> struct MergeMul<GfLdsK> { static __device__ __forceinline__ GfLdsK init(char* l) { return gf_ldsk_init(l); } static __device__ __forceinline__ bool lead(const GfLdsK&) { return true; } };
+template <> struct MergeMul<GfLdsQ> { static __device__ __forceinline__ GfLdsQ init(char* l) { return gf_ldsq_init(l); } static __device__ __forceinline__ bool lead(const GfLdsQ& c) { return c.r == 0; } };
+template <> struct MergeMul<GfLdsH> { static __device__ __forceinline__ GfLdsH init(char* l) { return gf_ldsh_init(l); } static __device__ __forceinline__ bool lead(const GfLdsH& c) { return c.r == 0; } };
+template <int GROUP, bool FIRST>
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GROUP > 1 ? 1 : 2, 2))) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+  using LT = typename std::conditional<GROUP == 1, GfLdsK, typename std::conditional<GROUP == 4, GfLdsQ, GfLdsH>::type>::type;
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (QUAD) tid >>= 2;
+  tid /= (uint32_t)GROUP;
   if (tid >= total) return;
   uint32_t blk = tid / (uint32_t)(j + 1), s = tid - blk * (uint32_t)(j + 1);
   size_t base = (size_t)blk << (j + 1);
   Ld l = A[base + s], r = A[base + ((size_t)1 << j) + s];
-  if (QUAD) {
-    GfLdsQ L = gf_ldsq_init(lds_raw);
-    if (FIRST) {  // j == 0
-      lam_from_ld(l, L);
-      lam_from_ld(r, L);
-    }
-    if (L.r == 0 && s == 0 && j != 1) A[base + 1 + j] = r;  // j = 0: the converted right operand; j = 1: T_right is in place already
-    if (!lam_add_ip(l, r, L)) {  // l == r (equal bucket sums: equal bases and scalars): double a copy read back
-      __threadfence_block();
-      l = A[base + s];
-      if (FIRST) lam_from_ld(l, L);
-      lam_dbl_ip(l, L);
-    }
-    if (L.r == 0) A[base + s] = l;
-  } else {
-    GfLdsK L = gf_ldsk_init(lds_raw);
-    if (FIRST) {
-      lam_from_ld(l, L);
-      lam_from_ld(r, L);
-    }
-    if (s == 0 && j != 1) A[base + 1 + j] = r;
-    if (!lam_add_ip(l, r, L)) {
-      l = A[base + s];
-      if (FIRST) lam_from_ld(l, L);
-      lam_dbl_ip(l, L);
-    }
-    A[base + s] = l;
+  LT L = MergeMul<LT>::init(lds_raw);
+  const bool lead = MergeMul<LT>::lead(L);  // the lane of the group that stores
+  if (FIRST) {  // j == 0
+    lam_from_ld(l, L);
+    lam_from_ld(r, L);
   }
+  if (lead && s == 0 && j != 1) A[base + 1 + j] = r;  // j = 0: the converted right operand; j = 1: T_right is in place already
+  if (!lam_add_ip(l, r, L)) {  // l == r (equal bucket sums: equal bases and scalars): double a copy read back
+    l = A[base + s];
+    if (FIRST) lam_from_ld(l, L);
+    lam_dbl_ip(l, L);
+  }
+  if (lead) A[base + s] = l;
 }
 
 // The whole Frobenius tail of an MSM in ONE single-workgroup launch: E[w*c+t] = tau^k(A[w*2^c + 1 + t]) with k = the first
@@ -1357,10 +1351,18 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(QUA
 // out_enc (optional): the result's 30-byte encoding under `rule` as well (what k_encode_point would make of out_xy): the affine
 // conversion and the encoding's 1 / x share ONE inversion, 1 / (X Z) -- a proof's two commitments are encoded right here instead
 // of after a host round trip, a launch and a second 45 us inversion chain.
+// HEX (round 4, the signed flavour's c points): a DPP row of 16 lanes per point instead of a quad -- the doublings, the add tree and the
+// final inversion are one dependent chain of ~140 products, and a lone wave pays per instruction (gf233.cuh: ~290 against ~450 per
+// product).  16 rows per workgroup: the points go out longest chain first, the few left over to the rows with the shortest ones.
+template <bool HEX>
 __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
                                                  uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf, uint8_t* __restrict__ out_enc, int rule) {
+  using LT = typename std::conditional<HEX, GfLdsH, GfLdsQ>::type;
+  constexpr int GS = HEX ? 4 : 2;             // log2 lanes per point
+  constexpr uint32_t NG = EC_TPB >> GS;       // points in flight per pass
   extern __shared__ char lds_raw[];
-  GfLdsQ L = gf_ldsq_init(lds_raw);
+  LT L = MergeMul<LT>::init(lds_raw);
+  const uint32_t grp = threadIdx.x >> GS;
   const uint32_t cnt0 = (uint32_t)(W * c);
   Ld* in = buf;
   Ld* out = buf + cnt0;
@@ -1368,7 +1370,11 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
     // signed aligned windows: t doublings of A[1 + t], one point per quad of lanes (a serial chain of <= c - 1 doublings at
     // 3 products + 5 squarings each); the last point is bucket 0 (the digits of magnitude 2^(c-1); saved at buf[2 cnt0] before
     // the merge turned slot 0 into the total)
-    for (uint32_t pt = threadIdx.x >> 2; pt < cnt0; pt += EC_TPB / 4) {
+    for (uint32_t q = 0; q * NG < cnt0; ++q) {
+      // point t needs t doublings: pass 0 hands the longest chains to groups 0, 1, ..; the next pass runs the other way round
+      const uint32_t idx = q * NG + ((q & 1u) ? NG - 1 - grp : grp);
+      if (idx >= cnt0) continue;  // whole groups skip together
+      const uint32_t pt = cnt0 - 1 - idx;
       Ld p = pt + 1 < cnt0 ? A[1 + pt] : buf[2 * cnt0];
       if (pt + 1 < cnt0) lam_to_ld(p, L);  // the merge tree's lambda-projective output; bucket 0 was saved before the tree (Lopez-Dahab)
 #pragma unroll 1
@@ -1389,10 +1395,9 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   }
   __syncthreads();
   uint32_t cnt = cnt0;
-  const uint32_t quad = threadIdx.x >> 2;
   while (cnt > 1) {
     const uint32_t half = (cnt + 1) / 2;
-    for (uint32_t i = quad; i < half; i += EC_TPB / 4) {  // whole quads take the same trips
+    for (uint32_t i = grp; i < half; i += NG) {  // whole groups take the same trips
       Ld a = in[2 * i];
       if (2 * i + 1 < cnt) ld_add_ip(a, in[2 * i + 1], L);
       if (L.r == 0) out[i] = a;
@@ -1401,7 +1406,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
     Ld* t = in; in = out; out = t;
     cnt = half;
   }
-  if (threadIdx.x >= 4) return;  // one quad: the inversion's products are a serial chain
+  if (threadIdx.x >= (1u << GS)) return;  // one group: the inversion's products are a serial chain
   Aff a;
   Ld p = in[0];
   const bool fin = !ld_is_inf(p);
@@ -1707,9 +1712,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
-                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<false, false>, (const void*)k_merge<true, false>, (const void*)k_merge<false, true>, (const void*)k_merge<true, true>,
+                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<1, false>, (const void*)k_merge<4, false>, (const void*)k_merge<16, false>, (const void*)k_merge<1, true>, (const void*)k_merge<4, true>, (const void*)k_merge<16, true>,
                           (const void*)k_affine_round<true, false>, (const void*)k_affine_round<false, false>, (const void*)k_affine_round<true, true>,
-                          (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail,
+                          (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail<false>, (const void*)k_tail<true>,
                           (const void*)k_bucket_pairs, (const void*)k_bucket_rest};
       for (const void* f : ec)
         if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_Q);
@@ -2109,21 +2114,23 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   for (int j = 0; j < merge_levels; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
-    if (total <= quad_max && j == 0)
-      hipLaunchKernelGGL((k_merge<true, true>), dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
-    else if (total <= quad_max)
-      hipLaunchKernelGGL((k_merge<true, false>), dim3(cdiv(4 * total, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, bkt, j, total);
-    else if (j == 0)
-      hipLaunchKernelGGL((k_merge<false, true>), dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
-    else
-      hipLaunchKernelGGL((k_merge<false, false>), dim3(cdiv(total, EC_TPB)), dim3(EC_TPB), EC_LDS, st, bkt, j, total);
+    const uint32_t hex_max = tn.msm_hex_max >= 0 ? (uint32_t)tn.msm_hex_max : MERGE_HEX_MAX;
+#define DVP_MERGE(G, F, LDSB) hipLaunchKernelGGL((k_merge<G, F>), dim3(cdiv((size_t)G * total, EC_TPB)), dim3(EC_TPB), LDSB, st, bkt, j, total)
+    if (total <= hex_max) { if (j == 0) DVP_MERGE(16, true, EC_LDS_Q); else DVP_MERGE(16, false, EC_LDS_Q); }
+    else if (total <= quad_max) { if (j == 0) DVP_MERGE(4, true, EC_LDS_Q); else DVP_MERGE(4, false, EC_LDS_Q); }
+    else { if (j == 0) DVP_MERGE(1, true, EC_LDS); else DVP_MERGE(1, false, EC_LDS); }
+#undef DVP_MERGE
   }
   const int w_tail = fx ? 1 : p.W;  // fixed-base mode has a single bucket set
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
   (void)cntT;
-  hipLaunchKernelGGL(k_tail, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
-                     (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0);
+  if (sign_mask && tn.msm_hex_max != 0)  // c points: one row of 16 lanes each
+    hipLaunchKernelGGL(k_tail<true>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, -3, Tsq, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf,
+                       (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0);
+  else
+    hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
+                       (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0);
   ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
