@@ -1395,7 +1395,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   }
   __syncthreads();
   uint32_t cnt = cnt0;
-  while (cnt > 1) {
+  while (cnt > 1 && (HEX || (cnt + 1) / 2 > EC_TPB / 16)) {  // quad variant: while a level has more additions than the block has rows
     const uint32_t half = (cnt + 1) / 2;
     for (uint32_t i = grp; i < half; i += NG) {  // whole groups take the same trips
       Ld a = in[2 * i];
@@ -1406,7 +1406,22 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
     Ld* t = in; in = out; out = t;
     cnt = half;
   }
-  if (threadIdx.x >= (1u << GS)) return;  // one group: the inversion's products are a serial chain
+  // the last levels (<= 16 additions) and the conversion run on rows of 16 lanes in both variants (same LDS tables)
+  GfLdsH H;
+  H.l = L.l;
+  H.r = threadIdx.x & 15u;
+  while (cnt > 1) {
+    const uint32_t half = (cnt + 1) / 2;
+    for (uint32_t i = threadIdx.x >> 4; i < half; i += EC_TPB / 16) {
+      Ld a = in[2 * i];
+      if (2 * i + 1 < cnt) ld_add_ip(a, in[2 * i + 1], H);
+      if (H.r == 0) out[i] = a;
+    }
+    __syncthreads();
+    Ld* t = in; in = out; out = t;
+    cnt = half;
+  }
+  if (threadIdx.x >= 16) return;  // one row: the inversion's products are a serial chain
   Aff a;
   Ld p = in[0];
   const bool fin = !ld_is_inf(p);
@@ -1416,19 +1431,19 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   if (fin) {
     if (out_enc && !gf_is_zero(p.X)) {
       // x = X / Z, y = Y / Z^2, y / x = Y / (X Z): everything from inv = 1 / (X Z)
-      const Gf inv = gf_inv_fast(gf_mul(p.X, p.Z, L), T, L);
-      const Gf zi = gf_mul(inv, p.X, L);
-      a.x = gf_mul(p.X, zi, L);
-      a.y = gf_mul(p.Y, gf_sqr(zi), L);
-      const Gf lam1 = gf_add(gf_add(a.x, gf_mul(p.Y, inv, L)), gf_one());
+      const Gf inv = gf_inv_fast(gf_mul(p.X, p.Z, H), T, H);
+      const Gf zi = gf_mul(inv, p.X, H);
+      a.x = gf_mul(p.X, zi, H);
+      a.y = gf_mul(p.Y, gf_sqr(zi), H);
+      const Gf lam1 = gf_add(gf_add(a.x, gf_mul(p.Y, inv, H)), gf_one());
       w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
       if (rule) w = codec_present(w, rule, T);
     } else {
-      Gf zi = gf_inv_fast(p.Z, T, L);
-      a.x = gf_mul(p.X, zi, L);
-      a.y = gf_mul(p.Y, gf_sqr(zi), L);
+      Gf zi = gf_inv_fast(p.Z, T, H);
+      a.x = gf_mul(p.X, zi, H);
+      a.y = gf_mul(p.Y, gf_sqr(zi), H);
       if (out_enc) {  // x = 0 (the point of order two): the same formula as k_encode_point, where 1 / 0 reads 0
-        const Gf lam1 = gf_add(gf_add(a.x, gf_mul(a.y, gf_inv_fast(a.x, T, L), L)), gf_one());
+        const Gf lam1 = gf_add(gf_add(a.x, gf_mul(a.y, gf_inv_fast(a.x, T, H), H)), gf_one());
         w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
         if (rule) w = codec_present(w, rule, T);
       }
@@ -1639,6 +1654,11 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
     double cost = W * (8.4 * (double)n + 28.0 * (double)(1u << c));
     if (cost < best) { best = cost; p.c = c; }
   }
+  // 2^15 .. 2^17 points are latency all the way (config #2: ~45 dependent launches): with the round-4 chains (lambda-projective merge,
+  // 16 lanes per product in the deep levels and the tail) two merge levels fewer beat the model's window -- tools/small_msm_sweep.py,
+  // c = 10 / K = 8 against the model's c = 12 / K = 4: 1.43 against 1.63 ms at 2^16, 1.82 against 2.02 ms at 2^17 (2^14 and 2^18: no difference)
+  const bool small_latency = !fixed && n >= ((size_t)1 << 15) && n <= ((size_t)1 << 17);
+  if (small_latency) p.c = 10;
   if (tune().msm_c >= 2 && tune().msm_c <= 15) p.c = (int)tune().msm_c;
   p.W = windows(p.c, &p.n_narrow);
   p.nkeys = (uint32_t)p.W << p.c;
@@ -1656,6 +1676,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   // small inputs (config #2's 2^16 points: ~1.5 M entries) are chain latency in the reducer as well: 2^16 .. 2^18 points run
   // 5-10 % faster with three additions per task than with seven (tools/small_msm_sweep.py)
   if (!fixed && n <= ((size_t)1 << 18)) K = 4;
+  if (small_latency) K = 8;
   // fixed-base mode: the reducer only sees what the pair rounds leave (<= ~20 entries in the fullest buckets) and is pure
   // chain latency there: two levels of <= 7 additions beat one of <= 15 (2^20 prove: 24.26 against 24.58 ms)
   if (fixed) K = 8;
