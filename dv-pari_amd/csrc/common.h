@@ -73,7 +73,7 @@ struct Tune {
   long long msm_aff_min = 1ll << 19;   // DVP_MSM_AFF_MIN: pair rounds run while a round has this many additions
   long long msm_gate_min = 1;   // DVP_MSM_GATE_MIN: pair rounds with at least this many additions take turns between concurrent MSMs (HeavyGate); smaller ones overlap
   long long msm_ws_slots = 2;   // DVP_MSM_WS_SLOTS: MSMs that may run at the same time on one device (1 or 2 workspaces; their pair rounds still take turns, HeavyGate)
-  long long cache_replicas = 2;  // DVP_CACHE_REPLICAS: provers dvp_prove_cache_dir may hold per cache_dir (2: a second one is opened when two callers overlap)
+  long long cache_replicas = 1;  // DVP_CACHE_REPLICAS: provers dvp_prove_cache_dir may hold per cache_dir (1 = callers take turns on one prover, the default since the end of round 4: with the witness in host memory a second prover's latency chains land in the first one's pair rounds and two callers got 23.3-23.8 ms per proof where taking turns gives 21.2-21.4; 2 = a second one is opened when two callers overlap)
   long long msm_aff_tpb = 256;  // DVP_MSM_AFF_TPB: workgroup size of the pair rounds (64, 128 or 256)
   long long msm_aff_bmin = 8;   // DVP_MSM_AFF_BMIN: fewest slots a round thread owns (small rounds then use fewer threads, each sharing its inversion among more additions)
   long long msm_aff_bmax = 48;  // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns

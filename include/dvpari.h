@@ -316,11 +316,12 @@ int dvp_ecfft_check_tree_file(dvp_ecfft* tree, const char* path, int matrices, i
 int dvp_prover_open_cache_dir(const char* cache_dir, uint32_t n_public, dvp_prover** out);
 /* Proof::prove(cache_dir, public_inputs, private_inputs) itself: opens cache_dir on first use and keeps the prover in
  * a process-wide table keyed by (cache_dir, n_public, current HIP device); dvp_cache_dir_release(NULL) drops every entry.
- * Thread safety: concurrent calls are allowed; one prover = one set of device buffers, so an entry opens a SECOND prover
- * from the same files when two calls on it overlap after the first prover has completed a proof AND free device memory
- * exceeds 1.25 x what is in use (two proofs in flight on the GPU; DVP_CACHE_REPLICAS=1 in the environment turns that
- * off); callers take whichever prover frees first and otherwise wait; a release during a prove takes effect when that
- * prove returns.  Files that change on disk after the first
+ * Thread safety: concurrent calls are allowed; one prover = one set of device buffers, so concurrent callers of one entry take
+ * turns on it (the default).  With DVP_CACHE_REPLICAS=2 in the environment an entry opens a SECOND prover from the same files
+ * when two calls on it overlap after the first prover has completed a proof AND free device memory exceeds 1.25 x what is in
+ * use (two proofs in flight on the GPU), callers taking whichever prover frees first; measured at the end of round 4 that is
+ * SLOWER than taking turns when the witness comes from host memory, so it is opt-in.  A release during a
+ * prove takes effect when that prove returns.  Files that change on disk after the first
  * call are not re-read: release the entry first.  Only SRS files whose 30-byte encodings follow this library's codec
  * rule are supported until that rule is pinned against xs233 (tools/pin_xsk233.py). */
 int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public_inputs, uint32_t n_public, const uint64_t* private_inputs,
