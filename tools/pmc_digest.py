@@ -17,7 +17,7 @@ for k, cs in acc.items():
     out[k] = {"launches": n, "total_ms": tot, "avg_ms": tot / max(len(dur[k]), 1)}
     for c, v in cs.items():
         out[k][c] = sum(v) / len(v)
-top = sorted(out.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
+top = sorted(out.items(), key=lambda kv: -kv[1]["total_ms"])[:int(os.environ.get("PMC_TOP", "12"))]
 for k, v in top:
     print(k[:40], json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items()}))
 json.dump(out, open(os.path.join(d, "digest.json"), "w"), indent=1)
