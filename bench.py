@@ -45,7 +45,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
                  "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
                  "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE", "OMP_NUM_THREADS")
@@ -81,7 +81,7 @@ def cpu_mhz() -> float:
 
 
 def load_profile(name):
-    for tag in (PROFILE_TAG, "r03"):
+    for tag in (PROFILE_TAG, "r04", "r03"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json")))
             d["_profile_tag"] = tag
@@ -215,7 +215,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        if args.inproc:
+        # one GPU: Proof::prove itself (dvp_prove_dev: the drop-in entry with the witness resident; rounds 1-4 timed the PHASED entries
+        # here -- begin / msm_partial / challenge / msm_partial / finish, what a rank of a sharded proof calls -- which wait for the
+        # host five times per proof where dvp_prove_dev waits once); N ranks: the phased entries with the MSMs sharded
+        if args.inproc or world == 1:
             return pv.prove_dev(assignment.data_ptr(), stream)
         return dvp.distributed.prove_sharded(gpu_backend, assignment)
 
@@ -254,6 +257,10 @@ def main():
         dvp.check(dvp.lib.dvp_profile_read(name.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    try:
+        host_waits = {"stream": prof("host_waits_stream")[1] / args.steps, "side_stream": prof("host_waits_side")[1] / args.steps}
+    except Exception:  # an older build of the library (DVP_LIB A/B runs) has no such counters
+        host_waits = None
     acc_ms, acc_n = prof("msm_affine_round0")
     rest_ms, _ = prof("msm_affine_rest")
     sort_ms, _ = prof("msm_sort")
@@ -297,7 +304,7 @@ def main():
     extras = single and not args.no_extras
 
     # ---- outside the timed region ---------------------------------------------------------------------------------------
-    host_ms = mul_rate = gather_rate = None
+    host_ms = mul_rate = gather_rate = fr_rate = ms_one_shot = cold = ecfft_live = None
     msm_standalone = None
     in_flight = None
     if extras:
@@ -352,6 +359,81 @@ def main():
                         best = dt
                 msm_standalone[f"2^{lg}"] = {"ms": best * 1e3, "mpoints_per_s": n_pts / best / 1e6}
             del d_bases, d_sc
+        # the ECFFT's multiplier alone (ceiling of the work model of extend / enter / exit)
+        dvp.check(dvp.lib.dvp_ubench_fr_mul(400, C.byref(r)), "dvp_ubench_fr_mul")
+        fr_rate = r.value
+        # BASELINE config #3, live: 2^20-coefficient enter / exit round trip and the prover's own op, extend (x4 vectors, m = 2^20)
+        if log_m >= 20:
+            n3 = 1 << 20
+            t3 = dvp.ec_fft.FFTree(n3)
+            rng3 = np.random.default_rng(3)
+            c3 = rng3.integers(0, 2**62, size=(n3, 4), dtype=np.uint64)
+            c3[:, 3] &= np.uint64((1 << 38) - 1)
+            d_in = torch.from_numpy(c3.view(np.int64)).to(dev)
+            d_ev, d_back = torch.empty_like(d_in), torch.empty_like(d_in)
+
+            def timeit(f, reps=3):
+                f()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    f()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / reps * 1e3
+            ms_enter = timeit(lambda: t3.enter_dev(d_in.data_ptr(), d_ev.data_ptr(), stream))
+            t3.exit_dev(d_ev.data_ptr(), d_back.data_ptr(), stream)  # first call bootstraps the exit tables
+            ms_exit = timeit(lambda: t3.exit_dev(d_ev.data_ptr(), d_back.data_ptr(), stream))
+            round_trip_exact = bool((d_back == d_in).all().item())
+            t3.close()
+            t6 = dvp.ec_fft.FFTree(2 * n3)
+            x4 = d_in.reshape(1, n3, 4).repeat(4, 1, 1).contiguous()
+            y4 = torch.empty_like(x4)
+            ms_ext4 = timeit(lambda: t6.extend_dev(x4.data_ptr(), 4, y4.data_ptr(), stream))
+            t6.close()
+            del d_in, d_ev, d_back, x4, y4
+            ecfft_live = {"n": n3, "enter_ms": ms_enter, "exit_ms": ms_exit, "extend_x4_ms": ms_ext4, "round_trip_exact": round_trip_exact}
+            assert round_trip_exact, "exit(enter(c)) != c"
+        # the same proof WITHOUT the fixed-base tables (one-shot MSMs over the decoded bases: what a prover that keeps nothing but the
+        # SRS between calls would run)
+        with dvp.tune(DVP_MSM_FIXED_MIN=1 << 40):
+            assert pv.prove_dev(assignment.data_ptr(), stream) == proof, "one-shot-MSM proof differs"
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                pv.prove_dev(assignment.data_ptr(), stream)
+            torch.cuda.synchronize()
+            ms_one_shot = (time.perf_counter() - t1) / 3 * 1e3
+        # the COLD call: Proof::prove(cache_dir, ..) from a fresh process (tools/cold_call.py) on a directory written here with the
+        # same trapdoor -- R1CS dump + five SRS point files read, 6 m points decoded, tables built, one proof
+        cold = None
+        if os.environ.get("DVP_BENCH_NO_COLD") != "1":
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="dvp_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                inst.write_dump_file(os.path.join(tmp, dvp.artifacts.R1CS_CONSTRAINTS_FILE))
+                nat = importlib.import_module("dv-pari_amd._native")
+                t_, d_, e_ = (dvp.fr.limbs(x) for x in (td.tau, td.delta, td.epsilon))
+                t1 = time.perf_counter()
+                dvp.check(dvp.lib.dvp_setup_cache_dir(nat.ptr(t_), nat.ptr(d_), nat.ptr(e_), os.fsencode(tmp), len(pub), 0), "dvp_setup_cache_dir")
+                setup_s = time.perf_counter() - t1
+                np.save(os.path.join(tmp, "witness.npy"), w_host)
+                env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+                rr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_call.py"), tmp, os.path.join(tmp, "witness.npy"), str(len(pub))],
+                                    capture_output=True, text=True, env=env, timeout=240)
+                lines = [l for l in rr.stdout.splitlines() if l.startswith("{")]
+                if rr.returncode == 0 and lines:
+                    cold = json.loads(lines[-1])
+                    cold["same_bytes_as_timed_proof"] = cold.pop("proof_hex") == proof.to_bytes().hex()
+                    cold["setup_cache_dir_s"] = setup_s
+                    cold["files_mb"] = round(sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp) if f != "witness.npy") / 1e6, 1)
+                    assert cold["same_bytes_as_timed_proof"], "the cold dvp_prove_cache_dir proof differs from the timed loop's"
+                else:
+                    cold = {"error": (rr.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+            except Exception as ex:  # the leg is an extra: report, do not fail the line
+                cold = {"error": repr(ex)[:300]}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
         # throughput with TWO proofs in flight on this GPU: a second prover (own tables, own stream, own host thread) over the same
         # circuit; the library lets the two MSMs overlap everything but their pair rounds (msm.hip: HeavyGate).  Every proof is
         # compared with the timed loop's bytes.  Not the headline: `value` stays one proof at a time.  The leg is skipped only on a
@@ -495,6 +577,45 @@ def main():
     sq = load_profile("pmc_sq_k_affine_round0")
     if sq and log_m == 20 and n_shards == 1:
         roof["issue"] = sq
+    # the OTHER half of the pair-round time: k_affine_round<false>, the later rounds (same code, coalesced inputs).  Live: HIP-event
+    # total and launches of this run; per round (additions, bytes, clock, issue rate): the committed request-level / SQ passes
+    rounds_prof = load_profile("pmc_pair_rounds_by_round")
+    later_launches = prof("msm_affine_rest")[1]
+
+    def later_additions(pairs, c):  # rounds 1 .. : round r adds entries / 2^(r+1) pairs, and runs while that is >= 2^19 (Tune::msm_aff_min)
+        e, tot, r = pairs * per_scalar(c, True) / n_shards, 0.0, 1
+        while e / 2 ** (r + 1) >= (1 << 19):
+            tot += e / 2 ** (r + 1)
+            r += 1
+        return tot
+    later_adds = sum(later_additions(n, c) for (c, _), n in zip(plans, sizes)) if all(c for c, _ in plans) else 0.0  # per proof
+    later_s = rest_ms / args.steps * 1e-3
+    roof["later_rounds"] = {
+        "kernel": "dvp::k_affine_round<false> (pair rounds after the first: inputs are the previous round's outputs, read in slot order)",
+        "ms_per_step": rest_ms / args.steps, "launches_per_step": later_launches / args.steps,
+        "additions_per_step": later_adds,
+        "algorithmic_bytes_per_addition": 128.0,
+        "algorithmic_note": "a later round reads two 64-byte points per addition (and writes one): 128 B read is the figure used; the shared-inversion "
+                            "design reads each point twice and parks a 32-byte prefix product -- ~400 B per addition measured (by_round)",
+        "achieved_gb_s": later_adds * 128.0 / later_s / 1e9 if later_s else None,
+        "frac_of_hbm_peak": later_adds * 128.0 / later_s / 1e9 / 8000.0 if later_s else None,
+        "work_model_frac": (later_adds * (5.13 + 15.0 / 16.0) / later_s) / mul_rate if (mul_rate and later_s) else None,
+        "work_model_note": "5 products + 1 squaring + 1/B of an inversion per addition, B = 48 .. 8 slots per thread over the rounds (15/16 product-"
+                           "equivalents of inversion share on average), against dvp_ubench_gf_mul of this run",
+    }
+    if rounds_prof and log_m == 20 and n_shards == 1:
+        roof["later_rounds"]["by_round"] = [
+            {"msm": msm["which"], **{k: r[k] for k in ("round", "kernel", "additions", "ms_under_pmc", "additions_per_s", "read_requests_per_addition",
+                                                         "traffic_bytes_per_addition", "traffic_tb_per_s", "l2_hit_rate", "effective_clock_ghz",
+                                                         "valu_insts_per_simd_cycle", "resident_wave_frac", "valu_insts_per_addition")}}
+            for msm in rounds_prof["msms"] for r in msm["rounds"]]
+        roof["later_rounds"]["by_round_source"] = f"profiles/{rounds_prof['_profile_tag']}_pmc_pair_rounds_by_round.json (committed rocprofv3 --pmc passes; not measured in this run)"
+        roof["later_rounds"]["reading"] = rounds_prof.get("reading")
+    g64 = load_profile("gather64_load_forms")
+    if g64:
+        roof["request_size_experiment"] = {"source": f"profiles/{g64['_profile_tag']}_gather64_load_forms.json (tools/ubench/gather64.hip under rocprofv3 --pmc)",
+                                           "fabric_read_bytes_per_64_byte_point": {v["variant"]: round(v["fabric_read_bytes_per_point"], 1) for v in g64["variants"]},
+                                           "reading": g64["reading"]}
     out = {
         "metric": "R1CS constraints/sec (prove)",
         "value": value,
@@ -521,8 +642,16 @@ def main():
             "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "signed_windows": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
                             "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "signed_windows": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
             "witness": "resident in HBM",
+            "entry": "dvp_prove_dev (Proof::prove with the witness resident)" if (args.inproc or world == 1) else "phased entries, MSMs sharded over the ranks",
             "proofs_in_flight": 1,
             "latency_ms_one_proof": ms_per_step,
+            "ms_per_step_one_shot_msm": ms_one_shot,
+            "ms_per_step_one_shot_msm_note": "the same proof with the fixed-base tables switched off (DVP_MSM_FIXED_MIN): one-shot MSMs over the decoded bases",
+            "cold_call_s": (cold or {}).get("cold_call_s"),
+            "cold_call": cold,
+            "cold_call_note": "first dvp_prove_cache_dir(cache_dir, public, private) of a FRESH process (tools/cold_call.py) on a directory written in this run "
+                              "with the same trapdoor: R1CS dump + five SRS point files read (page cache), 6 m points decoded on the GPU, both fixed-base tables "
+                              "built, one proof, bytes compared with the timed loop's; second_call_s is the same call again",
             "constraints_per_s_two_in_flight": (in_flight or {}).get("constraints_per_s"),
         },
         "hbm_resident_gb": hbm_resident_gb,
@@ -532,6 +661,10 @@ def main():
                        "rounds 2-3, 94-97 GB at this size for the same proof time, were removed in round 4)",
         "ms_per_step_host_witness": host_ms,
         "throughput_two_in_flight": in_flight,
+        "host_waits_per_proof": host_waits,
+        "host_waits_note": "stream = synchronisations of the proof's own stream (the GPU idles until the host has reacted): ONE per proof since round 5, the "
+                           "K MSM's final one, which brings [a0 b0 i0 r0 | flags | both encodings | alpha] along -- the transcript (BLAKE3, Z(alpha)) runs on "
+                           "the device; side_stream = an MSM's read of its largest bucket, taken on a side stream while its first pair round runs",
         "roofline": roof,
         "stages_ms_per_step": {
             "msm_total": msm_ms / args.steps,
@@ -544,6 +677,64 @@ def main():
         "msm_mpoints_per_s": (pairs_total / (msm_ms * 1e-3) / 1e6) if msm_ms else None,
         "msm_standalone": msm_standalone,
     }
+    # ---- every BASELINE config against its own algorithmic bytes, so that a reader of this line and profiles/ can recompute a fraction
+    by_cfg = {}
+    if msm_standalone and "2^16" in msm_standalone:
+        t16 = msm_standalone["2^16"]["ms"] * 1e-3
+        by_cfg["config_2_msm_2p16"] = {"ms": msm_standalone["2^16"]["ms"], "algorithmic_bytes": 96.0 * 65536, "achieved_gb_s": 96.0 * 65536 / t16 / 1e9,
+                                       "frac_of_hbm_peak": 96.0 * 65536 / t16 / 1e9 / 8000.0, "bound": "latency (a chain of ~40 dependent launches; 6.3 MB of input)",
+                                       "profile": f"profiles/{PROFILE_TAG}_msm_2p16_kernel_stats.csv"}
+    if ecfft_live:
+        n3 = ecfft_live["n"]
+        lg3 = n3.bit_length() - 1
+        ent_b, ext_b, x4_b = 320.0 * n3 * lg3, 640.0 * n3 * lg3, (64.0 * 4 + 256.0) * n3
+        ent_w, x4_w = n3 * lg3 * lg3 / 2.0 * 2, 4 * 2.0 * n3 * lg3  # multiply-adds: an extend of m values is 2 m log2(m); enter(n) = sum over levels of 2 extends of half size
+        by_cfg["config_3_ecfft_2p20"] = {
+            "enter": {"ms": ecfft_live["enter_ms"], "algorithmic_bytes": ent_b, "achieved_gb_s": ent_b / (ecfft_live["enter_ms"] * 1e-3) / 1e9,
+                      "frac_of_hbm_peak": ent_b / (ecfft_live["enter_ms"] * 1e-3) / 1e9 / 8000.0,
+                      "work_model_frac": (ent_w / (ecfft_live["enter_ms"] * 1e-3)) / fr_rate if fr_rate else None},
+            "exit": {"ms": ecfft_live["exit_ms"], "algorithmic_bytes": ext_b, "achieved_gb_s": ext_b / (ecfft_live["exit_ms"] * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": ext_b / (ecfft_live["exit_ms"] * 1e-3) / 1e9 / 8000.0,
+                     "work_model_frac": (2 * ent_w / (ecfft_live["exit_ms"] * 1e-3)) / fr_rate if fr_rate else None},
+            "extend_x4": {"ms": ecfft_live["extend_x4_ms"], "algorithmic_bytes": x4_b, "achieved_gb_s": x4_b / (ecfft_live["extend_x4_ms"] * 1e-3) / 1e9,
+                          "frac_of_hbm_peak": x4_b / (ecfft_live["extend_x4_ms"] * 1e-3) / 1e9 / 8000.0,
+                          "work_model_frac": (x4_w / (ecfft_live["extend_x4_ms"] * 1e-3)) / fr_rate if fr_rate else None},
+            "round_trip_exact": ecfft_live["round_trip_exact"],
+            "bytes_note": "SURVEY 8d: extend(m) = 64 m per vector + 256 m of butterfly constants; enter(n) = log2(n) x 320 n, exit(n) = twice that",
+            "work_note": "multiply-adds r = a b / R' + c on 30-bit limbs (2 per butterfly) against dvp_ubench_fr_mul of this run: the ECFFT is bound by the half-rate "
+                         "v_mad_u64_u32, not by HBM",
+            "fr_multiplier_muladds_per_s": fr_rate, "profile": f"profiles/{PROFILE_TAG}_config3_ecfft_2p20_kernel_stats.csv"}
+    if ext_ms and fr_rate:
+        n_ext_v = 3
+        by_cfg["config_4_prove_2p%d" % log_m] = {
+            "ms_per_step": ms_per_step, "algorithmic_bytes_per_constraint": 2400.0, "achieved_gb_s": 2400.0 * m / (ms_per_step * 1e-3) / 1e9,
+            "frac_of_hbm_peak": 2400.0 * m / (ms_per_step * 1e-3) / 1e9 / 8000.0,
+            "extends": {"vectors": n_ext_v, "ms_per_step": ext_ms / args.steps, "algorithmic_bytes": (64.0 * n_ext_v + 256.0) * m,
+                        "frac_of_hbm_peak": (64.0 * n_ext_v + 256.0) * m / (ext_ms / args.steps * 1e-3) / 1e9 / 8000.0,
+                        "work_model_frac": (n_ext_v * 2.0 * m * log_m / (ext_ms / args.steps * 1e-3)) / fr_rate},
+            "bound": "GF(2^233) products of the two MSMs' pair rounds (roofline.work_model / roofline.later_rounds)"}
+    for key, name in (("config_5_sparse_2p22", "config5_sparse_2p22"), ("setup_2p20", "setup_2p20")):
+        try:
+            txt = [l.strip() for l in open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.log")) if l.strip()]
+            by_cfg[key] = {"source": f"profiles/{PROFILE_TAG}_{name}.log + _kernel_stats.csv (committed rocprofv3 --kernel-trace --stats run; not measured in this run)",
+                           "result_lines": [l for l in txt if ("ms per proof" in l or "dvp_setup_cache_dir" in l or "prepares_precomputes" in l or l.startswith("setup ") or "rows" in l)][:8]}
+        except Exception:
+            pass
+    out["roofline_by_config"] = by_cfg
+    # ---- the committed profiles: taken at which sources?
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import profile_stamp
+        cur = profile_stamp.source_sha16(ROOT)
+        st_ = json.load(open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_profile_stamp.json")))
+        out["profiles"] = {"tag": PROFILE_TAG, "profile_source_sha16": st_["source_sha16"], "current_source_sha16": cur,
+                           "sources_match": st_["source_sha16"] == cur, "profile_commit": st_.get("git_head_when_digested"),
+                           "warning": None if st_["source_sha16"] == cur else "the committed counters (roofline.traffic / issue / later_rounds.by_round) were taken at OTHER kernel sources than this run's"}
+    except Exception as ex:
+        out["profiles"] = {"tag": PROFILE_TAG, "warning": f"no profile stamp: {ex!r}"[:200]}
+    out["scaling_measured"] = bool(world > 1 or n_dev_inproc > 1)
+    if not out["scaling_measured"]:
+        out["scaling_note"] = "one GPU: no multi-GPU figure is part of this line (python bench.py --gpus N shards both MSMs over N ranks; the builder's boxes have one GPU)"
     if dist_info:
         out.update(dist_info)
         out["ms_per_step_ranks"] = rank_ms
@@ -618,11 +809,18 @@ def main():
 
         def cpu_end_to_end(log_e):
             me = 1 << log_e
-            inst_e, pub_e, prv_e = dvp.gnark_r1cs.synthetic_dense(log_e)
-            pv_e = dvp.proving.Prover(inst_e)
+            own = log_e != log_m  # at the bench size the timed prover, its circuit and its SRS are reused
+            if own:
+                inst_e, pub_e, prv_e = dvp.gnark_r1cs.synthetic_dense(log_e)
+                pv_e = dvp.proving.Prover(inst_e)
+            else:
+                inst_e, pub_e, prv_e, pv_e = inst, pub, prv, pv
             try:
-                srs_e = dvp.srs.verifier_runs_setup(pv_e, inst_e, td)
-                pv_e.set_srs(srs_e)
+                if own:
+                    srs_e = dvp.srs.verifier_runs_setup(pv_e, inst_e, td)
+                    pv_e.set_srs(srs_e)
+                else:
+                    srs_e = srs
                 gpu_proof = pv_e.prove(pub_e, prv_e)
                 d_e, d2_e = pv_e.domains()
                 bar_e, z2inv_e = pv_e.domain_tables(0)
@@ -653,17 +851,25 @@ def main():
                         "constraints_per_s": me / e2e, "composed_s_at_this_size": composed, "measured_over_composed": e2e / composed,
                         "bytes_equal_gpu_proof": True}
             finally:
-                pv_e.close()
+                if own:
+                    pv_e.close()
 
-        e2e_runs = [cpu_end_to_end(lg) for lg in ((16, 18) if log_m >= 18 and args.cpu_seconds >= 10 else (min(16, log_m),))]
+        # 2^16 (the composition's cross-check at a small size) and THE BENCH SIZE ITSELF: cpu_baseline.value is the measured figure there
+        e2e_sizes = sorted(set(([16] if log_m > 16 else []) + ([log_m] if (log_m <= 20 and args.cpu_seconds >= 10) else [min(18, log_m)])))
+        e2e_runs = [cpu_end_to_end(lg) for lg in e2e_sizes]
+        at_size = next((r_ for r_ in e2e_runs if r_["log2_constraints"] == log_m), None)
         out["cpu_baseline"] = {
-            "value": m / cpu_s,
+            "value": (m / at_size["end_to_end_s"]) if at_size else m / cpu_s,
+            "value_is": "measured: a real CPU Proof::prove at the bench size (end_to_end[-1])" if at_size else "composed from bounded samples (see sample)",
+            "composed_value": m / cpu_s,
             "unit": "constraints/s",
             "cores": cores,
             "cpu_affinity_mask": mask,
             "cgroup_cpu_quota": quota,
             "kind": "port",
-            "sample": f"{n_s}-point reference-shaped MSM (one width-5 tau-NAF scalar multiplication per point + add tree, oracle/dvp_oracle.c) in "
+            "sample": (f"ONE real CPU Proof::prove of the 2^{log_m}-constraint instance on {cores} threads: {at_size['end_to_end_s']:.2f} s, its 118 bytes equal "
+                       f"the GPU prover's (stages in end_to_end[-1].stages_s).  Cross-check by composition -- " if at_size else "")
+                      + f"{n_s}-point reference-shaped MSM (one width-5 tau-NAF scalar multiplication per point + add tree, oracle/dvp_oracle.c) in "
                       f"{dt:.1f}s = {pts_per_s:.0f} points/s on {cores} threads = {us_core:.1f} us*core per point"
                       + (f" (~{us_core * mhz / 1e3:.0f} k cycles at {mhz:.0f} MHz; xs233's own xsk233_mul_frob is quoted at ~29.6 k cycles, so the "
                          f"reference's C library would be ~{us_core * mhz / 1e3 / 29.6:.1f}x faster than this port)" if mhz else "")
@@ -676,8 +882,8 @@ def main():
             "end_to_end_note": "a REAL Proof::prove on the host cores (oracle/dvp_oracle.c: sequential R1CS mat-vec and barycentric loops as in the "
                                "reference, threaded extends / pointwise maps / batch inversions / per-point scalar multiplications), inputs = the "
                                "cache_dir tables and decoded SRS of a GPU setup at that size; its 118 proof bytes are compared with the GPU "
-                               "prover's.  `value` above stays the figure composed at the bench size from bounded samples (a 2^20 CPU prove takes "
-                               "~4-5 s per proof on 16 threads); measured_over_composed says how well that composition predicts a real run",
+                               "prover's.  Since round 5 one of the runs is AT THE BENCH SIZE and `value` is its constraints per second; `composed_value` "
+                               "(bounded samples scaled up, rounds 1-4's headline) stays as the cross-check: measured_over_composed says how well it predicts",
             "msm_points_per_s": pts_per_s,
             "msm_us_core_per_point": us_core,
             "extend_s_per_proof": ext_s_per_proof,

@@ -41,6 +41,7 @@ _SIGS = {
     "dvp_debug_ecfft_matrices": (C.c_int, [vp, C.c_int, C.c_int, u64p]),
     "dvp_debug_ecfft_layer": (C.c_int, [vp, u32, u64p]),
     "dvp_ubench_gf_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "dvp_ubench_fr_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "dvp_debug_wave_trace": (C.c_int, [vp, u32]),
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),
@@ -108,6 +109,7 @@ _SIGS = {
     "dvp_prove_challenge_finish": (C.c_int, [vp, vp, C.c_uint32, C.c_size_t, C.c_size_t, vp]),
     "dvp_prove_finish": (C.c_int, [vp, vp, vp, u8p, vp]),
     "dvp_prover_debug_read": (C.c_int, [vp, C.c_char_p, u64p, sz]),
+    "dvp_prover_debug_transcript_dev": (C.c_int, [vp, u8p, u64p, u32, u64p, u64p]),
     "dvp_prover_domains": (C.c_int, [vp, u64p, u64p]),
     "dvp_prover_domain_tables": (C.c_int, [vp, C.c_int, u64p, u64p]),
     "dvp_ecfft_domain_tables": (C.c_int, [vp, C.c_int, u64p, u64p]),

@@ -229,6 +229,7 @@ struct OpenEntry {
   std::condition_variable slot_cv;
   bool busy[2] = {false, false};
   uint64_t proofs_done = 0;
+  uint64_t room_retry_at = 1;  // a second prover is considered once proofs_done reaches this (first: after one completed proof)
   ~OpenEntry() {
     if (p) dvp_prover_destroy(p);
     if (p2) dvp_prover_destroy(p2);
@@ -450,23 +451,24 @@ extern "C" int dvp_prove_cache_dir(const char* cache_dir, const uint64_t* public
     for (;;) {
       if (!e->busy[0]) { slot = 0; break; }
       if (replicas >= 2 && e->opened2 && e->rc2 == DVP_OK && !e->busy[1]) { slot = 1; break; }
-      if (replicas >= 2 && !e->opened2 && !e->opening2 && e->proofs_done > 0) {
-        size_t free_b = 0, total_b = 0;
-        const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > 1.25 * (double)(total_b - free_b);
-        if (!room) {  // callers keep taking turns on the first prover; asked again only after a release + reopen
-          e->opened2 = true;
-          e->rc2 = DVP_ENOMEM;
-          continue;
-        }
+      if (replicas >= 2 && !e->opened2 && !e->opening2 && e->proofs_done >= e->room_retry_at) {
+        // the room check (device-wide, other tenants included) and the open itself run OUTSIDE slot_mu, which every release needs;
+        // a failed check is not latched: it is asked again after another 16 completed proofs (memory may have come back)
         e->opening2 = true;
         g.unlock();
+        size_t free_b = 0, total_b = 0;
+        const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > 1.25 * (double)(total_b - free_b);
         dvp_prover* q = nullptr;
-        const int r2 = dvp_prover_open_cache_dir(cache_dir, n_public, &q);
+        const int r2 = room ? dvp_prover_open_cache_dir(cache_dir, n_public, &q) : DVP_ENOMEM;
         g.lock();
-        e->p2 = q;
-        e->rc2 = r2;
-        e->opened2 = true;
         e->opening2 = false;
+        if (room) {
+          e->p2 = q;
+          e->rc2 = r2;
+          e->opened2 = true;
+        } else {
+          e->room_retry_at = e->proofs_done + 16;
+        }
         e->slot_cv.notify_all();
         continue;
       }

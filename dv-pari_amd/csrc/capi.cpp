@@ -1,6 +1,7 @@
 // Library-wide C ABI pieces: status strings, device selection, last-error bookkeeping.
 #include "common.h"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -48,6 +49,9 @@ void prof_collect() {
   g_prof_pending.clear();
 }
 
+static std::atomic<uint64_t> g_host_waits[2];
+void count_host_wait(int kind) { g_host_waits[kind & 1].fetch_add(1, std::memory_order_relaxed); }
+
 static void tune_from_env(Tune& t) {
   t = Tune();
   auto geti = [](const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
@@ -74,6 +78,7 @@ static void tune_from_env(Tune& t) {
   t.msm_fixed_min = geti("DVP_MSM_FIXED_MIN", t.msm_fixed_min);
   t.horner_max_pub = geti("DVP_HORNER_MAX_PUB", t.horner_max_pub);
   t.msm_aligned_signed = geti("DVP_MSM_ALIGNED_SIGNED", t.msm_aligned_signed);
+  t.prove_host_transcript = geti("DVP_PROVE_HOST_TRANSCRIPT", t.prove_host_transcript);
 }
 static std::mutex g_dev_mu;
 static std::vector<int> g_devices;
@@ -93,7 +98,7 @@ static long long* tune_slot(const char* name) {
       {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi},
       {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_HEX_MAX", &t.msm_hex_max}, {"DVP_MSM_ROUND_PIPELINE", &t.msm_round_pipeline}, {"DVP_MSM_SORT_FUSED", &t.msm_sort_fused}, {"DVP_MSM_BUCKET_PAIRS_MAX", &t.msm_bucket_pairs_max}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax}, {"DVP_MSM_AFF_BMIN", &t.msm_aff_bmin}, {"DVP_ECFFT_RADIX4", &t.ecfft_radix4}, {"DVP_MSM_WS_SLOTS", &t.msm_ws_slots}, {"DVP_MSM_GATE_MIN", &t.msm_gate_min}, {"DVP_MSM_AFF_TPB", &t.msm_aff_tpb}, {"DVP_CACHE_REPLICAS", &t.cache_replicas},
       {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_ACCUM_QUAD_MAX", &t.msm_accum_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub},
-      {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}};
+      {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}, {"DVP_PROVE_HOST_TRANSCRIPT", &t.prove_host_transcript}};
   for (auto& e : tab)
     if (!strcmp(name, e.n)) return e.v;
   return nullptr;
@@ -118,6 +123,8 @@ extern "C" void dvp_profile_reset(void) {
   std::lock_guard<std::mutex> g(dvp::g_prof_mu);
   for (int i = 0; i < dvp::PROF_NSLOTS; ++i) { dvp::g_prof_ms[i] = 0; dvp::g_prof_n[i] = 0; }
   dvp::g_prof_round0.clear();
+  dvp::g_host_waits[0] = 0;
+  dvp::g_host_waits[1] = 0;
 }
 // the "msm_affine_round0" slot split by launch shape: one entry per distinct MSM size seen since the last reset
 extern "C" int dvp_profile_round0_shapes(uint64_t* pairs, double* total_ms, uint64_t* launches, int cap) {
@@ -133,6 +140,11 @@ extern "C" int dvp_profile_round0_shapes(uint64_t* pairs, double* total_ms, uint
 }
 extern "C" int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches) {
   if (!name || !total_ms || !launches) return DVP_EINVAL;
+  if (!strcmp(name, "host_waits_stream") || !strcmp(name, "host_waits_side")) {  // counts since the last dvp_profile_reset
+    *total_ms = 0;
+    *launches = dvp::g_host_waits[name[11] == 's' && name[12] == 'i' ? 1 : 0].load();
+    return DVP_OK;
+  }
   dvp::prof_collect();
   std::lock_guard<std::mutex> g(dvp::g_prof_mu);
   for (int i = 0; i < dvp::PROF_NSLOTS; ++i)

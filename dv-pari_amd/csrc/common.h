@@ -86,6 +86,7 @@ struct Tune {
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables
   long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)
+  long long prove_host_transcript = 0; // DVP_PROVE_HOST_TRANSCRIPT: 1 = dvp_prove_dev waits for the commitment MSM and hashes the transcript on the host (rounds 1-4); 0 = on the device, one stream wait per proof
   long long msm_aligned_signed = 1;    // DVP_MSM_ALIGNED_SIGNED: the aligned-window tables hold 2^(c w) P and the windows are signed binary digits (0 = the tau-adic aligned windows over rows tau^(o_w) P)
 };
 Tune& tune();
@@ -109,5 +110,9 @@ struct ProfScope {
   void stop();
 };
 void prof_collect();
+// host waits on the proof path, counted always (dvp_profile_read "host_waits_stream" / "host_waits_side"): kind 0 = a synchronisation
+// of the caller's stream (the GPU idles until the host has reacted), kind 1 = the largest-bucket read of an MSM, taken on a side
+// stream while the first pair round runs (the host waits, the GPU does not)
+void count_host_wait(int kind);
 
 }  // namespace dvp

@@ -479,8 +479,9 @@ DVP_HD Fr fr_pow_u64(const Fr& a, uint64_t e) {
   return r;
 }
 
-// a^(p-2) (Montgomery in/out); a == 0 -> 0
-DVP_HD Fr fr_inv(const Fr& a) {
+// a^(p-2) (Montgomery in/out); a == 0 -> 0.  232 squarings + 116 products: the reference route (ark-ff inverts by an extended
+// Euclid; the value is unique).  Kept as the cross-check of fr_inv below.
+DVP_HD Fr fr_inv_fermat(const Fr& a) {
   constexpr uint32_t e[8] = DVP_FR_PM2_LIMBS;
   Fr r = fr_one_mont();
   for (int i = 231; i >= 0; --i) {
@@ -488,6 +489,146 @@ DVP_HD Fr fr_inv(const Fr& a) {
     if ((e[i >> 5] >> (i & 31)) & 1) r = fr_mul(r, a);
   }
   return r;
+}
+
+// ---- inversion by a binary GCD on 62-bit approximations (round 5) --------------------------------------------------------
+// T. Pornin, "Optimized Binary GCD for Modular Inversion" (ePrint 2020/972), Algorithm 2 with k = 31: the classic binary extended
+// GCD keeps a = u y, b = v y (mod p) and spends a full-width subtraction and two full-width halvings per step; here 30 steps at a
+// time run on 62-bit APPROXIMATIONS of a and b (their low 30 bits, which decide every parity, and their top 32 bits, which decide
+// the comparisons) while the steps are recorded as a 2 x 2 matrix of small integers (|f| + |g| <= 2^30), which is then applied ONCE to
+// the full-width (a, b) -- exactly divisible by 2^30 -- and to (u, v) modulo p (one Montgomery-style step makes that division exact as
+// well).  2 x 232 - 1 = 463 steps reach a = 0, b = 1 for every invertible input (the paper's bound for this variant): 16 rounds of 30.
+// A wrong comparison (the approximation can misjudge a and b when they are close) only makes a value negative, which the sign fix
+// after the update absorbs.  ~16 x 0.9 k instructions against ~348 x 250 for the Fermat chain: what the one serial inversion of a
+// batch inversion (fr_ops.hip: a lone wave per workgroup) and the per-point inversions of the domain tables are made of.
+#define DVP_FR_R3_LIMBS \
+  { 0xa736e62au, 0xd5434168u, 0x8fe1c0d5u, 0x4ddf2901u, 0x8acce292u, 0xc70972a5u, 0xbf5ec775u, 0x00000072u }
+// t = f x + g y as a 9-limb two's complement number; |f| + |g| <= 2^30
+DVP_HD void fr_gcd_lin(int32_t f, const uint32_t* x, int32_t g, const uint32_t* y, uint32_t* t) {
+  int64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc += (int64_t)f * (int64_t)(uint64_t)x[i] + (int64_t)g * (int64_t)(uint64_t)y[i];
+    t[i] = (uint32_t)acc;
+    acc >>= 32;  // arithmetic: the carry keeps its sign
+  }
+  t[8] = (uint32_t)acc;
+}
+// bits [s, s + 32) of the 256-bit x (zero beyond bit 255), 30 <= s < 256
+DVP_HD uint32_t fr_gcd_window(const uint32_t* x, uint32_t s) {
+  const uint32_t q = s >> 5, r = s & 31u;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    lo = (i == q) ? x[i] : lo;
+    hi = (i == q + 1) ? x[i] : hi;
+  }
+  return r ? (lo >> r) | (hi << (32 - r)) : lo;
+}
+// y^{-1} mod p for a canonical integer y < p (no Montgomery factors); 0 -> 0
+DVP_HD Fr fr_inv_gcd_raw(const Fr& y) {
+  constexpr uint32_t P[8] = DVP_FR_P_LIMBS;
+  uint32_t a[8], b[8], u[8], v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = y.v[i]; b[i] = P[i]; u[i] = 0; v[i] = 0; }
+  u[0] = 1;
+#pragma unroll 1
+  for (int it = 0; it < 16; ++it) {
+    // n = max(len(a), len(b), 62); the approximations keep bits [0, 30) and [n - 32, n)
+    uint32_t top = 0, w = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint32_t o = a[i] | b[i];
+      top = o ? o : top;
+      w = o ? i : w;
+    }
+    uint32_t n = top ? 32u * (w + 1) - (uint32_t)__builtin_clz(top) : 0u;
+    n = n < 62u ? 62u : n;
+    uint64_t xa = (uint64_t)(a[0] & 0x3fffffffu) | ((uint64_t)fr_gcd_window(a, n - 32) << 30);
+    uint64_t xb = (uint64_t)(b[0] & 0x3fffffffu) | ((uint64_t)fr_gcd_window(b, n - 32) << 30);
+    int32_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+#pragma unroll 2
+    for (int j = 0; j < 30; ++j) {
+      const bool odd = xa & 1u;
+      const bool sw = odd && xa < xb;
+      const uint64_t ta = sw ? xb : xa, tb = sw ? xa : xb;
+      const int32_t tf0 = sw ? f1 : f0, tf1 = sw ? f0 : f1, tg0 = sw ? g1 : g0, tg1 = sw ? g0 : g1;
+      xa = (odd ? ta - tb : ta) >> 1;
+      xb = tb;
+      f0 = odd ? tf0 - tf1 : tf0;
+      g0 = odd ? tg0 - tg1 : tg0;
+      f1 = tf1 << 1;
+      g1 = tg1 << 1;
+    }
+    // (a, b) <- (f0 a + g0 b, f1 a + g1 b) / 2^30, signs folded into the matrix rows
+    uint32_t ta[9], tb[9];
+    fr_gcd_lin(f0, a, g0, b, ta);
+    fr_gcd_lin(f1, a, g1, b, tb);
+    const bool na = (int32_t)ta[8] < 0, nb = (int32_t)tb[8] < 0;
+    uint64_t ca = na ? 1 : 0, cb = nb ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t ra = (ta[i] >> 30) | (ta[i + 1] << 2), rb = (tb[i] >> 30) | (tb[i + 1] << 2);
+      ca += na ? (uint32_t)~ra : ra;  // two's complement negation when the value came out negative
+      cb += nb ? (uint32_t)~rb : rb;
+      a[i] = (uint32_t)ca;
+      b[i] = (uint32_t)cb;
+      ca >>= 32;
+      cb >>= 32;
+    }
+    if (na) { f0 = -f0; g0 = -g0; }
+    if (nb) { f1 = -f1; g1 = -g1; }
+    // (u, v) <- the same rows / 2^30 modulo p: make the low 30 bits vanish with a multiple of p, shift, fold into [0, p)
+    fr_gcd_lin(f0, u, g0, v, ta);
+    fr_gcd_lin(f1, u, g1, v, tb);
+    const uint32_t qa = (ta[0] * FR_N0_30) & 0x3fffffffu, qb = (tb[0] * FR_N0_30) & 0x3fffffffu;
+    uint64_t da = 0, db = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      da += (uint64_t)ta[i] + (uint64_t)qa * P[i];
+      db += (uint64_t)tb[i] + (uint64_t)qb * P[i];
+      ta[i] = (uint32_t)da;
+      tb[i] = (uint32_t)db;
+      da >>= 32;
+      db >>= 32;
+    }
+    ta[8] += (uint32_t)da;
+    tb[8] += (uint32_t)db;
+    Fr ru, rv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ru.v[i] = (ta[i] >> 30) | (ta[i + 1] << 2);
+      rv.v[i] = (tb[i] >> 30) | (tb[i + 1] << 2);
+    }
+    // a value in (-p, 2p) as 256-bit two's complement
+    const bool nu = (int32_t)ru.v[7] < 0, nv = (int32_t)rv.v[7] < 0;
+    uint64_t cu = 0, cv = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      cu += (uint64_t)ru.v[i] + (nu ? P[i] : 0u);
+      cv += (uint64_t)rv.v[i] + (nv ? P[i] : 0u);
+      ru.v[i] = (uint32_t)cu;
+      rv.v[i] = (uint32_t)cv;
+      cu >>= 32;
+      cv >>= 32;
+    }
+    ru = fr_cond_sub_p(ru);
+    rv = fr_cond_sub_p(rv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { u[i] = ru.v[i]; v[i] = rv.v[i]; }
+  }
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.v[i] = v[i];
+  return r;
+}
+// a^{-1} (Montgomery in / out): (a R)^{-1} = a^{-1} R^{-1}, times R^3 / R; a == 0 -> 0
+DVP_HD Fr fr_inv(const Fr& a) {
+  constexpr uint32_t c[8] = DVP_FR_R3_LIMBS;
+  Fr r3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r3.v[i] = c[i];
+  return fr_mul(fr_inv_gcd_raw(a), r3);
 }
 
 // canonical value < p ?

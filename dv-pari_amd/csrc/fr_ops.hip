@@ -136,6 +136,29 @@ __global__ void __launch_bounds__(256) k_bary_final(const Fr* __restrict__ parti
   if (threadIdx.x == 0) *out = fr_from_mont(fr_mul(sh[0], z_alpha_m));
 }
 
+// microbenchmark of the ECFFT's multiplier alone (bench.py's work model for configs #3 / #4's extends): pairs of independent
+// multiply-adds r = a b / R' + c on lazy 30-bit limbs (fr30_muladd_x2: what a twisted butterfly is made of), a dependent chain per
+// thread at the unfused passes' shape (256-thread workgroups, the compiler's own occupancy)
+__global__ void __launch_bounds__(256) k_ubench_fr30(Fr30* __restrict__ out, int reps) {
+  const uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+  Fr30 a0, a1, x0, x1, c;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a0.l[i] = (t * 2654435761u + 977u * i) & FR_M30;
+    a1.l[i] = (t * 40503u + 7919u * i) & FR_M30;
+    x0.l[i] = (t + 13u * i) & FR_M30;
+    x1.l[i] = (3u * t + 17u * i) & FR_M30;
+    c.l[i] = (5u * t + i) & FR_M30;
+  }
+  a0.l[7] &= 0x1fffffu; a1.l[7] &= 0x1fffffu; x0.l[7] &= 0x1fffffu; x1.l[7] &= 0x1fffffu; c.l[7] &= 0x1fffffu;  // constants below p, values of a few p
+#pragma unroll 1
+  for (int r = 0; r < reps; ++r) fr30_muladd_x2(a0, x0, c, a1, x1, c, x0, x1);
+  Fr30 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.l[i] = x0.l[i] ^ x1.l[i];
+  out[t] = o;
+}
+
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st) {
   if (!n) return DVP_OK;
   hipLaunchKernelGGL(k_batch_inverse, dim3(cdiv(n, (size_t)BI_TPB * INV_CHUNK)), dim3(BI_TPB), 0, st, d, n);
@@ -157,6 +180,32 @@ int barycentric_dev(const Fr* dom, const Fr* wts, const Fr* ev, size_t n, Fr alp
 }  // namespace dvp
 
 using namespace dvp;
+
+// multiply-adds per second of the lazy 30-bit Fr multiplier, whole chip (the ceiling of bench.py's ECFFT work model)
+extern "C" int dvp_ubench_fr_mul(int reps, double* muladds_per_s) {
+  if (reps < 1 || !muladds_per_s) return DVP_EINVAL;
+  int n_cu = 256;
+  int dev = 0;
+  DVP_HIP(hipGetDevice(&dev));
+  DVP_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  const uint32_t blocks = (uint32_t)n_cu * 8;  // 8 workgroups of 256 per CU
+  DevBuf out;
+  DVP_TRY(out.alloc((size_t)blocks * 256 * sizeof(Fr30)));
+  hipEvent_t e0, e1;
+  DVP_HIP(hipEventCreate(&e0));
+  DVP_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_ubench_fr30, dim3(blocks), dim3(256), 0, 0, out.as<Fr30>(), 8);
+  DVP_HIP(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_ubench_fr30, dim3(blocks), dim3(256), 0, 0, out.as<Fr30>(), reps);
+  DVP_HIP(hipEventRecord(e1, 0));
+  DVP_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DVP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *muladds_per_s = 2.0 * (double)blocks * 256.0 * (double)reps / ((double)ms * 1e-3);
+  return DVP_OK;
+}
 
 extern "C" int dvp_fr_batch_inverse_dev(void* d_vals, size_t n, void* stream) {
   if (n && !d_vals) return DVP_EINVAL;

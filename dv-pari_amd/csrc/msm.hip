@@ -381,29 +381,47 @@ k_part_hist(const uint32_t* __restrict__ digits, size_t total, FxBits fb, uint32
   __syncthreads();
   for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) phist[(size_t)blockIdx.x * FX_NP + k] = h[k];
 }
-// per partition (one block each): exclusive prefix over the level-1 blocks
+// exclusive prefix of every partition's counts over the level-1 blocks, in two coalesced launches (round 5; the first version gave a
+// block a partition and walked phist down a column -- a 128-byte line per 4-byte count, twice: 52 us per MSM).
+// pass A: a block takes FX_SCAN_CB consecutive level-1 blocks; a thread owns partition columns (consecutive threads, consecutive
+// partitions: whole lines in, whole lines out) and leaves the prefix WITHIN the chunk in pbase and the chunk's totals in ctot[part][chunk];
+// pass B: a wave per partition scans its chunk totals in place (exclusive) and leaves the partition's count.
+// A level-1 block b then starts its run of partition p at pstart[p] + ctot[p][b / FX_SCAN_CB] + pbase[b][p].
+constexpr uint32_t FX_SCAN_CB = 32;
 __global__ void __launch_bounds__(256)
-k_part_scan(const uint32_t* __restrict__ phist, uint32_t nblk, FxBits fb, uint32_t* __restrict__ pbase, uint32_t* __restrict__ pcount) {
-  __shared__ uint32_t sh[256];
+k_part_scan_chunks(const uint32_t* __restrict__ phist, uint32_t nblk, FxBits fb, uint32_t* __restrict__ pbase, uint32_t* __restrict__ ctot, uint32_t nch) {
   const uint32_t FX_NP = fb.np();
-  const uint32_t part = blockIdx.x, t = threadIdx.x;
-  const uint32_t per = (nblk + 255) / 256, b0 = t * per, b1 = min(nblk, b0 + per);
-  uint32_t s = 0;
-  for (uint32_t b = b0; b < b1; ++b) s += phist[(size_t)b * FX_NP + part];
-  sh[t] = s;
-  __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {
-    uint32_t x = (t >= (uint32_t)o) ? sh[t - o] : 0;
-    __syncthreads();
-    sh[t] += x;
-    __syncthreads();
+  const uint32_t ch = blockIdx.x, b0 = ch * FX_SCAN_CB, b1 = min(nblk, b0 + FX_SCAN_CB);
+  for (uint32_t part = threadIdx.x; part < FX_NP; part += 256) {
+    uint32_t run = 0;
+#pragma unroll 8
+    for (uint32_t b = b0; b < b1; ++b) {
+      const uint32_t v = phist[(size_t)b * FX_NP + part];
+      pbase[(size_t)b * FX_NP + part] = run;
+      run += v;
+    }
+    ctot[(size_t)part * nch + ch] = run;
   }
-  uint32_t run = sh[t] - s;
-  for (uint32_t b = b0; b < b1; ++b) {
-    pbase[(size_t)b * FX_NP + part] = run;
-    run += phist[(size_t)b * FX_NP + part];
+}
+__global__ void __launch_bounds__(256)
+k_part_scan_totals(uint32_t* __restrict__ ctot, uint32_t nch, FxBits fb, uint32_t* __restrict__ pcount) {
+  const uint32_t part = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (part >= fb.np()) return;  // whole waves
+  uint32_t* row = ctot + (size_t)part * nch;
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nch; base += 64) {
+    const uint32_t idx = base + lane;
+    const uint32_t v = idx < nch ? row[idx] : 0;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if ((int)lane >= o) x += y;
+    }
+    if (idx < nch) row[idx] = carry + x - v;
+    carry += __shfl(x, 63);
   }
-  if (t == 255) pcount[part] = sh[255];
+  if (lane == 0) pcount[part] = carry;
 }
 // partition starts and the global level-2 chunk index of each partition (one block of FX_NP_MAX threads)
 __global__ void __launch_bounds__(FX_NP_MAX)
@@ -432,12 +450,13 @@ k_part_starts(const uint32_t* __restrict__ pcount, FxBits fb, uint32_t* __restri
 }
 __global__ void __launch_bounds__(SORT_TPB)
 k_part_scatter(const uint32_t* __restrict__ digits, size_t total, uint32_t n, uint32_t n_total, uint32_t i0, FxBits fb,
-               const uint32_t* __restrict__ pbase, const uint32_t* __restrict__ pstart, uint16_t* __restrict__ plo,
-               uint32_t* __restrict__ pid) {
+               const uint32_t* __restrict__ pbase, const uint32_t* __restrict__ cbase, uint32_t nch, const uint32_t* __restrict__ pstart,
+               uint16_t* __restrict__ plo, uint32_t* __restrict__ pid) {
   __shared__ uint32_t cur[FX_NP_MAX];
   const uint32_t FX_NP = fb.np();
   const int FX_LO = fb.lo;
-  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + pbase[(size_t)blockIdx.x * FX_NP + k];
+  const uint32_t ch = blockIdx.x / FX_SCAN_CB;
+  for (uint32_t k = threadIdx.x; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + cbase[(size_t)k * nch + ch] + pbase[(size_t)blockIdx.x * FX_NP + k];
   __syncthreads();
   size_t lo = (size_t)blockIdx.x * FX_CHUNK, hi = min(total, lo + FX_CHUNK);
   for (size_t e = lo + threadIdx.x; e < hi; e += SORT_TPB) {
@@ -525,8 +544,8 @@ constexpr unsigned FX_STAGE2_LDS = (2 * FX_NP_MAX + SORT_TPB + FX_CHUNK) * 4 + F
 
 __global__ void __launch_bounds__(SORT_TPB)
 k_part_scatter_staged(const uint32_t* __restrict__ digits, size_t total, uint32_t n, uint32_t n_total, uint32_t i0, FxBits fb,
-                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pbase, const uint32_t* __restrict__ pstart,
-                      uint16_t* __restrict__ plo, uint32_t* __restrict__ pid) {
+                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pbase, const uint32_t* __restrict__ cbase, uint32_t nch,
+                      const uint32_t* __restrict__ pstart, uint16_t* __restrict__ plo, uint32_t* __restrict__ pid) {
   extern __shared__ uint32_t lds_st[];
   uint32_t* cur = lds_st;             // [FX_NP_MAX]
   uint32_t* gdst = cur + FX_NP_MAX;   // [FX_NP_MAX] destination of staged position 0 of the bin
@@ -540,7 +559,7 @@ k_part_scatter_staged(const uint32_t* __restrict__ digits, size_t total, uint32_
   uint32_t ex = block_scan_tpb(h, sh, &tot);
   if (t < FX_NP) {
     cur[t] = ex;
-    gdst[t] = pstart[t] + pbase[hb + t] - ex;
+    gdst[t] = pstart[t] + cbase[(size_t)t * nch + blockIdx.x / FX_SCAN_CB] + pbase[hb + t] - ex;
   }
   __syncthreads();
   const size_t lo = (size_t)blockIdx.x * FX_CHUNK, hi = min(total, lo + FX_CHUNK);
@@ -593,7 +612,8 @@ template <bool STAGED>
 __global__ void __launch_bounds__(SORT_TPB)
 k_part_scatter_signed(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf, uint32_t n, int c, int W, int n_narrow, uint32_t S,
                       uint32_t n_total, uint32_t i0, FxBits fb, const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pbase,
-                      const uint32_t* __restrict__ pstart, uint16_t* __restrict__ plo, uint32_t* __restrict__ pid) {
+                      const uint32_t* __restrict__ cbase, uint32_t nch, const uint32_t* __restrict__ pstart, uint16_t* __restrict__ plo,
+                      uint32_t* __restrict__ pid) {
   extern __shared__ uint32_t lds_st[];
   uint32_t* cur = lds_st;             // [FX_NP_MAX]
   uint32_t* gdst = cur + FX_NP_MAX;   // [FX_NP_MAX] STAGED: destination of staged position 0 of the bin
@@ -605,15 +625,16 @@ k_part_scatter_signed(const uint32_t* __restrict__ scalars, const uint8_t* __res
   const size_t hb = (size_t)blockIdx.x * FX_NP;
   const uint32_t mask = (1u << FX_LO) - 1;
   uint32_t tot = 0;
+  const uint32_t ch = blockIdx.x / FX_SCAN_CB;
   if (STAGED) {
     uint32_t h = t < FX_NP ? phist[hb + t] : 0;
     uint32_t ex = block_scan_tpb(h, sh, &tot);
     if (t < FX_NP) {
       cur[t] = ex;
-      gdst[t] = pstart[t] + pbase[hb + t] - ex;
+      gdst[t] = pstart[t] + cbase[(size_t)t * nch + ch] + pbase[hb + t] - ex;
     }
   } else {
-    for (uint32_t k = t; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + pbase[hb + k];
+    for (uint32_t k = t; k < FX_NP; k += SORT_TPB) cur[k] = pstart[k] + cbase[(size_t)k * nch + ch] + pbase[hb + k];
   }
   __syncthreads();
   const uint32_t lo = blockIdx.x * S, hi = min(n, lo + S);
@@ -1356,7 +1377,8 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GRO
 // product).  16 rows per workgroup: the points go out longest chain first, the few left over to the rows with the shortest ones.
 template <bool HEX>
 __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
-                                                 uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf, uint8_t* __restrict__ out_enc, int rule) {
+                                                 uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf, uint8_t* __restrict__ out_enc, int rule,
+                                                 const unsigned long long* __restrict__ err_src, unsigned long long* __restrict__ err_dst) {
   using LT = typename std::conditional<HEX, GfLdsH, GfLdsQ>::type;
   constexpr int GS = HEX ? 4 : 2;             // log2 lanes per point
   constexpr uint32_t NG = EC_TPB >> GS;       // points in flight per pass
@@ -1457,6 +1479,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   }
   *out_inf = fin ? 0u : 1u;
   if (out_enc) store30(out_enc, w, rule);
+  if (err_dst) *err_dst = *err_src;  // a deferred MSM (msm_core, d_err_defer) hands its scalar-range word to the caller's block
 }
 
 // sum of n affine points (the partial MSM results of n GPUs or ranks) -> affine: one quad of lanes, n - 1 mixed
@@ -1507,9 +1530,16 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(3, 
 }
 
 // wave trace of the pair rounds (dvp_debug_wave_trace): device buffer, record capacity, launch tag (counts traced launches)
-static std::atomic<unsigned long long*> g_wave_trace{nullptr};
+// (buffer, capacity) are published together under a mutex: an MSM in flight on another thread takes one consistent snapshot per launch
+static std::mutex g_wave_trace_mu;
+static unsigned long long* g_wave_trace_buf = nullptr;
 static uint32_t g_wave_trace_cap = 0;
 static std::atomic<uint32_t> g_wave_trace_tag{0};
+static void wave_trace_snapshot(unsigned long long** buf, uint32_t* cap) {
+  std::lock_guard<std::mutex> g(g_wave_trace_mu);
+  *buf = g_wave_trace_buf;
+  *cap = g_wave_trace_cap;
+}
 
 // ---- workspace -----------------------------------------------------------------------------------
 struct MsmWorkspace {
@@ -1522,6 +1552,13 @@ struct MsmWorkspace {
   hipStream_t aux = nullptr;
   hipEvent_t ev = nullptr;
   hipEvent_t ev_heavy = nullptr;  // end of this workspace's last run of pair rounds (HeavyGate)
+  // a DEFERRED MSM (msm_core, d_err_defer) returns with its kernels still in flight: ev_busy marks their end on busy_stream.  A later
+  // call on the same stream is ordered behind them by the stream itself; a call on another stream waits for the event ON THE GPU
+  // (and the slot choice prefers a workspace that is idle, so that two provers in flight keep to a workspace each)
+  hipEvent_t ev_busy = nullptr;
+  hipStream_t busy_stream = nullptr;
+  bool busy_valid = false;
+  bool busy_for(hipStream_t st) { return busy_valid && busy_stream != st && hipEventQuery(ev_busy) == hipErrorNotReady; }
   uint32_t* pinned = nullptr;
   // round bookkeeping (counts, offsets, descriptors of the later pair rounds) runs on a side stream while the first round fills
   // the chip: ev_pre = the first round's offsets are in place, ev_side[r] = round r may start
@@ -1545,6 +1582,7 @@ struct MsmWorkspace {
     DVP_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
     DVP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     DVP_HIP(hipEventCreateWithFlags(&ev_heavy, hipEventDisableTiming));
+    DVP_HIP(hipEventCreateWithFlags(&ev_busy, hipEventDisableTiming));
     DVP_HIP(hipHostMalloc((void**)&pinned, 64, hipHostMallocDefault));
     return DVP_OK;
   }
@@ -1694,7 +1732,18 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 static int msm_core(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, const MsmFixedCtx* fx, uint32_t i0,
                     void* d_out_xy, void* d_out_inf, hipStream_t st, void* d_out_enc = nullptr /* + the result's 30-byte encoding */,
                     void* h_copy = nullptr, const void* d_copy = nullptr, size_t copy_bytes = 0 /* a device block the caller wants on the
-                    host (pinned) when this call returns: it rides on the MSM's own final synchronisation */) {
+                    host (pinned) when this call returns: it rides on the MSM's own final synchronisation */,
+                    unsigned long long* d_err_defer = nullptr /* DEFERRED completion: the call returns once everything is enqueued -- no final
+                    synchronisation, no h_copy; the scalar-range word (~0 = fine, else the index of the first scalar >= p) is written to
+                    this device word by the tail kernel and the caller reads it with whatever it synchronises on later */) {
+  if (n == 0 && d_err_defer) {
+    DVP_HIP(hipMemsetAsync(d_out_xy, 0, 64, st));
+    if (d_out_enc) DVP_HIP(hipMemsetAsync(d_out_enc, 0, 30, st));
+    DVP_HIP(hipMemsetAsync(d_out_inf, 0, 4, st));
+    DVP_HIP(hipMemsetAsync(d_out_inf, 1, 1, st));  // little-endian u32 1
+    DVP_HIP(hipMemsetAsync(d_err_defer, 0xff, 8, st));
+    return DVP_OK;
+  }
   if (n == 0) {
     DVP_HIP(hipMemsetAsync(d_out_xy, 0, 64, st));
     if (d_out_enc) DVP_HIP(hipMemsetAsync(d_out_enc, 0, 30, st));
@@ -1749,12 +1798,19 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   std::unique_lock<std::mutex> g;
   int ws_slot = 0;
   const int ws_slots = tune().msm_ws_slots >= 1 && tune().msm_ws_slots <= MSM_WS_SLOTS ? (int)tune().msm_ws_slots : 1;
-  for (int sl = 0; sl < ws_slots && !g.owns_lock(); ++sl) {
-    g = std::unique_lock<std::mutex>(g_ws_dev[cur_dev][sl].mu, std::try_to_lock);
-    if (g.owns_lock()) ws_slot = sl;
-  }
+  // first choice: a workspace nobody holds AND whose last deferred MSM (if any) is finished or sits on this very stream
+  for (int pass = 0; pass < 2 && !g.owns_lock(); ++pass)
+    for (int sl = 0; sl < ws_slots && !g.owns_lock(); ++sl) {
+      g = std::unique_lock<std::mutex>(g_ws_dev[cur_dev][sl].mu, std::try_to_lock);
+      if (g.owns_lock() && pass == 0 && g_ws_dev[cur_dev][sl].busy_for(st)) g.unlock();
+      if (g.owns_lock()) ws_slot = sl;
+    }
   if (!g.owns_lock()) g = std::unique_lock<std::mutex>(g_ws_dev[cur_dev][0].mu);
   MsmWorkspace& g_ws = g_ws_dev[cur_dev][ws_slot];
+  if (g_ws.busy_valid) {  // kernels of a deferred MSM may still be using this workspace
+    if (g_ws.busy_stream != st) DVP_HIP(hipStreamWaitEvent(st, g_ws.ev_busy, 0));
+    g_ws.busy_valid = false;
+  }
   // carve the workspace
   size_t o = 0;
   auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
@@ -1769,6 +1825,8 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_pid = carve(fx ? p.e_max * 4 : 16);
   size_t o_phist = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
   size_t o_pbase = carve(fx ? (size_t)fx_nblk * FX_NP * 4 : 16);
+  const uint32_t fx_nch = cdiv(fx_nblk, FX_SCAN_CB);  // chunks of the level-1 scan (k_part_scan_chunks)
+  size_t o_ctot = carve(fx ? (size_t)FX_NP * fx_nch * 4 : 16);
   size_t o_pstart = carve((FX_NP_MAX + 1) * 4 * 3);
   size_t o_cnt = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off = carve(((size_t)p.nkeys + 1) * 4);
@@ -1826,6 +1884,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto* pid = (uint32_t*)(base + o_pid);
   auto* phist = (uint32_t*)(base + o_phist);
   auto* pbase = (uint32_t*)(base + o_pbase);
+  auto* ctot = (uint32_t*)(base + o_ctot);
   auto* pstart = (uint32_t*)(base + o_pstart);
   auto* cstart = pstart + FX_NP_MAX + 1;
   auto* pcount = cstart + FX_NP_MAX + 1;
@@ -1927,22 +1986,23 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                          p.c, p.W, p.n_narrow, fx_S, fb, phist, err);
     else
       hipLaunchKernelGGL(k_part_hist, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, fb, phist);
-    hipLaunchKernelGGL(k_part_scan, dim3(FX_NP), dim3(256), 0, st, phist, fx_nblk, fb, pbase, pcount);
+    hipLaunchKernelGGL(k_part_scan_chunks, dim3(fx_nch), dim3(256), 0, st, phist, fx_nblk, fb, pbase, ctot, fx_nch);
+    hipLaunchKernelGGL(k_part_scan_totals, dim3(cdiv((size_t)FX_NP * 64, 256)), dim3(256), 0, st, ctot, fx_nch, fb, pcount);
     hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(FX_NP_MAX), 0, st, pcount, fb, pstart, cstart);
     const bool staged1 = FX_NP >= 64;           // few partitions: direct stores already coalesce
     const bool staged2 = fb.lo <= 10;           // one bin per thread in the block scan
     if (fused1 && staged1)
       hipLaunchKernelGGL(k_part_scatter_signed<true>, dim3(fx_nblk), dim3(SORT_TPB), FX_STAGE1_LDS, st, (const uint32_t*)d_scalars,
-                         (const uint8_t*)d_inf, (uint32_t)n, p.c, p.W, p.n_narrow, fx_S, fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
+                         (const uint8_t*)d_inf, (uint32_t)n, p.c, p.W, p.n_narrow, fx_S, fx->n_total, i0, fb, phist, pbase, ctot, fx_nch, pstart, plo, pid);
     else if (fused1)
       hipLaunchKernelGGL(k_part_scatter_signed<false>, dim3(fx_nblk), dim3(SORT_TPB), (2 * FX_NP_MAX + SORT_TPB) * 4, st, (const uint32_t*)d_scalars,
-                         (const uint8_t*)d_inf, (uint32_t)n, p.c, p.W, p.n_narrow, fx_S, fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
+                         (const uint8_t*)d_inf, (uint32_t)n, p.c, p.W, p.n_narrow, fx_S, fx->n_total, i0, fb, phist, pbase, ctot, fx_nch, pstart, plo, pid);
     else if (staged1)
       hipLaunchKernelGGL(k_part_scatter_staged, dim3(fx_nblk), dim3(SORT_TPB), FX_STAGE1_LDS, st, digits32, p.e_max, (uint32_t)n,
-                         fx->n_total, i0, fb, phist, pbase, pstart, plo, pid);
+                         fx->n_total, i0, fb, phist, pbase, ctot, fx_nch, pstart, plo, pid);
     else
       hipLaunchKernelGGL(k_part_scatter, dim3(fx_nblk), dim3(SORT_TPB), 0, st, digits32, p.e_max, (uint32_t)n, fx->n_total, i0, fb, pbase,
-                         pstart, plo, pid);
+                         ctot, fx_nch, pstart, plo, pid);
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
     hipLaunchKernelGGL(k_hist_scan2, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, cstart, fb, chunk_off, cnt);
     DVP_TRY(prepare_rounds());  // needs the counts only
@@ -1994,7 +2054,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const uint32_t aff_bmax_only = tn.msm_aff_bmax >= 1 && tn.msm_aff_bmax <= 255 ? (uint32_t)tn.msm_aff_bmax : AFF_BMAX;
   const uint32_t aff_bmin = tn.msm_aff_bmin >= 1 && (uint32_t)tn.msm_aff_bmin <= aff_bmax_only ? (uint32_t)tn.msm_aff_bmin : 1u;
   const uint32_t aff_bmax = aff_bmax_only | (aff_bmin << 8);
-  const bool wt_on = g_wave_trace.load() != nullptr;
+  unsigned long long* wt_buf = nullptr;
+  uint32_t wt_cap = 0;
+  wave_trace_snapshot(&wt_buf, &wt_cap);  // one snapshot per MSM: every round of it traces into the same buffer or none does
+  const bool wt_on = wt_buf != nullptr;
   // the round itself: d_total = the scanned output count (ooff[nkeys]), dsc = one (a, b) descriptor per output slot
   auto launch_round = [&](int r, const uint32_t* d_total, const uint2* dsc) -> int {
     size_t out_max = cap / 2 + nk + 1;
@@ -2004,7 +2067,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t grid = r_max * (aff_cap / aff_tpb) + 1;
     {
       ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st, (uint64_t)n);  // r == 0 is the dominant kernel: it gathers the bases
-      WaveTrace wt{g_wave_trace.load(), g_wave_trace_cap, g_wave_trace_tag.fetch_add(wt_on ? 1u : 0u)};
+      WaveTrace wt{wt_buf, wt_cap, g_wave_trace_tag.fetch_add(wt_on ? 1u : 0u)};
       if (r == 0 && wt.buf)
         hipLaunchKernelGGL((k_affine_round<true, true>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask, wt);
       else if (r == 0)
@@ -2048,6 +2111,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     launched = 1;
   }
   DVP_HIP(hipStreamSynchronize(g_ws.aux));  // the caller's stream keeps running round 0 meanwhile
+  count_host_wait(launched ? 1 : 0);
   const uint32_t max_cnt = *g_ws.pinned;
   int ra = 0;
   if (affine_mode)
@@ -2148,20 +2212,27 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   (void)cntT;
   if (sign_mask && tn.msm_hex_max != 0)  // c points: one row of 16 lanes each
     hipLaunchKernelGGL(k_tail<true>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, -3, Tsq, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf,
-                       (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0);
+                       (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, (const unsigned long long*)err, d_err_defer);
   else
     hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
-                       (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0);
+                       (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, (const unsigned long long*)err, d_err_defer);
   ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
   // the scalar-range flag is the only thing that needs the host
   // into the workspace's pinned words (a pageable destination makes the runtime stage the copy and take a host round trip of its own
   // between the two copies: 60 us per MSM)
+  if (d_err_defer) {  // deferred: the workspace stays in use until this point of the stream
+    DVP_HIP(hipEventRecord(g_ws.ev_busy, st));
+    g_ws.busy_stream = st;
+    g_ws.busy_valid = true;
+    return DVP_OK;
+  }
   volatile unsigned long long* h_err = (volatile unsigned long long*)(g_ws.pinned + 2);
   if (h_copy) DVP_HIP(hipMemcpyAsync(h_copy, d_copy, copy_bytes, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemcpyAsync((void*)h_err, err, 8, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
+  count_host_wait(0);
   const unsigned long long e = *h_err;
   if (e != ~0ull) {
     g_last_error_index = (int64_t)(e & 0xffffffffull);
@@ -2292,14 +2363,16 @@ int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf
 }
 // the same with the result's 30-byte encoding written to d_out_enc by the tail kernel itself
 // (h_copy, d_copy, copy_bytes): a device block copied to pinned host memory before the call's own final synchronisation
+// d_err_defer != nullptr: deferred completion (see msm_core) -- returns once everything is enqueued
 int msm_fixed_dev_enc(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
-                      void* d_out_inf, void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st) {
+                      void* d_out_inf, void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st,
+                      unsigned long long* d_err_defer) {
   if (!c || lo > hi || hi > c->n_total) return DVP_EINVAL;
-  return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st, d_out_enc, h_copy, d_copy, copy_bytes);
+  return msm_core(d_scalars, nullptr, d_inf, hi - lo, c, lo, d_out_xy, d_out_inf, st, d_out_enc, h_copy, d_copy, copy_bytes, d_err_defer);
 }
 int msm_affine_dev_enc(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf,
-                       void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st) {
-  return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st, d_out_enc, h_copy, d_copy, copy_bytes);
+                       void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st, unsigned long long* d_err_defer) {
+  return msm_core(d_scalars, d_bases, d_inf, n, nullptr, 0, d_out_xy, d_out_inf, st, d_out_enc, h_copy, d_copy, copy_bytes, d_err_defer);
 }
 
 }  // namespace dvp
@@ -2325,9 +2398,15 @@ extern "C" int dvp_points_sum_dev(const void* d_records, uint32_t n, void* d_out
 // d_buf: device buffer of 64 + 64 * n_records bytes, zeroed by the caller (word 0 counts the records); NULL switches the trace off.
 // While set, every pair round runs its TRACE instantiation and appends one record per wave (layout: WaveTrace above).
 extern "C" int dvp_debug_wave_trace(void* d_buf, uint32_t n_records) {
-  g_wave_trace_cap = d_buf ? n_records : 0;
-  g_wave_trace_tag.store(0);
-  g_wave_trace.store((unsigned long long*)d_buf);
+  {
+    std::lock_guard<std::mutex> g(g_wave_trace_mu);
+    g_wave_trace_cap = d_buf ? n_records : 0;
+    g_wave_trace_buf = (unsigned long long*)d_buf;
+    g_wave_trace_tag.store(0);
+  }
+  // switching the trace off (or to another buffer): launches that took the old snapshot may still be writing into it -- the caller
+  // is about to free it
+  DVP_HIP(hipDeviceSynchronize());
   return DVP_OK;
 }
 

@@ -49,9 +49,10 @@ int msm_fixed_info(const MsmFixedCtx* c, int* cbits, int* windows);
 uint64_t msm_fixed_table_bytes(const MsmFixedCtx* c, int* signed_flavour);
 const void* msm_fixed_table_ptr(const MsmFixedCtx* c);
 int msm_fixed_dev_enc(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
-                      void* d_out_inf, void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st);
+                      void* d_out_inf, void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st,
+                      unsigned long long* d_err_defer);
 int msm_affine_dev_enc(const void* d_scalars, const void* d_bases, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf,
-                       void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st);
+                       void* d_out_enc, void* h_copy, const void* d_copy, size_t copy_bytes, hipStream_t st, unsigned long long* d_err_defer);
 int msm_fixed_dev(const MsmFixedCtx* c, const void* d_scalars, const void* d_inf, uint32_t lo, uint32_t hi, void* d_out_xy,
                   void* d_out_inf, hipStream_t st);
 
@@ -154,10 +155,11 @@ k_quotient(Fr* __restrict__ E2, const Fr* __restrict__ z2inv_m, uint32_t m, cons
 
 // den[i] = d_i - alpha, den2[i] = d'_i - alpha (canonical); flags alpha in D u D' (src/proving.rs:548-556)
 __global__ void __launch_bounds__(256)
-k_alpha_denoms(const Fr* __restrict__ d_m, const Fr* __restrict__ d2_m, Fr alpha_m, uint32_t m, Fr* __restrict__ den,
+k_alpha_denoms(const Fr* __restrict__ d_m, const Fr* __restrict__ d2_m, const Fr* __restrict__ alpha_m_p, uint32_t m, Fr* __restrict__ den,
                Fr* __restrict__ den2, unsigned long long* __restrict__ hit) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
+  const Fr alpha_m = *alpha_m_p;  // from the host (dvp_prove_challenge) or from k_transcript, in the prover's own block
   Fr x = fr_sub(d_m[i], alpha_m), y = fr_sub(d2_m[i], alpha_m);
   if (fr_is_zero(x) || fr_is_zero(y)) atomicMin(hit, (unsigned long long)i);
   den[i] = fr_from_mont(x);
@@ -188,9 +190,10 @@ k_bary3_partial(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, const F
   }
 }
 // out[0..2] = a0, b0, i0 (canonical); out[3] = r0 = a0 b0 - i0.   P(alpha) = -Z(alpha) * sum y w / (d - alpha)
-__global__ void __launch_bounds__(256) k_bary3_final(const Fr* __restrict__ partial, uint32_t nb, Fr neg_z_alpha_m, Fr* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_bary3_final(const Fr* __restrict__ partial, uint32_t nb, const Fr* __restrict__ neg_z_alpha_m_p, Fr* __restrict__ out) {
   __shared__ Fr sh[256];
   Fr res[3];
+  const Fr neg_z_alpha_m = *neg_z_alpha_m_p;
   for (int v = 0; v < 3; ++v) {
     Fr s = fr_zero();
     for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[(size_t)v * nb + i]);
@@ -330,6 +333,112 @@ k_kscalars_range(const Fr* __restrict__ E, const Fr* __restrict__ r2, const Fr* 
   }
 }
 
+
+// ---- the Fiat-Shamir transcript on the device (round 5) ----------------------------------------------------------------
+// Transcript::output (src/proving.rs:164-197) needs four single-chunk BLAKE3 hashes once commit_p exists -- H(commit_p),
+// H(public inputs as 29-byte LE), H(H_wc || H_pi), H(H_ct || H_rt); H_ct = H(H(empty) || H(empty)) is a constant the host passes in --
+// and alpha is the result with its top four bytes cleared (:192).  One lane of one wave does that right behind the commitment MSM's
+// tail kernel, so dvp_prove_dev has no host round trip between its two MSMs (the host is already enqueueing the second MSM's sort while
+// the first one's rounds run).  Written from the BLAKE3 specification like blake3.h (the host flavour, which the phased entries and
+// n_public > 35 keep using); the two are compared in tests/ (dvp_debug_transcript_dev).
+namespace b3d {
+struct Words8 { uint32_t w[8]; };
+__device__ __forceinline__ uint32_t rotr(uint32_t x, uint32_t n) { return (x >> n) | (x << (32 - n)); }
+#define DVP_B3G(a, b, c, d, mx, my)                      \
+  do {                                                   \
+    s[a] = s[a] + s[b] + (mx); s[d] = rotr(s[d] ^ s[a], 16); \
+    s[c] = s[c] + s[d];        s[b] = rotr(s[b] ^ s[c], 12); \
+    s[a] = s[a] + s[b] + (my); s[d] = rotr(s[d] ^ s[a], 8);  \
+    s[c] = s[c] + s[d];        s[b] = rotr(s[b] ^ s[c], 7);  \
+  } while (0)
+// one compression of a single-chunk hash (counter 0): cv' = first eight output words
+__device__ __forceinline__ void compress(uint32_t cv[8], const uint32_t blk[16], uint32_t block_len, uint32_t flags) {
+  constexpr uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+  constexpr int PERM[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
+  uint32_t s[16], m[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = cv[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[8 + i] = IV[i];
+  s[12] = 0; s[13] = 0; s[14] = block_len; s[15] = flags;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m[i] = blk[i];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    DVP_B3G(0, 4, 8, 12, m[0], m[1]); DVP_B3G(1, 5, 9, 13, m[2], m[3]); DVP_B3G(2, 6, 10, 14, m[4], m[5]); DVP_B3G(3, 7, 11, 15, m[6], m[7]);
+    DVP_B3G(0, 5, 10, 15, m[8], m[9]); DVP_B3G(1, 6, 11, 12, m[10], m[11]); DVP_B3G(2, 7, 8, 13, m[12], m[13]); DVP_B3G(3, 4, 9, 14, m[14], m[15]);
+    if (r < 6) {
+      uint32_t t[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t[i] = m[PERM[i]];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m[i] = t[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cv[i] = s[i] ^ s[i + 8];
+}
+#undef DVP_B3G
+// BLAKE3 of `len` <= 1024 bytes held as zero-padded little-endian words
+__device__ __forceinline__ void hash_chunk(const uint32_t* words, uint32_t len, uint32_t out[8]) {
+  constexpr uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = IV[i];
+  const uint32_t nblocks = len ? (len + 63) / 64 : 1;
+#pragma unroll 1
+  for (uint32_t b = 0; b < nblocks; ++b) {
+    uint32_t blk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) blk[i] = words[16 * b + i];
+    const bool last = b + 1 == nblocks;
+    compress(out, blk, last ? len - 64 * b : 64u, (b == 0 ? 1u : 0u) | (last ? (2u | 8u) : 0u));  // CHUNK_START | CHUNK_END | ROOT
+  }
+}
+}  // namespace b3d
+constexpr uint32_t TRANSCRIPT_DEV_MAX_PUB = 35;  // 35 x 29 bytes = 1015 <= one 1024-byte chunk
+
+// alpha from (commit_p, public inputs), both resident: enc30 = the commitment's 30 bytes (16-byte aligned, the two bytes behind them
+// belong to the next encoding), pub = n_pub canonical Fr.  Writes alpha (canonical) and alpha (Montgomery).
+__global__ void __launch_bounds__(64) k_transcript(const uint32_t* __restrict__ enc30, const Fr* __restrict__ pub, uint32_t npub, b3d::Words8 h_ct,
+                                                   Fr* __restrict__ alpha_canon, Fr* __restrict__ alpha_m) {
+  __shared__ uint32_t msg[256];
+  for (uint32_t i = threadIdx.x; i < 256; i += 64) msg[i] = 0;
+  __syncthreads();
+  const uint32_t len = 29u * npub;  // <= 1015
+  uint8_t* mb = (uint8_t*)msg;
+  for (uint32_t t = threadIdx.x; t < len; t += 64) {
+    const uint32_t j = t / 29u, b = t - 29u * j;
+    mb[t] = ((const uint8_t*)(pub + j))[b];  // 29-byte LE of a canonical Fr (src/proving.rs:147-150)
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  uint32_t blk[16], h_wc[8], h_pi[8], h_rt[8], out[8];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) blk[i] = i < 8 ? enc30[i] : 0u;
+  blk[7] &= 0xffffu;  // 30 bytes
+  b3d::hash_chunk(blk, 30, h_wc);
+  b3d::hash_chunk(msg, len, h_pi);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { blk[i] = h_wc[i]; blk[8 + i] = h_pi[i]; }
+  b3d::hash_chunk(blk, 64, h_rt);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { blk[i] = h_ct.w[i]; blk[8 + i] = h_rt[i]; }
+  b3d::hash_chunk(blk, 64, out);
+  Fr a;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) a.v[i] = out[i];
+  a.v[7] = 0;  // 224-bit challenge: the top four bytes cleared (src/proving.rs:192), always < p
+  *alpha_canon = a;
+  *alpha_m = fr_to_mont(a);
+}
+// -Z_D(alpha) from the isogeny chain (what host_vanish computes on the host): one lane, ~7 log2(m) dependent products -- run on the
+// prover's side stream beside the denominators / batch inversion / barycentric partial sums, which do not need it
+__global__ void __launch_bounds__(64) k_zalpha(const Fr* __restrict__ alpha_m, const Fr* __restrict__ x0s, const Fr* __restrict__ ts, int kk,
+                                               const Fr* __restrict__ ctop, Fr* __restrict__ neg_z_alpha_m) {
+  if (threadIdx.x != 0) return;
+  *neg_z_alpha_m = fr_neg(vanish_chain(*alpha_m, x0s, ts, kk, ctop[0]));
+}
+
 __global__ void __launch_bounds__(256) k_to_mont_vec(const Fr* __restrict__ in, Fr* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = fr_to_mont(in[i]);
@@ -352,7 +461,15 @@ struct DevCsr {
   uint32_t max_coeff_id = 0;  // largest coefficient id stored (re-checked against the table in prover_ready)
 };
 
-static constexpr size_t FIN_BYTES = 4 * sizeof(Fr) + 16 + 64;  // a0 b0 i0 r0 | flags | commit_p, kzg_k encodings
+// the prover's result block on the device; the first FIN_BYTES go to the host (pinned) in ONE copy at the end of a proof
+static constexpr size_t FIN_OFF_FLAGS = 4 * sizeof(Fr);        // a0 b0 i0 r0, then [0] unsatisfied row, [1] alpha in D u D'
+static constexpr size_t FIN_OFF_ENC = FIN_OFF_FLAGS + 16;      // commit_p (30) | kzg_k (30) | 4 spare
+static constexpr size_t FIN_OFF_ALPHA = FIN_OFF_ENC + 64;      // alpha, canonical (written by k_transcript; the host flavour keeps its own copy)
+static constexpr size_t FIN_OFF_MSMERR = FIN_OFF_ALPHA + 32;   // scalar-range words of deferred MSMs: [0] the commitment MSM's
+static constexpr size_t FIN_BYTES = FIN_OFF_MSMERR + 16;
+static constexpr size_t DEV_OFF_ALPHA_M = FIN_BYTES;           // device only: alpha (Montgomery), -Z_D(alpha) (Montgomery)
+static constexpr size_t DEV_OFF_NEGZ = DEV_OFF_ALPHA_M + 32;
+static constexpr size_t DEV_BLOCK_BYTES = DEV_OFF_NEGZ + 32;
 struct dvp_prover {
   uint32_t log_m = 0, m = 0, n_pub = 0, n_wires = 0;
   dvp_ecfft* tree = nullptr;  // 2m leaves (tree2n)
@@ -405,7 +522,14 @@ struct dvp_prover {
   Fr neg_z_alpha_m;  // -Z_D(alpha), kept between dvp_prove_challenge_partial and dvp_prove_challenge_finish
   std::vector<uint64_t> pub_host;
   uint8_t commit_p_host[30];
-  uint8_t* fin_host = nullptr;  // pinned mirror of the device block [abir0 | flags | enc]
+  uint8_t* fin_host = nullptr;  // pinned mirror of the device block [abir0 | flags | enc | alpha | msm err] + 64 bytes of staging for (alpha_m, -Z(alpha))
+  Fr* chal_dev = nullptr;       // device: [alpha_m, -Z_D(alpha)] (Montgomery), behind the block the host reads
+  Fr* alpha_dev = nullptr;      // device: alpha, canonical (inside the block)
+  unsigned long long* msm_err = nullptr;  // device: scalar-range words of deferred MSMs (inside the block)
+  // side stream + events of the device transcript: -Z(alpha) is computed beside the challenge phase's vector kernels
+  hipStream_t side = nullptr;
+  hipEvent_t ev_alpha = nullptr, ev_negz = nullptr;
+  b3d::Words8 h_ct;             // H(H(empty) || H(empty)): srs / circuit hashes are hashes of empty buffers (src/proving.rs:86-105,113-132)
 };
 
 static const int PT = 256;
@@ -471,10 +595,24 @@ static int prover_init(dvp_prover* p, uint32_t log2_m, uint32_t n_public, uint32
   DVP_TRY(A((void**)&p->SK, 4 * m * sizeof(Fr)));
   DVP_TRY(A((void**)&p->partial, 3 * 1024 * sizeof(Fr)));
   // what the host reads back at the end of a proof, in ONE block and one copy: a0 b0 i0 r0 | flags | encoded points
-  DVP_TRY(A((void**)&p->abir0, FIN_BYTES));
-  p->flags = (unsigned long long*)((char*)p->abir0 + 4 * sizeof(Fr));
-  p->enc = (uint8_t*)p->abir0 + 4 * sizeof(Fr) + 16;
-  DVP_HIP(hipHostMalloc((void**)&p->fin_host, FIN_BYTES, hipHostMallocDefault));
+  DVP_TRY(A((void**)&p->abir0, DEV_BLOCK_BYTES));
+  DVP_HIP(hipMemset(p->abir0, 0, DEV_BLOCK_BYTES));
+  p->flags = (unsigned long long*)((char*)p->abir0 + FIN_OFF_FLAGS);
+  p->enc = (uint8_t*)p->abir0 + FIN_OFF_ENC;
+  p->alpha_dev = (Fr*)((char*)p->abir0 + FIN_OFF_ALPHA);
+  p->msm_err = (unsigned long long*)((char*)p->abir0 + FIN_OFF_MSMERR);
+  p->chal_dev = (Fr*)((char*)p->abir0 + DEV_OFF_ALPHA_M);
+  DVP_HIP(hipHostMalloc((void**)&p->fin_host, FIN_BYTES + 64, hipHostMallocDefault));
+  DVP_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+  DVP_HIP(hipEventCreateWithFlags(&p->ev_alpha, hipEventDisableTiming));
+  DVP_HIP(hipEventCreateWithFlags(&p->ev_negz, hipEventDisableTiming));
+  {
+    uint8_t h_empty[32], buf[64], h[32];
+    b3::hash(nullptr, 0, h_empty);
+    memcpy(buf, h_empty, 32); memcpy(buf + 32, h_empty, 32);
+    b3::hash(buf, 64, h);
+    memcpy(p->h_ct.w, h, 32);
+  }
   DVP_TRY(A((void**)&p->pts, 2 * sizeof(Aff)));
   DVP_TRY(A((void**)&p->pts_inf32, 8));
   DVP_TRY(A((void**)&p->pts_inf8, 8));
@@ -501,6 +639,9 @@ extern "C" void dvp_prover_destroy(dvp_prover* p) {
     if (q) (void)hipFree(q);
   if (p->fin_host) (void)hipHostFree(p->fin_host);
   if (p->own_stream) (void)hipStreamDestroy(p->own_stream);
+  if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->ev_alpha) (void)hipEventDestroy(p->ev_alpha);
+  if (p->ev_negz) (void)hipEventDestroy(p->ev_negz);
   for (auto& mt : p->mat) {
     if (mt.row_ptr) (void)hipFree(mt.row_ptr);
     if (mt.wire) (void)hipFree(mt.wire);
@@ -655,6 +796,30 @@ extern "C" int dvp_transcript_challenge(const uint8_t commit_p[30], const uint64
   return DVP_OK;
 }
 
+// parity-test access to the DEVICE flavour of the transcript (k_transcript, k_zalpha) on caller-supplied inputs: alpha (canonical) and
+// -Z_D(alpha) (canonical) for this prover's domain, to be compared with dvp_transcript_challenge / the oracle
+extern "C" int dvp_prover_debug_transcript_dev(dvp_prover* p, const uint8_t commit_p[30], const uint64_t* public_inputs, uint32_t n_public,
+                                               uint64_t out_alpha[4], uint64_t out_neg_z_alpha[4]) {
+  if (!p || !commit_p || (n_public && !public_inputs) || !out_alpha || !out_neg_z_alpha || n_public > TRANSCRIPT_DEV_MAX_PUB) return DVP_EINVAL;
+  DevBuf in, out;
+  DVP_TRY(in.alloc(64 + (size_t)(n_public ? n_public : 1) * sizeof(Fr)));
+  DVP_TRY(out.alloc(4 * sizeof(Fr)));
+  uint8_t head[64];
+  memset(head, 0xa5, sizeof(head));  // the bytes behind the 30 must not matter
+  memcpy(head, commit_p, 30);
+  DVP_HIP(hipMemcpy(in.p, head, 64, hipMemcpyHostToDevice));
+  if (n_public) DVP_HIP(hipMemcpy((char*)in.p + 64, public_inputs, (size_t)n_public * sizeof(Fr), hipMemcpyHostToDevice));
+  Fr* o = out.as<Fr>();
+  hipLaunchKernelGGL(k_transcript, dim3(1), dim3(64), 0, 0, (const uint32_t*)in.p, (const Fr*)((char*)in.p + 64), n_public, p->h_ct, o, o + 1);
+  hipLaunchKernelGGL(k_zalpha, dim3(1), dim3(64), 0, 0, o + 1, p->tree->d_x0, p->tree->d_t, (int)p->log_m, p->tree->layer((int)p->log_m), o + 2);
+  hipLaunchKernelGGL(k_from_mont_vec, dim3(1), dim3(PT), 0, 0, o + 2, o + 3, (size_t)1);
+  DVP_HIP(hipGetLastError());
+  DVP_HIP(hipDeviceSynchronize());
+  DVP_HIP(hipMemcpy(out_alpha, o, sizeof(Fr), hipMemcpyDeviceToHost));
+  DVP_HIP(hipMemcpy(out_neg_z_alpha, o + 3, sizeof(Fr), hipMemcpyDeviceToHost));
+  return DVP_OK;
+}
+
 extern "C" int dvp_blake3(const uint8_t* data, size_t len, uint8_t out[32]) {
   if ((len && !data) || !out) return DVP_EINVAL;
   b3::hash(data, len, out);
@@ -686,7 +851,7 @@ extern "C" int dvp_prove_begin(dvp_prover* p, const void* d_assignment, void* st
 // need_extend == 0: the caller's MSM shards lie inside [w] and [k_a | k_b] only, which need neither q2 nor r2, so the
 // three extends and the quotient are skipped (multi-GPU load balancing, distributed.py::shard_plan).  q2 / r2 and the
 // k_r part of the second MSM's scalars are then NOT valid on this prover until the next full begin.
-static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_extend, void* stream, bool defer_unsat);
+static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_extend, void* stream, bool defer_unsat, bool pub_to_host = true);
 extern "C" int dvp_prove_begin_partial(dvp_prover* p, const void* d_assignment, int need_extend, void* stream) {
   return prove_begin_impl(p, d_assignment, need_extend, stream, false);
 }
@@ -695,6 +860,7 @@ static int prove_check_unsat(dvp_prover* p, hipStream_t st) {
   unsigned long long f0[2];
   DVP_HIP(hipMemcpyAsync(f0, p->flags, 16, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipStreamSynchronize(st));
+  count_host_wait(0);
   if (f0[0] != ~0ull) {
     g_last_error_index = (int64_t)f0[0];
     return DVP_EUNSAT;
@@ -704,10 +870,11 @@ static int prove_check_unsat(dvp_prover* p, hipStream_t st) {
 // defer_unsat (dvp_prove_dev only): the flag is NOT waited for here -- the commitment MSM does not need the host to know it, and its
 // own final synchronisation brings the flag block along (one host round trip less per proof; an unsatisfied witness then costs an
 // MSM before it is reported)
-static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_extend, void* stream, bool defer_unsat) {
+static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_extend, void* stream, bool defer_unsat, bool pub_to_host) {
   if (!p || !d_assignment || !prover_ready(p)) return DVP_EINVAL;
   p->last_begin_extended = false;  // set by dvp_prove_quotient once every extended vector is in place
   p->ext_filled = 0;
+  p->enc_fused[0] = p->enc_fused[1] = false;  // a staged caller may have abandoned a proof after an MSM into the prover's own slot
   hipStream_t st = (hipStream_t)stream;
   const uint32_t m = p->m;
   const size_t nw = p->n_wires;
@@ -715,7 +882,7 @@ static int prove_begin_impl(dvp_prover* p, const void* d_assignment, int need_ex
   // staging buffer of the host-pointer seam): one 32 B / wire copy per proof instead of two
   if (d_assignment != p->SA) DVP_HIP(hipMemcpyAsync(p->SA, d_assignment, nw * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   p->pub_host.resize((size_t)p->n_pub * 4);
-  if (p->n_pub) DVP_HIP(hipMemcpyAsync(p->pub_host.data(), p->SA + 1, (size_t)p->n_pub * 32, hipMemcpyDeviceToHost, st));
+  if (p->n_pub && pub_to_host) DVP_HIP(hipMemcpyAsync(p->pub_host.data(), p->SA + 1, (size_t)p->n_pub * 32, hipMemcpyDeviceToHost, st));
   DVP_HIP(hipMemsetAsync(p->flags, 0xff, 16, st));
   Csr A{p->mat[0].row_ptr, p->mat[0].wire, p->mat[0].coeff, p->mat[0].n_rows};
   Csr B{p->mat[1].row_ptr, p->mat[1].wire, p->mat[1].coeff, p->mat[1].n_rows};
@@ -794,7 +961,10 @@ extern "C" int dvp_prove_quotient(dvp_prover* p, void* stream) {
 // which = 1: <[k_a | k_b | k_r], [g_k_0 | g_k_1 | g_k_2]> (4m terms, src/proving.rs:666-680)
 // restricted to the index range [lo, hi): the per-GPU shard of the sum.
 // d_out_enc (optional): the MSM's tail kernel also writes the 30-byte encoding of its result there
-static int prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* d_out_enc, void* stream) {
+// d_err_defer (optional): deferred completion -- the call returns with the MSM enqueued (msm.hip: msm_core), its scalar-range word
+// goes to that device word and nothing is copied to the host
+static int prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* d_out_enc, void* stream,
+                              unsigned long long* d_err_defer = nullptr) {
   if (!p || (which != 0 && which != 1) || !d_out_xy || !d_out_inf) return DVP_EINVAL;
   size_t total = which ? 4 * (size_t)p->m : (size_t)p->n_wires + p->m;
   if (lo > hi || hi > total) return DVP_EINVAL;
@@ -820,10 +990,10 @@ static int prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, vo
     }
     const size_t o = p->fx_lo[which];
     return msm_fixed_dev_enc(p->fx[which], sc + lo, inf + lo, (uint32_t)(lo - o), (uint32_t)(hi - o), d_out_xy, d_out_inf, d_out_enc,
-                             d_out_enc ? p->fin_host : nullptr, p->abir0, FIN_BYTES, (hipStream_t)stream);
+                             d_out_enc && !d_err_defer ? p->fin_host : nullptr, p->abir0, FIN_BYTES, (hipStream_t)stream, d_err_defer);
   }
-  return msm_affine_dev_enc(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, d_out_enc, d_out_enc ? p->fin_host : nullptr, p->abir0, FIN_BYTES,
-                            (hipStream_t)stream);
+  return msm_affine_dev_enc(sc + lo, bs + lo, inf + lo, hi - lo, d_out_xy, d_out_inf, d_out_enc, d_out_enc && !d_err_defer ? p->fin_host : nullptr, p->abir0,
+                            FIN_BYTES, (hipStream_t)stream, d_err_defer);
 }
 extern "C" int dvp_prover_msm_partial(dvp_prover* p, int which, size_t lo, size_t hi, void* d_out_xy, void* d_out_inf, void* stream) {
   if (p && (which == 0 || which == 1) && d_out_xy == (void*)(p->pts + which)) p->enc_fused[which] = false;  // the point changes, its encoding does not follow
@@ -1012,20 +1182,49 @@ extern "C" size_t dvp_prover_msm_size(const dvp_prover* p, int which) {
   return which ? 4 * (size_t)p->m : (size_t)p->n_wires + p->m;
 }
 
+// the vector stages of the challenge phase (src/proving.rs:561-654) once alpha (Montgomery) is in p->chal_dev[0]: denominators,
+// one batch inversion over D and D', the three barycentric sums, a0 b0 i0 r0, the K scalars.  -Z_D(alpha) (p->chal_dev[1]) is needed
+// by k_bary3_final only: the host flavour copies it in with alpha; the device flavour computes it on the prover's side stream
+// meanwhile (z_on_side_stream: the stream joins the side stream in front of k_bary3_final).
+static int challenge_vector_stages(dvp_prover* p, hipStream_t st, bool z_on_side_stream) {
+  const uint32_t m = p->m;
+  dim3 gm(cdiv(m, PT)), bt(PT);
+  hipLaunchKernelGGL(k_alpha_denoms, gm, bt, 0, st, p->dD, p->dD2, p->chal_dev, m, p->den, p->den2, p->flags + 1);
+  DVP_TRY(batch_inverse_dev(p->den, 2 * (size_t)m, st));  // den2 = den + m
+  uint32_t nb = cdiv(m, PT);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_bary3_partial, dim3(nb), bt, 0, st, p->E, p->barw, p->den, m, p->partial);
+  if (z_on_side_stream) DVP_HIP(hipStreamWaitEvent(st, p->ev_negz, 0));
+  hipLaunchKernelGGL(k_bary3_final, dim3(1), bt, 0, st, p->partial, nb, p->chal_dev + 1, p->abir0);
+  hipLaunchKernelGGL(k_kscalars, gm, bt, 0, st, p->E, p->r2, p->den, p->den2, p->abir0, m, p->SK);
+  DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+// the same phase with the transcript on the device: commit_p's 30 bytes are where the commitment MSM's tail kernel wrote them
+// (p->enc), the public inputs in the witness vector; no host round trip
+static int challenge_dev(dvp_prover* p, hipStream_t st) {
+  hipLaunchKernelGGL(k_transcript, dim3(1), dim3(64), 0, st, (const uint32_t*)p->enc, p->SA + 1, p->n_pub, p->h_ct, p->alpha_dev, p->chal_dev);
+  DVP_HIP(hipEventRecord(p->ev_alpha, st));
+  DVP_HIP(hipStreamWaitEvent(p->side, p->ev_alpha, 0));
+  hipLaunchKernelGGL(k_zalpha, dim3(1), dim3(64), 0, p->side, p->chal_dev, p->tree->d_x0, p->tree->d_t, (int)p->log_m, p->tree->layer((int)p->log_m),
+                     p->chal_dev + 1);
+  DVP_HIP(hipEventRecord(p->ev_negz, p->side));
+  return challenge_vector_stages(p, st, /*z_on_side_stream=*/true);
+}
+
 // phase 2 (src/proving.rs:515-654): commit_p -> alpha -> a0,b0,i0,r0 -> K scalars SK.
 extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const void* d_commit_inf, void* stream) {
   if (!p || !d_commit_xy || !d_commit_inf) return DVP_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const uint32_t m = p->m;
-  dim3 gm(cdiv(m, PT)), bt(PT);
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
   if (d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0]) {
-    memcpy(p->commit_p_host, p->fin_host + 4 * sizeof(Fr) + 16, 30);  // encoded by the MSM's tail, on the host since the MSM's own sync
+    memcpy(p->commit_p_host, p->fin_host + FIN_OFF_ENC, 30);  // encoded by the MSM's tail, on the host since the MSM's own sync
   } else {
     DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
     DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
     DVP_HIP(hipStreamSynchronize(st));
+    count_host_wait(0);
   }
   p->enc_fused[0] = false;
   uint8_t ch[32];
@@ -1033,17 +1232,11 @@ extern "C" int dvp_prove_challenge(dvp_prover* p, const void* d_commit_xy, const
   Fr alpha;
   memcpy(alpha.v, ch, 32);
   p->alpha_canon = alpha;
-  Fr alpha_m = fr_to_mont(alpha);
-  Fr z_alpha_m = host_vanish(p, 0, alpha_m);
-  hipLaunchKernelGGL(k_alpha_denoms, gm, bt, 0, st, p->dD, p->dD2, alpha_m, m, p->den, p->den2, p->flags + 1);
-  DVP_TRY(batch_inverse_dev(p->den, 2 * (size_t)m, st));  // den2 = den + m
-  uint32_t nb = cdiv(m, PT);
-  if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(k_bary3_partial, dim3(nb), bt, 0, st, p->E, p->barw, p->den, m, p->partial);
-  hipLaunchKernelGGL(k_bary3_final, dim3(1), bt, 0, st, p->partial, nb, fr_neg(z_alpha_m), p->abir0);
-  hipLaunchKernelGGL(k_kscalars, gm, bt, 0, st, p->E, p->r2, p->den, p->den2, p->abir0, m, p->SK);
-  DVP_HIP(hipGetLastError());
-  return DVP_OK;
+  Fr* stage = (Fr*)(p->fin_host + FIN_BYTES);  // pinned; rewritten only after this proof's final synchronisation
+  stage[0] = fr_to_mont(alpha);
+  stage[1] = fr_neg(host_vanish(p, 0, stage[0]));
+  DVP_HIP(hipMemcpyAsync(p->chal_dev, stage, 2 * sizeof(Fr), hipMemcpyHostToDevice, st));
+  return challenge_vector_stages(p, st, /*z_on_side_stream=*/false);
 }
 
 // ---- phase 2 for index-sharded provers (one process per GPU; SURVEY 8e "pointwise / batch-inverse / barycentric": slice by
@@ -1063,11 +1256,12 @@ extern "C" int dvp_prove_challenge_partial(dvp_prover* p, const void* d_commit_x
   if (d_commit_xy != p->pts) DVP_HIP(hipMemcpyAsync(p->pts, d_commit_xy, sizeof(Aff), hipMemcpyDeviceToDevice, st));
   if (d_commit_inf != p->pts_inf32) DVP_HIP(hipMemcpyAsync(p->pts_inf32, d_commit_inf, 4, hipMemcpyDeviceToDevice, st));
   if (d_commit_xy == p->pts && d_commit_inf == p->pts_inf32 && p->enc_fused[0]) {
-    memcpy(p->commit_p_host, p->fin_host + 4 * sizeof(Fr) + 16, 30);  // encoded by the MSM's tail, on the host since the MSM's own sync
+    memcpy(p->commit_p_host, p->fin_host + FIN_OFF_ENC, 30);  // encoded by the MSM's tail, on the host since the MSM's own sync
   } else {
     DVP_TRY(encode_point_dev(p->pts, p->pts_inf32, p->enc, st));
     DVP_HIP(hipMemcpyAsync(p->commit_p_host, p->enc, 30, hipMemcpyDeviceToHost, st));
     DVP_HIP(hipStreamSynchronize(st));
+    count_host_wait(0);
   }
   p->enc_fused[0] = false;
   uint8_t ch[32];
@@ -1140,12 +1334,13 @@ extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void*
     DVP_TRY(encode_point_dev(p->pts + 1, p->pts_inf32 + 1, p->enc + 30, st));
     DVP_HIP(hipMemcpyAsync(p->fin_host, p->abir0, FIN_BYTES, hipMemcpyDeviceToHost, st));  // pinned: one DMA, no staging
     DVP_HIP(hipStreamSynchronize(st));
+    count_host_wait(0);
   }  // else: the K MSM's tail encoded kzg_k and fin_host was filled before that MSM's final sync (a0 b0 i0 r0 and the flags were final by then)
   p->enc_fused[1] = false;
   unsigned long long f[2];
   memcpy(p->abir0_host, p->fin_host, 4 * sizeof(Fr));
-  memcpy(f, p->fin_host + 4 * sizeof(Fr), 16);
-  const uint8_t* kz = p->fin_host + 4 * sizeof(Fr) + 16 + 30;
+  memcpy(f, p->fin_host + FIN_OFF_FLAGS, 16);
+  const uint8_t* kz = p->fin_host + FIN_OFF_ENC + 30;
   if (f[1] != ~0ull) {
     g_last_error_index = (int64_t)f[1];
     return DVP_ECHALLENGE;  // alpha in D u D', src/proving.rs:548-556
@@ -1158,8 +1353,9 @@ extern "C" int dvp_prove_finish(dvp_prover* p, const void* d_kzg_xy, const void*
 }
 
 // Proof::prove with the assignment already resident in HBM (the timed configuration of bench.py)
-extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t proof[118], void* stream) {
-  if (!p || !d_assignment || !proof) return DVP_EINVAL;
+// Host-transcript flavour (rounds 1-4; still what a device list, n_public > 35 or DVP_PROVE_HOST_TRANSCRIPT=1 gets): the host waits for
+// the commitment MSM, hashes, and enqueues the challenge phase.
+static int prove_dev_host_transcript(dvp_prover* p, const void* d_assignment, uint8_t proof[118], void* stream) {
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps(PROF_PROVE_TOTAL, st);
   DVP_TRY(prove_begin_impl(p, d_assignment, 1, stream, true));
@@ -1167,7 +1363,7 @@ extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t pr
     const int rc = prove_msm(p, 0, p->pts, p->pts_inf32, stream);
     if (rc == DVP_OK && p->enc_fused[0]) {  // fin_host = [a0 b0 i0 r0 | flags | encodings] as of the MSM's end
       unsigned long long f0;
-      memcpy(&f0, p->fin_host + 4 * sizeof(Fr), 8);
+      memcpy(&f0, p->fin_host + FIN_OFF_FLAGS, 8);
       if (f0 != ~0ull) {
         g_last_error_index = (int64_t)f0;
         return DVP_EUNSAT;
@@ -1181,6 +1377,46 @@ extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t pr
   DVP_TRY(prove_msm(p, 1, p->pts + 1, p->pts_inf32 + 1, stream));
   ps.stop();
   return dvp_prove_finish(p, p->pts + 1, p->pts_inf32 + 1, proof, stream);
+}
+// Device-transcript flavour (round 5, the default on one device): begin -> commitment MSM (deferred: no final synchronisation, its
+// tail kernel leaves commit_p's 30 bytes and its scalar-range word in the prover's block) -> k_transcript -> challenge phase -> K MSM,
+// whose own final synchronisation -- the ONE wait of the proof on its stream -- brings the block
+// [a0 b0 i0 r0 | flags | commit_p kzg_k | alpha | commitment MSM's word] to the host.  (Inside each MSM the host still reads the largest
+// bucket on a side stream while the first pair round runs; that read never idles the GPU.)  Errors are reported in the reference's
+// order from that block: unsatisfied row (src/proving.rs:389-395), scalar >= p in the witness (multi_scalar_mul's fr_to_le_bytes),
+// alpha in D u D' (:548-556), then the K MSM's own status.
+static int prove_dev_device_transcript(dvp_prover* p, const void* d_assignment, uint8_t proof[118], void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!p->shards.empty()) shards_release(p);
+  ProfScope ps(PROF_PROVE_TOTAL, st);
+  DVP_TRY(prove_begin_impl(p, d_assignment, 1, stream, true, /*pub_to_host=*/false));
+  DVP_TRY(prover_msm_partial(p, 0, 0, dvp_prover_msm_size(p, 0), p->pts, p->pts_inf32, p->enc, stream, p->msm_err));
+  DVP_TRY(challenge_dev(p, st));
+  const int rc_k = prover_msm_partial(p, 1, 0, dvp_prover_msm_size(p, 1), p->pts + 1, p->pts_inf32 + 1, p->enc + 30, stream);
+  ps.stop();
+  if (rc_k == DVP_EHIP) return rc_k;  // nothing was brought to the host
+  const int64_t k_idx = g_last_error_index;
+  unsigned long long f[2], e0;
+  memcpy(f, p->fin_host + FIN_OFF_FLAGS, 16);
+  memcpy(&e0, p->fin_host + FIN_OFF_MSMERR, 8);
+  memcpy(p->abir0_host, p->fin_host, 4 * sizeof(Fr));
+  memcpy(p->commit_p_host, p->fin_host + FIN_OFF_ENC, 30);
+  memcpy(p->alpha_canon.v, p->fin_host + FIN_OFF_ALPHA, 32);
+  if (f[0] != ~0ull) { g_last_error_index = (int64_t)f[0]; return DVP_EUNSAT; }
+  if (e0 != ~0ull) { g_last_error_index = (int64_t)(e0 & 0xffffffffull); return DVP_EINVAL; }
+  if (f[1] != ~0ull) { g_last_error_index = (int64_t)f[1]; return DVP_ECHALLENGE; }
+  if (rc_k != DVP_OK) { g_last_error_index = k_idx; return rc_k; }
+  memcpy(proof, p->commit_p_host, 30);
+  memcpy(proof + 30, p->fin_host + FIN_OFF_ENC + 30, 30);
+  memcpy(proof + 60, p->abir0_host[0].v, 29);  // FrBits::from_fr(a0): 232 LE bits, src/curve.rs:30-40
+  memcpy(proof + 89, p->abir0_host[1].v, 29);
+  return DVP_OK;
+}
+extern "C" int dvp_prove_dev(dvp_prover* p, const void* d_assignment, uint8_t proof[118], void* stream) {
+  if (!p || !d_assignment || !proof) return DVP_EINVAL;
+  if (mgpu_devices().size() <= 1 && p->n_pub <= TRANSCRIPT_DEV_MAX_PUB && !tune().prove_host_transcript)
+    return prove_dev_device_transcript(p, d_assignment, proof, stream);
+  return prove_dev_host_transcript(p, d_assignment, proof, stream);
 }
 
 // Proof::prove(cache_dir, public_inputs, private_inputs) -> Proof, src/proving.rs:426-688 (host witness).

@@ -105,6 +105,19 @@ __global__ void __launch_bounds__(TPB) ks_m_values(CsrT A, CsrT B, CsrT C, const
   Fr v = fr_add(fr_add(gather(A), fr_mul(delta_m, gather(B))), fr_mul(delta2_m, gather(C)));
   out[j] = fr_mul(eps_m, v);
 }
+// target -= s_m x (sum of the nb block partials of ks_dot_partial)   (canonical values, s_m Montgomery; one block)
+__global__ void __launch_bounds__(TPB) ks_fold_apply(const Fr* __restrict__ partial, uint32_t nb, Fr s_m, Fr* __restrict__ target) {
+  __shared__ Fr sh[TPB];
+  Fr acc = fr_zero();
+  for (uint32_t k = threadIdx.x; k < nb; k += TPB) acc = fr_add(acc, partial[k]);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = TPB / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *target = fr_sub(*target, fr_mul(s_m, sh[0]));
+}
 __global__ void __launch_bounds__(TPB) ks_to_mont(const Fr* __restrict__ a, Fr* __restrict__ o, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) o[i] = fr_to_mont(a[i]);
@@ -243,6 +256,16 @@ extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delt
   for (DevBuf* b : {&d, &d2, &bar, &z2inv, &bard, &z2dinv, &t1, &l_tau, &l_taud}) DVP_TRY(b->alloc(m * sizeof(Fr)));
   const size_t n_sc = (size_t)n_wires + 5 * m;  // g_m | g_q | g_k_0 | g_k_1 | g_k_2
   DVP_TRY(sc.alloc(n_sc * sizeof(Fr)));
+  // the discrete logs of the SRS and the Lagrange values at tau are trapdoor material (src/srs.rs:41-50): zeroed before their memory
+  // goes back to the allocator, on every exit
+  struct Wipe {
+    std::vector<DevBuf*> bufs;
+    ~Wipe() {
+      for (DevBuf* b : bufs)
+        if (b->p) (void)hipMemset(b->p, 0, b->bytes);
+      (void)hipDeviceSynchronize();
+    }
+  } wipe{{&sc, &l_tau, &l_taud, &t1}};
   Fr* s_gm = sc.as<Fr>();
   Fr* s_gq = s_gm + n_wires;
   Fr* s_k0 = s_gq + m;
@@ -295,21 +318,16 @@ extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delt
     DVP_TRY(pw.alloc(m * sizeof(Fr)));
     DVP_TRY(part.alloc((size_t)nb * sizeof(Fr)));
     hipLaunchKernelGGL(ks_fill_one, gm, bt, 0, st, pw.as<Fr>(), m);
-    std::vector<Fr> hp(nb);
     const Fr ed2_m = fr_to_mont(fr_mul(eps_m, fr_mul(delta2_m, fr_one_canon())));  // eps delta^2
+    // per public input: block partials of <d^j, L(tau)>, then ONE block folds them and subtracts eps delta^2 x the sum from the wire's
+    // scalar in place -- no copy to the host and no wait inside the loop (the first version took two host round trips per input)
     for (uint32_t j = 0; j < n_public; ++j) {
       hipLaunchKernelGGL(ks_dot_partial, dim3(nb), bt, 0, st, pw.as<Fr>(), l_tau.as<Fr>(), m, part.as<Fr>());
-      DVP_HIP(hipMemcpyAsync(hp.data(), part.p, (size_t)nb * sizeof(Fr), hipMemcpyDeviceToHost, st));
-      Fr cur;
-      DVP_HIP(hipMemcpyAsync(&cur, s_gm + 1 + j, sizeof(Fr), hipMemcpyDeviceToHost, st));
-      DVP_HIP(hipStreamSynchronize(st));
-      Fr dot = fr_zero();
-      for (uint32_t k = 0; k < nb; ++k) dot = fr_add(dot, hp[k]);
-      cur = fr_sub(cur, fr_mul(ed2_m, dot));
-      DVP_HIP(hipMemcpyAsync(s_gm + 1 + j, &cur, sizeof(Fr), hipMemcpyHostToDevice, st));
-      DVP_HIP(hipStreamSynchronize(st));
+      hipLaunchKernelGGL(ks_fold_apply, dim3(1), bt, 0, st, part.as<Fr>(), nb, ed2_m, s_gm + 1 + j);
       if (j + 1 < n_public) hipLaunchKernelGGL(ks_mul, gm, bt, 0, st, pw.as<Fr>(), d.as<Fr>(), pw.as<Fr>(), m);
     }
+    DVP_HIP(hipGetLastError());
+    DVP_HIP(hipStreamSynchronize(st));  // pw / part go out of scope
   }
   DVP_HIP(hipGetLastError());
   if (out_scalars) {
@@ -529,6 +547,24 @@ extern "C" int dvp_prover_prepares_precomputes(const char* cache_dir, int valida
   DVP_TRY(bar.alloc(m * sizeof(Fr)));
   DVP_TRY(zinv.alloc(m * sizeof(Fr)));
   DVP_TRY(ecfft_domain_tables_dev(tree, 0, bar.as<Fr>(), zinv.as<Fr>(), st));
+  // The regenerated tables belong to the MONIC Z_D; the reference derives both files from the z_poly it finds (1 / Z'(d_i) and
+  // 1 / Z(d'_i), src/proving.rs:284-304).  For z_poly = c Z_D (which passes the reference's own checks) they are therefore the
+  // monic tables times 1 / c: scaled here, so that what is written -- and what found files are compared with -- stays what a
+  // reference prover would compute from this directory.  A z_poly whose leading coefficient is zero has no such c: nothing is
+  // written or judged from it (DVP_PREP_BAD_Z_POLY).
+  const bool monic = zpoly[m * 4] == 1 && !zpoly[m * 4 + 1] && !zpoly[m * 4 + 2] && !zpoly[m * 4 + 3];
+  if (!monic) {
+    Fr c;
+    memcpy(c.v, &zpoly[m * 4], 32);
+    if (fr_is_zero(c) || !fr_is_canonical(c)) {
+      rep |= DVP_PREP_Z_POLY_NOT_MONIC | DVP_PREP_BAD_Z_POLY;
+      return DVP_EINVAL;
+    }
+    const Fr cinv_m = fr_inv(fr_to_mont(c));  // Montgomery: ks_scale(canonical, Montgomery) -> canonical
+    hipLaunchKernelGGL(ks_scale, gm, bt, 0, st, bar.as<Fr>(), cinv_m, bar.as<Fr>(), m);
+    hipLaunchKernelGGL(ks_scale, gm, bt, 0, st, zinv.as<Fr>(), cinv_m, zinv.as<Fr>(), m);
+    DVP_HIP(hipGetLastError());
+  }
   std::vector<uint64_t> host(m * 4), found(m * 4);
   static const struct { const char* name; uint32_t wrote, bad; } files[2] = {{"bar_wts", DVP_PREP_WROTE_BAR_WTS, DVP_PREP_BAD_BAR_WTS},
                                                                             {"z_vals2inv", DVP_PREP_WROTE_Z_VALS2INV, DVP_PREP_BAD_Z_VALS2INV}};
@@ -557,7 +593,7 @@ extern "C" int dvp_prover_prepares_precomputes(const char* cache_dir, int valida
     }
   }
   // ---- the vanishing polynomial (validate_precompute, :281-296 / :307-321) ----
-  if (zpoly[m * 4] != 1 || zpoly[m * 4 + 1] || zpoly[m * 4 + 2] || zpoly[m * 4 + 3]) rep |= DVP_PREP_Z_POLY_NOT_MONIC;
+  if (!monic) rep |= DVP_PREP_Z_POLY_NOT_MONIC;
   if (validate_precompute) {
     bool all_zero = true;
     for (uint64_t w : zpoly) all_zero = all_zero && w == 0;

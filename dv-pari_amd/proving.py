@@ -200,6 +200,15 @@ class Prover:
         check(lib.dvp_prover_debug_read(self._h, name.encode(), ptr(out), n), "dvp_prover_debug_read")
         return out
 
+    def transcript_dev(self, commit_p: bytes, public_inputs):
+        """(alpha, -Z_D(alpha)) from the DEVICE flavour of the transcript (k_transcript / k_zalpha): parity-test access"""
+        pub = _fr_arg(public_inputs)
+        cp = np.frombuffer(bytes(commit_p), dtype=np.uint8).copy()
+        a, z = np.zeros((1, 4), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64)
+        check(lib.dvp_prover_debug_transcript_dev(self._h, ptr(cp), ptr(pub) if pub.shape[0] else None, pub.shape[0], ptr(a), ptr(z)),
+              "dvp_prover_debug_transcript_dev")
+        return fr.to_int(a), fr.to_int(z)
+
     # ---- device-resident / phased flavours --------------------------------------------------------------
     def prove_dev(self, d_assignment: int, stream: int = 0) -> Proof:
         """assignment = [1, public.., private..] as n_wires x 4 uint64 already in HBM (device pointer)."""

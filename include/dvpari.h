@@ -296,7 +296,9 @@ int dvp_setup_cache_dir(const uint64_t tau[4], const uint64_t delta[4], const ui
 #define DVP_PREP_WROTE_TREE2N 0x1u
 #define DVP_PREP_WROTE_BAR_WTS 0x2u
 #define DVP_PREP_WROTE_Z_VALS2INV 0x4u
-#define DVP_PREP_Z_POLY_NOT_MONIC 0x8u /* informational: c Z_D with c != 1 passes the reference's check too */
+#define DVP_PREP_Z_POLY_NOT_MONIC 0x8u /* informational: c Z_D with c != 1 passes the reference's check too; bar_wts / z_vals2inv are then
+                                        * written (and found files compared) as the monic tables times 1 / c, i.e. what the reference derives
+                                        * from THAT z_poly; a zero leading coefficient is DVP_PREP_BAD_Z_POLY */
 #define DVP_PREP_BAD_Z_POLY 0x100u
 #define DVP_PREP_BAD_BAR_WTS 0x200u
 #define DVP_PREP_BAD_Z_VALS2INV 0x400u

@@ -26,7 +26,9 @@ void dvp_tune_reset(void);
 /* Per-kernel HIP-event timers for the measurement harness (bench.py): off by default.  Names:
  * "msm_affine_round0" (first k_affine_round of an MSM, the dominant kernel: it gathers the bases), "msm_affine_rest"
  * (the later pair rounds), "msm_sort" (recode + counting sort), "msm_tail" (merge tree, Frobenius tail), "msm_total",
- * "extend_total", "prove_total". */
+ * "extend_total", "prove_total"; and two counters that are always on (launches = count since dvp_profile_reset, total_ms = 0):
+ * "host_waits_stream" (synchronisations of the proof's own stream: the GPU idles until the host has reacted) and
+ * "host_waits_side" (an MSM's largest-bucket read, taken on a side stream while its first pair round runs). */
 void dvp_profile_enable(int on);
 void dvp_profile_reset(void);
 int dvp_profile_read(const char* name, double* total_ms, uint64_t* launches);
@@ -37,6 +39,10 @@ int dvp_profile_round0_shapes(uint64_t* pairs, double* total_ms, uint64_t* launc
 /* microbenchmark of the MSM kernels' GF(2^233) multiplier alone (products per second, whole chip, the pair rounds'
  * occupancy): the ceiling of bench.py's work model, measured in the same run */
 int dvp_ubench_gf_mul(int reps, double* products_per_s);
+/* the same for the ECFFT's multiplier: multiply-adds r = a b / R' + c per second of the lazy 30-bit-limb Fr multiplier (pairs of
+ * independent chains, as the twisted butterflies issue them), whole chip: the ceiling of bench.py's work model for extend / enter /
+ * exit (BASELINE configs #3 and #4) */
+int dvp_ubench_fr_mul(int reps, double* muladds_per_s);
 /* Wave-level trace of the batched-affine pair rounds (dvp::k_affine_round, tools/wave_trace.py).  d_buf = device buffer of
  * 64 + 64 * n_records bytes zeroed by the caller, NULL = off.  While set, every pair round appends one 64-byte record per
  * wave (8 u64: s_memrealtime at wave start / after pass 1 / after the shared inversion / at the end; s_memtime at start / end;
@@ -54,12 +60,19 @@ int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_tabl
  * digit is negative | w << 20 | |digit| (|digit| = 2^(c-1) is stored as key 0); *windows = ceil(234 / c_bits) */
 int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* windows);
 
-/* dvp_setup_cache_dir that also returns the discrete logs of the bases it wrote (host, (n_wires + 5 m) x 4 u64, file order
+/* TEST-ONLY (never bind this in a host): dvp_setup_cache_dir that also returns the discrete logs of the bases it wrote -- trapdoor
+ * material, which dvp_setup_cache_dir itself zeroes on the device before it returns -- (host, (n_wires + 5 m) x 4 u64, file order
  * g_m | g_q | g_k_0 | g_k_1 | g_k_2; NULL = not wanted; out_cap in elements) and the circuit's sizes: parity tests pin the SRS
  * and the proof's commitments with them */
 int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
                            uint32_t n_public, int write_precomputes, uint64_t* out_scalars, size_t out_cap, uint32_t* out_n_wires,
                            uint32_t* out_log2_m);
+
+/* the device flavour of the Fiat-Shamir transcript (what dvp_prove_dev runs between its two MSMs since round 5) on caller-supplied
+ * inputs: alpha (canonical, to be compared with dvp_transcript_challenge) and -Z_D(alpha) (canonical) for this prover's domain;
+ * n_public <= 35 (one BLAKE3 chunk of 29-byte inputs) */
+int dvp_prover_debug_transcript_dev(dvp_prover* p, const uint8_t commit_p[30], const uint64_t* public_inputs, uint32_t n_public,
+                                    uint64_t out_alpha[4], uint64_t out_neg_z_alpha[4]);
 
 /* intermediates of the last proof, for parity tests (names: see prove.hip) */
 int dvp_prover_debug_read(dvp_prover* p, const char* name, uint64_t* out, size_t n_elems);

@@ -149,7 +149,20 @@ def test_toy_cache_dir_end_to_end(dvp, tmp_path):
     z = dvp.io_utils.read_fr_vec_from_file(cache / A.Z_POLY)
     z2 = to_limbs([(2 * v) % o.P for v in from_limbs(z)])
     dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, z2)
+    # ... and the tables the reference derives from THAT z_poly (1 / Z'(d_i), 1 / Z(d'_i), src/proving.rs:284-304) are the monic ones
+    # times 1 / 2: the monic files now in the directory no longer belong to it, the regenerated ones do
+    with pytest.raises(ValueError, match="bar_wts"):
+        P.prover_prepares_precomputes(cache, validate_precompute=True)
+    monic = {n: from_limbs(dvp.io_utils.read_fr_vec_from_file(cache / n)) for n in (A.BAR_WTS, A.Z_VALS2_INV)}
+    os.remove(cache / A.BAR_WTS)
+    os.remove(cache / A.Z_VALS2_INV)
+    assert P.prover_prepares_precomputes(cache) == P.PREP_WROTE_BAR_WTS | P.PREP_WROTE_Z_VALS2INV | P.PREP_Z_POLY_NOT_MONIC
+    half = pow(2, -1, o.P)
+    for n in (A.BAR_WTS, A.Z_VALS2_INV):
+        assert from_limbs(dvp.io_utils.read_fr_vec_from_file(cache / n)) == [v * half % o.P for v in monic[n]]
     assert P.prover_prepares_precomputes(cache, validate_precompute=True) == P.PREP_Z_POLY_NOT_MONIC
+    for n in (A.BAR_WTS, A.Z_VALS2_INV):
+        (cache / n).write_bytes(before[n])
     zb = z.copy()
     zb[0, 0] ^= 1
     dvp.io_utils.write_fr_vec_to_file(cache / A.Z_POLY, zb)

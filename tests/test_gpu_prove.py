@@ -526,3 +526,105 @@ def test_two_provers_in_flight_same_bytes(dvp, slots, devices):
     for pv, *_ in jobs:
         pv.close()
     pv_u.close()
+
+
+def _prof_count(dvp, name):
+    import ctypes as C
+    ms, n = C.c_double(0), C.c_uint64(0)
+    dvp.check(dvp.lib.dvp_profile_read(name.encode(), C.byref(ms), C.byref(n)))
+    return int(n.value)
+
+
+def test_device_transcript_kernels_vs_oracle(dvp):
+    """k_transcript / k_zalpha (what dvp_prove_dev runs between its MSMs since round 5) against the oracle's transcript
+    (src/proving.rs:79-198) and the big-int vanishing polynomial, for 0 .. 35 public inputs (one BLAKE3 chunk of 29-byte inputs)"""
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(6)
+    pv = dvp.proving.Prover(inst)
+    rnd = random.Random(55)
+    d, _ = pv.domains()
+    dom = from_limbs(d)
+    for npub in (0, 1, 2, 3, 17, 34, 35):
+        pubs = [rnd.randrange(o.P) for _ in range(npub)]
+        if npub >= 2:
+            pubs[0], pubs[1] = 0, o.P - 1
+        commit = bytes(rnd.randrange(256) for _ in range(30))
+        alpha, neg_z = pv.transcript_dev(commit, pubs)
+        assert alpha == o.transcript_challenge(commit, pubs), npub
+        assert alpha == dvp.proving.transcript_challenge(commit, pubs), npub
+        z = 1
+        for x in dom:
+            z = z * (alpha - x) % o.P
+        assert neg_z == (-z) % o.P, npub
+    assert hex(pv.transcript_dev(bytes(range(30)), o.TOY_PUBLIC)[0]) == VEC["challenge_toy"]
+    with pytest.raises(dvp.DvpError):
+        pv.transcript_dev(bytes(30), [1] * 36)
+    pv.close()
+
+
+@pytest.mark.parametrize("log_m", [8, 17])
+def test_host_and_device_transcript_same_bytes_and_waits(dvp, log_m):
+    """dvp_prove_dev with the transcript on the device (default) and on the host (rounds 1-4, DVP_PROVE_HOST_TRANSCRIPT=1): same 118
+    bytes and same intermediates; the device flavour waits one time fewer on the proof's stream than the host flavour -- ONCE (the K
+    MSM's final synchronisation) as soon as the MSMs are large enough for pair rounds (2^17), where the read of the largest bucket
+    rides on a side stream behind the first round and is counted apart; a small MSM has to wait for that read mid-way"""
+    import torch
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(log_m)
+    rnd = random.Random(100 + log_m)
+    td = dvp.srs.Trapdoor(rnd.randrange(1, o.P), rnd.randrange(1, o.P), rnd.randrange(1, o.P))
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    w = torch.from_numpy(dvp.fr.vec([1] + pub + prv).view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for host in (1, 0, 1, 0):
+        with dvp.tune(DVP_PROVE_HOST_TRANSCRIPT=host):
+            pv.prove_dev(w.data_ptr(), st)  # tables, workspaces
+            dvp.lib.dvp_profile_reset()
+            proof = pv.prove_dev(w.data_ptr(), st)
+            waits = (_prof_count(dvp, "host_waits_stream"), _prof_count(dvp, "host_waits_side"))
+            mids = {k: from_limbs(pv.debug(k))[0] for k in ("alpha", "a0", "b0", "i0", "r0")}
+        res.setdefault(host, (proof, mids, waits))
+        assert res[host] == (proof, mids, waits)
+        assert waits[0] + waits[1] == (4 if host else 3), (host, waits)
+        if log_m >= 17:
+            assert waits == ((2, 2) if host else (1, 2)), (host, waits)
+    assert res[0][:2] == res[1][:2]
+    assert dvp.srs.verify(td, pub, res[0][0])
+    assert mids["alpha"] == o.transcript_challenge(res[0][0].commit_p, pub)
+    pv.close()
+
+
+def test_device_transcript_error_order(dvp):
+    """the deferred flavour reports from ONE block at the end, in the reference's order: an unsatisfied row first
+    (src/proving.rs:389-395), then a witness scalar >= p (the commitment MSM's range word, with its index)"""
+    import torch
+    inst, pub, prv = dvp.gnark_r1cs.synthetic_dense(10)
+    td = dvp.srs.Trapdoor(3, 5, 7)
+    pv = dvp.proving.Prover(inst)
+    pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
+    st = torch.cuda.current_stream().cuda_stream
+    good = dvp.fr.vec([1] + pub + prv)
+    proof = pv.prove_dev(torch.from_numpy(good.view(np.int64)).cuda().data_ptr(), st)
+    assert dvp.srs.verify(td, pub, proof)
+    # (1) a wire no row reads correctly any more: unsatisfied row index
+    bad = good.copy()
+    bad[5, 0] ^= np.uint64(1)
+    with pytest.raises(dvp.DvpError) as ei:
+        pv.prove_dev(torch.from_numpy(bad.view(np.int64)).cuda().data_ptr(), st)
+    assert ei.value.status == -3 and ei.value.index >= 0
+    # (2) a non-canonical wire (value + p < 2^256): the rows are evaluated on whatever the limbs hold, so either a row is reported
+    # (-3, as the reference asserts satisfaction first) or the commitment MSM's deferred range word names the wire (-1, index)
+    k = 7
+    v = int.from_bytes(good[k].tobytes(), "little") + o.P
+    bad = good.copy()
+    bad[k] = np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    with pytest.raises(dvp.DvpError) as ei:
+        pv.prove_dev(torch.from_numpy(bad.view(np.int64)).cuda().data_ptr(), st)
+    assert ei.value.status == -3 or (ei.value.status, ei.value.index) == (-1, k)
+    with dvp.tune(DVP_PROVE_HOST_TRANSCRIPT=1):
+        with pytest.raises(dvp.DvpError) as ej:
+            pv.prove_dev(torch.from_numpy(bad.view(np.int64)).cuda().data_ptr(), st)
+    assert (ej.value.status, ej.value.index) == (ei.value.status, ei.value.index)
+    # the prover is usable afterwards and gives the same bytes
+    assert pv.prove_dev(torch.from_numpy(good.view(np.int64)).cuda().data_ptr(), st) == proof
+    pv.close()
