@@ -220,10 +220,14 @@ def main():
         # host five times per proof where dvp_prove_dev waits once); N ranks: the phased entries with the MSMs sharded
         if args.inproc or world == 1:
             return pv.prove_dev(assignment.data_ptr(), stream)
-        return dvp.distributed.prove_sharded(gpu_backend, assignment)
+        return dvp.distributed.prove_sharded(gpu_backend, assignment, plan_costs=plan_costs)
 
+    plan_costs = None
     if world > 1:  # communicator set-up is not part of a proof: one throw-away exchange even with --warmup 0
         dvp.distributed.probe_collectives(dev)
+        # what the shard plan charges an extender rank is MEASURED here (one timed extend, one timed broadcast of an m-vector, one timed
+        # MSM slice; max over ranks) instead of typed in: the plan adapts to the real xGMI cost of the vector exchange
+        plan_costs = dvp.distributed.measure_plan_costs(gpu_backend, assignment)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -251,6 +255,19 @@ def main():
         elapsed = max(float(x[0].item()) for x in allt)
         rank_ms = [float(x[1].item()) / args.steps * 1e3 for x in allt]
         dist_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        # every rank's own stage times (HIP events of its own launches) and its slice of the plan, so that a bad plan shows in one run
+        mine = {"rank": rank}
+        for nm in ("msm_total", "msm_sort", "msm_affine_round0", "msm_affine_rest", "msm_tail", "extend_total"):
+            ms_, n_ = C.c_double(0), C.c_uint64(0)
+            dvp.check(dvp.lib.dvp_profile_read(nm.encode(), C.byref(ms_), C.byref(n_)))
+            mine[nm + "_ms_per_step"] = ms_.value / args.steps
+        allm = [None] * world
+        dist.all_gather_object(allm, mine)
+        plan_ = dvp.distributed.shard_plan(world, inst.n_wires, m, extend_pairs=plan_costs)
+        dist_info["shard_plan"] = [{"rank": r_, "commit_msm_range": list(pa), "k_msm_range": list(pb), "extends": bool(ne),
+                                    "pairs": (pa[1] - pa[0]) + (pb[1] - pb[0])} for r_, (pa, pb, ne) in enumerate(plan_)]
+        dist_info["shard_plan_costs"] = plan_costs
+        dist_info["stages_ms_per_step_by_rank"] = allm
 
     def prof(name):
         ms, n = C.c_double(0), C.c_uint64(0)

@@ -42,6 +42,7 @@ _SIGS = {
     "dvp_debug_ecfft_layer": (C.c_int, [vp, u32, u64p]),
     "dvp_ubench_gf_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "dvp_ubench_fr_mul": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "dvp_setup_scalars": (C.c_int, [u64p, u64p, u64p, u32, u32, u32, u32, u64p, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p, sz]),
     "dvp_debug_wave_trace": (C.c_int, [vp, u32]),
     "dvp_profile_enable": (None, [C.c_int]),
     "dvp_profile_reset": (None, []),

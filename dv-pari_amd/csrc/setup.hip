@@ -199,73 +199,53 @@ Fr load_fr(const uint64_t v[4]) {
 
 using namespace dvp;
 
-// out_scalars (optional, host, (n_wires + 5 m) x 4 u64): the discrete logs of the bases written, in file order g_m | g_q |
-// g_k_0 | g_k_1 | g_k_2 -- what a test pins the proof's commitments with.  *out_n_wires / *out_log2_m (optional) report the sizes.
-extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
-                                      uint32_t n_public, int write_precomputes, uint64_t* out_scalars, size_t out_cap, uint32_t* out_n_wires,
-                                      uint32_t* out_log2_m) {
-  if (!tau || !delta || !epsilon || !cache_dir) return DVP_EINVAL;
-  const Fr tau_c = load_fr(tau), delta_c = load_fr(delta), eps_c = load_fr(epsilon);
-  if (!fr_is_canonical(tau_c) || !fr_is_canonical(delta_c) || !fr_is_canonical(eps_c)) return DVP_EINVAL;
-  if (fr_is_zero(tau_c) || fr_is_zero(delta_c) || fr_is_zero(eps_c)) return DVP_EINVAL;  // src/srs.rs:199-201
-  const std::string dir(cache_dir);
-  auto path = [&](const char* name) { return dir + "/" + name; };
-  // ---- the circuit (src/gnark_r1cs.rs:121-185) ----
-  File dump;
-  DVP_TRY(dump.open_ro(path("r1cs_to_dvsnark").c_str()));  // R1CS_CONSTRAINTS_FILE, src/artifacts.rs:76
+// The scalar pipeline of SRS::verifier_runs_setup on the device (src/srs.rs:177-361 -> compute_srs_matrices' inputs, :112-160): the
+// domain tables from the isogeny chain, L_i(tau) / L'_i(tau) by the barycentric formula, the unified-domain values, accumulate_m_values
+// as a gather per wire over the transposed matrices, the Vandermonde fold.  ONE implementation: dvp_setup_cache_dir feeds it the
+// parsed dump, dvp_setup_scalars (the in-memory flavour srs.py uses for circuits that exist only in python) a caller's CSR.
+namespace {
+struct SetupCircuit {
   uint32_t n_coeffs = 0, n_rows = 0, n_wires = 0;
-  uint64_t nnz[3] = {0, 0, 0};
-  DVP_TRY(dvp_r1cs_dump_sizes(dump.p, dump.len, &n_coeffs, &n_rows, nnz, &n_wires));
-  if (n_rows == 0 || n_wires < 1 + (uint64_t)n_public) return DVP_EINVAL;
-  for (int k = 0; k < 3; ++k)
-    if (nnz[k] > 0xffffffffull) return DVP_EINVAL;
+  const uint64_t* coeffs = nullptr;       // n_coeffs x 4, canonical
+  const uint32_t* rp[3] = {nullptr, nullptr, nullptr};  // L, R, O: CSR over n_rows rows
+  const uint32_t* wi[3] = {nullptr, nullptr, nullptr};
+  const uint32_t* ci[3] = {nullptr, nullptr, nullptr};
+};
+struct SetupState {
+  dvp_ecfft* tree = nullptr;
   uint32_t log_m = 0;
-  while ((1ull << log_m) < n_rows) ++log_m;  // next_power_of_two, src/gnark_r1cs.rs:291
-  if (log_m < 1) log_m = 1;
-  if (log_m > DVP_MAX_LOG2_CONSTRAINTS) return DVP_EINVAL;
-  const size_t m = (size_t)1 << log_m;
-  if (out_n_wires) *out_n_wires = n_wires;
-  if (out_log2_m) *out_log2_m = log_m;
-  if (out_scalars && out_cap < (size_t)n_wires + 5 * m) return DVP_EINVAL;
-  std::vector<uint64_t> coeffs((size_t)4 * n_coeffs);
-  std::vector<uint32_t> rp[3], wi[3], ci[3];
-  uint32_t *rpp[3], *wip[3], *cip[3];
-  for (int k = 0; k < 3; ++k) {
-    rp[k].resize((size_t)n_rows + 1);
-    wi[k].resize(nnz[k] ? nnz[k] : 1);
-    ci[k].resize(nnz[k] ? nnz[k] : 1);
-    rpp[k] = rp[k].data(); wip[k] = wi[k].data(); cip[k] = ci[k].data();
+  size_t m = 0, n_sc = 0;
+  DevBuf d, d2, bar, z2inv, bard, z2dinv, t1, l_tau, l_taud, sc;
+  ~SetupState() {
+    // the discrete logs of the SRS and the Lagrange values at tau are trapdoor material (src/srs.rs:41-50): zeroed before their memory
+    // goes back to the allocator, on every exit
+    for (DevBuf* b : {&sc, &l_tau, &l_taud, &t1})
+      if (b->p) (void)hipMemset(b->p, 0, b->bytes);
+    (void)hipDeviceSynchronize();
+    if (tree) dvp_ecfft_destroy(tree);
   }
-  DVP_TRY(dvp_r1cs_dump_fill(dump.p, dump.len, coeffs.data(), rpp, wip, cip));
+  Fr* s_gm() { return sc.as<Fr>(); }
+};
+int setup_scalars_core(const SetupCircuit& cc, const uint64_t tau[4], const Fr& tau_c, const Fr& delta_c, const Fr& eps_c, uint32_t n_public, SetupState& S,
+                       hipStream_t st) {
+  const uint32_t n_coeffs = cc.n_coeffs, n_rows = cc.n_rows, n_wires = cc.n_wires;
+  const size_t m = S.m;
   DevBuf d_coeffs, tptr[3], trow[3], tcid[3];
-  DVP_TRY(up(d_coeffs, coeffs.data(), (size_t)n_coeffs * 32));
+  DVP_TRY(up(d_coeffs, cc.coeffs, (size_t)n_coeffs * 32));
   for (int k = 0; k < 3; ++k) {
     std::vector<uint32_t> a, b, c;
-    transpose(n_rows, n_wires, rpp[k], wip[k], cip[k], a, b, c);
+    transpose(n_rows, n_wires, cc.rp[k], cc.wi[k], cc.ci[k], a, b, c);
     DVP_TRY(up(tptr[k], a.data(), a.size() * 4));
     DVP_TRY(up(trow[k], b.data(), b.size() * 4));
     DVP_TRY(up(tcid[k], c.data(), c.size() * 4));
-    rp[k] = std::vector<uint32_t>(); wi[k] = std::vector<uint32_t>(); ci[k] = std::vector<uint32_t>();
   }
   // ---- the domains and their tables (TREE_2N, src/srs.rs:216-346) ----
-  dvp_ecfft* tree = nullptr;
-  DVP_TRY(dvp_ecfft_create(log_m + 1, 0, 0, &tree));
-  struct TreeGuard { dvp_ecfft* t; ~TreeGuard() { if (t) dvp_ecfft_destroy(t); } } tree_guard{tree};
-  hipStream_t st = nullptr;
-  DevBuf d, d2, bar, z2inv, bard, z2dinv, t1, l_tau, l_taud, sc;
+  DVP_TRY(dvp_ecfft_create(S.log_m + 1, 0, 0, &S.tree));
+  dvp_ecfft* tree = S.tree;
+  DevBuf &d = S.d, &d2 = S.d2, &bar = S.bar, &z2inv = S.z2inv, &bard = S.bard, &z2dinv = S.z2dinv, &t1 = S.t1, &l_tau = S.l_tau, &l_taud = S.l_taud, &sc = S.sc;
   for (DevBuf* b : {&d, &d2, &bar, &z2inv, &bard, &z2dinv, &t1, &l_tau, &l_taud}) DVP_TRY(b->alloc(m * sizeof(Fr)));
-  const size_t n_sc = (size_t)n_wires + 5 * m;  // g_m | g_q | g_k_0 | g_k_1 | g_k_2
-  DVP_TRY(sc.alloc(n_sc * sizeof(Fr)));
-  // the discrete logs of the SRS and the Lagrange values at tau are trapdoor material (src/srs.rs:41-50): zeroed before their memory
-  // goes back to the allocator, on every exit
-  struct Wipe {
-    std::vector<DevBuf*> bufs;
-    ~Wipe() {
-      for (DevBuf* b : bufs)
-        if (b->p) (void)hipMemset(b->p, 0, b->bytes);
-      (void)hipDeviceSynchronize();
-    }
-  } wipe{{&sc, &l_tau, &l_taud, &t1}};
+  S.n_sc = (size_t)n_wires + 5 * m;  // g_m | g_q | g_k_0 | g_k_1 | g_k_2
+  DVP_TRY(sc.alloc(S.n_sc * sizeof(Fr)));
   Fr* s_gm = sc.as<Fr>();
   Fr* s_gq = s_gm + n_wires;
   Fr* s_k0 = s_gq + m;
@@ -330,6 +310,104 @@ extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delt
     DVP_HIP(hipStreamSynchronize(st));  // pw / part go out of scope
   }
   DVP_HIP(hipGetLastError());
+  return DVP_OK;
+}
+int setup_check_trapdoor(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], Fr& tau_c, Fr& delta_c, Fr& eps_c) {
+  if (!tau || !delta || !epsilon) return DVP_EINVAL;
+  tau_c = load_fr(tau); delta_c = load_fr(delta); eps_c = load_fr(epsilon);
+  if (!fr_is_canonical(tau_c) || !fr_is_canonical(delta_c) || !fr_is_canonical(eps_c)) return DVP_EINVAL;
+  if (fr_is_zero(tau_c) || fr_is_zero(delta_c) || fr_is_zero(eps_c)) return DVP_EINVAL;  // src/srs.rs:199-201
+  return DVP_OK;
+}
+}  // namespace
+
+// TEST / HARNESS ONLY (include/dvpari_internal.h): the SRS scalars (discrete logs: trapdoor material) of an IN-MEMORY circuit -- CSR
+// matrices L, R, O over n_rows <= 2^log2_m rows, coefficient table, n_wires -- in file order g_m | g_q | g_k_0 | g_k_1 | g_k_2
+// ((n_wires + 5 m) x 4 u64): the same device pipeline dvp_setup_cache_dir runs on a parsed dump (srs.py: srs_scalars)
+extern "C" int dvp_setup_scalars(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], uint32_t log2_m, uint32_t n_public,
+                                 uint32_t n_rows, uint32_t n_wires, const uint64_t* coeffs, uint32_t n_coeffs, const uint32_t* const row_ptr[3],
+                                 const uint32_t* const wire_ids[3], const uint32_t* const coeff_ids[3], uint64_t* out_scalars, size_t out_cap) {
+  Fr tau_c, delta_c, eps_c;
+  DVP_TRY(setup_check_trapdoor(tau, delta, epsilon, tau_c, delta_c, eps_c));
+  if (!row_ptr || !wire_ids || !coeff_ids || !out_scalars || (n_coeffs && !coeffs)) return DVP_EINVAL;
+  if (log2_m < 1 || log2_m > DVP_MAX_LOG2_CONSTRAINTS || n_rows == 0 || n_rows > (1ull << log2_m) || n_wires < 1 + (uint64_t)n_public) return DVP_EINVAL;
+  SetupCircuit cc;
+  cc.n_coeffs = n_coeffs; cc.n_rows = n_rows; cc.n_wires = n_wires; cc.coeffs = coeffs;
+  for (int k = 0; k < 3; ++k) {
+    if (!row_ptr[k] || row_ptr[k][0] != 0) return DVP_EINVAL;
+    for (uint32_t i = 0; i < n_rows; ++i)
+      if (row_ptr[k][i + 1] < row_ptr[k][i]) { g_last_error_index = (int64_t)i; return DVP_EINVAL; }
+    const size_t nnz = row_ptr[k][n_rows];
+    if (nnz && (!wire_ids[k] || !coeff_ids[k])) return DVP_EINVAL;
+    for (size_t e = 0; e < nnz; ++e)
+      if (wire_ids[k][e] >= n_wires || coeff_ids[k][e] >= n_coeffs) { g_last_error_index = (int64_t)e; return DVP_EINVAL; }
+    cc.rp[k] = row_ptr[k]; cc.wi[k] = wire_ids[k]; cc.ci[k] = coeff_ids[k];
+  }
+  SetupState S;
+  S.log_m = log2_m;
+  S.m = (size_t)1 << log2_m;
+  if (out_cap < (size_t)n_wires + 5 * S.m) return DVP_EINVAL;
+  hipStream_t st = nullptr;
+  DVP_TRY(setup_scalars_core(cc, tau, tau_c, delta_c, eps_c, n_public, S, st));
+  DVP_HIP(hipMemcpyAsync(out_scalars, S.sc.p, S.n_sc * sizeof(Fr), hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipStreamSynchronize(st));
+  return DVP_OK;
+}
+
+// out_scalars (optional, host, (n_wires + 5 m) x 4 u64): the discrete logs of the bases written, in file order g_m | g_q |
+// g_k_0 | g_k_1 | g_k_2 -- what a test pins the proof's commitments with.  *out_n_wires / *out_log2_m (optional) report the sizes.
+extern "C" int dvp_setup_cache_dir_ex(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], const char* cache_dir,
+                                      uint32_t n_public, int write_precomputes, uint64_t* out_scalars, size_t out_cap, uint32_t* out_n_wires,
+                                      uint32_t* out_log2_m) {
+  if (!cache_dir) return DVP_EINVAL;
+  Fr tau_c, delta_c, eps_c;
+  DVP_TRY(setup_check_trapdoor(tau, delta, epsilon, tau_c, delta_c, eps_c));
+  const std::string dir(cache_dir);
+  auto path = [&](const char* name) { return dir + "/" + name; };
+  // ---- the circuit (src/gnark_r1cs.rs:121-185) ----
+  File dump;
+  DVP_TRY(dump.open_ro(path("r1cs_to_dvsnark").c_str()));  // R1CS_CONSTRAINTS_FILE, src/artifacts.rs:76
+  uint32_t n_coeffs = 0, n_rows = 0, n_wires = 0;
+  uint64_t nnz[3] = {0, 0, 0};
+  DVP_TRY(dvp_r1cs_dump_sizes(dump.p, dump.len, &n_coeffs, &n_rows, nnz, &n_wires));
+  if (n_rows == 0 || n_wires < 1 + (uint64_t)n_public) return DVP_EINVAL;
+  for (int k = 0; k < 3; ++k)
+    if (nnz[k] > 0xffffffffull) return DVP_EINVAL;
+  uint32_t log_m = 0;
+  while ((1ull << log_m) < n_rows) ++log_m;  // next_power_of_two, src/gnark_r1cs.rs:291
+  if (log_m < 1) log_m = 1;
+  if (log_m > DVP_MAX_LOG2_CONSTRAINTS) return DVP_EINVAL;
+  const size_t m = (size_t)1 << log_m;
+  if (out_n_wires) *out_n_wires = n_wires;
+  if (out_log2_m) *out_log2_m = log_m;
+  if (out_scalars && out_cap < (size_t)n_wires + 5 * m) return DVP_EINVAL;
+  std::vector<uint64_t> coeffs((size_t)4 * n_coeffs);
+  std::vector<uint32_t> rp[3], wi[3], ci[3];
+  uint32_t *rpp[3], *wip[3], *cip[3];
+  for (int k = 0; k < 3; ++k) {
+    rp[k].resize((size_t)n_rows + 1);
+    wi[k].resize(nnz[k] ? nnz[k] : 1);
+    ci[k].resize(nnz[k] ? nnz[k] : 1);
+    rpp[k] = rp[k].data(); wip[k] = wi[k].data(); cip[k] = ci[k].data();
+  }
+  DVP_TRY(dvp_r1cs_dump_fill(dump.p, dump.len, coeffs.data(), rpp, wip, cip));
+  SetupCircuit cc;
+  cc.n_coeffs = n_coeffs; cc.n_rows = n_rows; cc.n_wires = n_wires; cc.coeffs = coeffs.data();
+  for (int k = 0; k < 3; ++k) { cc.rp[k] = rpp[k]; cc.wi[k] = wip[k]; cc.ci[k] = cip[k]; }
+  SetupState S;
+  S.log_m = log_m;
+  S.m = m;
+  hipStream_t st = nullptr;
+  DVP_TRY(setup_scalars_core(cc, tau, tau_c, delta_c, eps_c, n_public, S, st));
+  dvp_ecfft* tree = S.tree;
+  DevBuf &bar = S.bar, &z2inv = S.z2inv, &bard = S.bard, &z2dinv = S.z2dinv, &t1 = S.t1, &sc = S.sc;
+  const size_t n_sc = S.n_sc;
+  Fr* s_gm = sc.as<Fr>();
+  Fr* s_gq = s_gm + n_wires;
+  Fr* s_k0 = s_gq + m;
+  Fr* s_k1 = s_k0 + m;
+  Fr* s_k2 = s_k1 + m;
+  const dim3 gm(cdiv(m, TPB)), bt(TPB);
   if (out_scalars) {
     DVP_HIP(hipMemcpyAsync(out_scalars, sc.p, n_sc * sizeof(Fr), hipMemcpyDeviceToHost, st));
     DVP_HIP(hipStreamSynchronize(st));

@@ -25,21 +25,29 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_plan(world: int, n_wires: int, m: int, extend_pairs: float = None):
+def shard_plan(world: int, n_wires: int, m: int, extend_pairs=None):
     """Per-rank (range of MSM 0, range of MSM 1, need_extend).  MSM 0 runs over [w (n_wires) | q2 (m)], MSM 1 over
     [k_a (m) | k_b (m) | k_r (2m)]; q2 and k_r need the extends (q2 itself, r2 inside k_r), the rest does not.  With s
     "extender" ranks (the last s) and cost E of the extends expressed in (scalar, base) pairs, the non-extenders take X
     pairs of the extend-free part and the extenders everything else; X equalises the two loads where the caps allow, and
-    s minimises the larger load.  s == world (uniform slices, every rank extends) is what small worlds get."""
+    s minimises the larger load.  s == world (uniform slices, every rank extends) is what small worlds get.
+    extend_pairs: None = the typed-in defaults below; a number = that cost for every s; a dict {"replicated": pairs,
+    "split": pairs} = what measure_plan_costs MEASURED on this machine (every rank must pass the same values)."""
     ta, tb = n_wires + m, 4 * m
     cap_a, cap_b = n_wires, 2 * m
-    # measured on MI355X (tools/shard_profile.py): R1CS evaluation + three extends + quotient of 2^20 = 1.58 ms, the time the
-    # sharded MSMs take for ~0.42 * 2^20 (scalar, base) pairs.  From three extenders up the extends are split by vector
+    # defaults, measured on ONE MI355X (tools/shard_profile.py): R1CS evaluation + three extends + quotient of 2^20 = 1.58 ms, the
+    # time the sharded MSMs take for ~0.42 * 2^20 (scalar, base) pairs.  From three extenders up the extends are split by vector
     # (prove_sharded): an extender then spends 0.25 ms (quotient only) to 0.9 ms (one vector + quotient) plus the broadcasts
-    # of the vectors it does not own (64-96 MB in over xGMI, not measurable on a one-GPU box): charged as 0.30 * m pairs
+    # of the vectors it does not own (64-96 MB in over xGMI, which a one-GPU box cannot time): charged as 0.30 * m pairs.
+    # bench.py --gpus N replaces both by measure_plan_costs (one timed extend, one timed broadcast, one timed MSM slice).
     best = None
     for s in range(world, 0, -1):
-        e = (0.42 if s < 3 else 0.30) * m if extend_pairs is None else extend_pairs
+        if extend_pairs is None:
+            e = (0.42 if s < 3 else 0.30) * m
+        elif isinstance(extend_pairs, dict):
+            e = float(extend_pairs["replicated" if s < 3 else "split"])
+        else:
+            e = float(extend_pairs)
         if s == world:
             x, load = 0.0, e + (ta + tb) / world
         else:
@@ -215,6 +223,71 @@ def probe_collectives(device, group=None):
     return mode
 
 
+def measure_plan_costs(backend, assignment, group=None, reps: int = 3):
+    """What shard_plan charges an extender rank, MEASURED on this machine instead of typed in: one timed begin with and without
+    the extends, one timed single-vector extend + quotient, one timed broadcast of an m-vector inside `group` (the exchange of
+    the vector split), and one timed slice of the K MSM (the exchange rate between milliseconds and (scalar, base) pairs).
+    Collective: every rank of `group` calls it at the same point (bench.py: before the warm-up); the ranks agree on the MAXIMUM
+    of each figure.  Returns {"replicated": pairs, "split": pairs, "ms": {...}} -- pass it to prove_sharded(plan_costs=..)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n_wires, m = backend.dims()
+    dev = assignment.device
+
+    def timed(fn):
+        fn()
+        best = None
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            best = t if best is None or t < best else best
+        return best
+
+    n_ext = backend.extend_count()
+    t_full = timed(lambda: backend.begin(assignment, True))
+    t_none = timed(lambda: backend.begin(assignment, False))
+
+    def one_vector():
+        backend.begin(assignment, False)
+        backend.extend_vectors([0])
+    t_one = timed(one_vector) - t_none
+    # quotient alone = full - none - n_ext vectors (the batched extend shares its constants, so this is a slight over-estimate)
+    t_quot = max(0.0, t_full - t_none - n_ext * t_one)
+    t_bcast = 0.0
+    if world > 1:
+        buf = backend.extended_tensor(0)
+
+        def bc():
+            dist.broadcast(buf, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        t_bcast = timed(bc)
+    lo, hi = shard_range(4 * m, rank, world)
+    backend.begin(assignment, True)
+    zero_pt = torch.zeros(10, dtype=torch.int64, device=dev)
+    zero_pt[8] = 1  # the point at infinity as a commitment: alpha is then the transcript of the zero encoding -- any alpha serves a timing
+    backend.challenge(zero_pt) if hasattr(backend, "challenge") else None
+    t_msm = timed(lambda: backend.msm_partial(1, lo, hi))
+    pairs_per_ms = (hi - lo) / t_msm if t_msm > 0 else float(m)
+    fig = torch.tensor([t_full, t_none, t_one, t_quot, t_bcast, 1.0 / pairs_per_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(fig, op=dist.ReduceOp.MAX, group=group)
+    t_full, t_none, t_one, t_quot, t_bcast, ms_per_pair = (float(x) for x in fig.tolist())
+    ext_ranks_guess = max(3, min(world, n_ext))
+    own = -(-n_ext // ext_ranks_guess)  # vectors an extender extends itself under the split
+    split_ms = own * t_one + (n_ext - own) * t_bcast + t_quot
+    return {"replicated": (t_full - t_none) / ms_per_pair, "split": split_ms / ms_per_pair,
+            "ms": {"begin_with_extends": t_full, "begin_without": t_none, "extend_one_vector": t_one, "quotient": t_quot,
+                   "broadcast_one_vector": t_bcast, "msm_ms_per_million_pairs": ms_per_pair * 1e6, "split_extender_extra": split_ms},
+            "note": "measured once per group (max over ranks); shard_plan charges an extender rank `replicated` pairs when fewer than three ranks "
+                    "extend and `split` pairs under the vector split"}
+
+
 def _all_gather_records(part, world, group):
     """[world, k] tensor of every rank's record: ONE collective into one preallocated tensor where the backend has
     all_gather_into_tensor (RCCL does), the list form + stack otherwise (decided by probe_collectives, never mid-run)"""
@@ -259,7 +332,7 @@ def extend_owner(v, ext_ranks):
     return ext_ranks[v % len(ext_ranks)]
 
 
-def prove_sharded(backend, assignment, group=None, always_gather=False, shard_extends=True):
+def prove_sharded(backend, assignment, group=None, always_gather=False, shard_extends=True, plan_costs=None):
     """Proof::prove (src/proving.rs:426-688) with both MSMs sharded over the ranks of `group`.
     Every rank returns the same proof.  always_gather runs the collectives and the record combination even in a
     one-rank group (how a one-GPU box executes the RCCL calls of this path for real).
@@ -272,7 +345,7 @@ def prove_sharded(backend, assignment, group=None, always_gather=False, shard_ex
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_wires, m = backend.dims()
-    plan = shard_plan(world, n_wires, m)
+    plan = shard_plan(world, n_wires, m, extend_pairs=plan_costs)  # plan_costs: measure_plan_costs' figures (the same on every rank) or None
     range_a, range_b, need_extend = plan[rank]
     ext_ranks = [r for r in range(world) if plan[r][2]]
     # worth it from three extenders up (one vector each): with two, the rank that owns two vectors saves one extend

@@ -33,11 +33,34 @@ class SRS:
 
 
 def srs_scalars(prover, inst: R1CSInstance, td: Trapdoor):
-    """(The in-memory flavour, for instances that exist only in python -- bench.py's synthetic circuits, the tests; the
-    cache_dir flavour below is one library call with every vector resident on the device, dvp_setup_cache_dir.)
-    The scalars k with base = k*G for every SRS vector: verifier_runs_setup + compute_srs_matrices,
-    src/srs.rs:112-167,177-361 (Lagrange bases at tau through the barycentric formula,
-    src/ec_fft.rs:340-390,424-450; accumulate_m_values, src/srs.rs:53-84)."""
+    """The scalars k with base = k*G for every SRS vector of an instance that exists only in python (bench.py's synthetic
+    circuits, the tests): verifier_runs_setup + compute_srs_matrices, src/srs.rs:112-167,177-361 (Lagrange bases at tau through
+    the barycentric formula, src/ec_fft.rs:340-390,424-450; accumulate_m_values, src/srs.rs:53-84).  ONE implementation since
+    round 5: the device pipeline of dvp_setup_cache_dir (csrc/setup.hip: setup_scalars_core), fed this instance's CSR matrices
+    through dvp_setup_scalars; rounds 1-4 orchestrated the same stages from here, vector by vector over the host-pointer seams
+    (srs_scalars_hostside below keeps that route as the cross-check the tests compare against)."""
+    import ctypes as C
+
+    from ._native import lib, check, ptr
+
+    assert td.tau % P and td.delta % P and td.epsilon % P  # src/srs.rs:199-201
+    m = inst.num_constraints
+    log_m = m.bit_length() - 1
+    t, d, e = (fr.limbs(x) for x in (td.tau, td.delta, td.epsilon))
+    mats = (inst.l, inst.r, inst.o)
+    keep = [[np.ascontiguousarray(getattr(mt, f), dtype=np.uint32) for mt in mats] for f in ("row_ptr", "wire", "coeff")]
+    arr = [(C.c_void_p * 3)(*[a.ctypes.data for a in col]) for col in keep]
+    coeffs = np.ascontiguousarray(inst.coeffs, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((inst.n_wires + 5 * m, 4), dtype=np.uint64)
+    check(lib.dvp_setup_scalars(ptr(t), ptr(d), ptr(e), log_m, inst.num_public_inputs, inst.n_rows, inst.n_wires, ptr(coeffs), coeffs.shape[0],
+                                arr[0], arr[1], arr[2], ptr(out), out.shape[0]), "dvp_setup_scalars")
+    o = inst.n_wires
+    return out[:o], out[o:o + m], [out[o + m:o + 2 * m], out[o + 2 * m:o + 3 * m], out[o + 3 * m:]]
+
+
+def srs_scalars_hostside(prover, inst: R1CSInstance, td: Trapdoor):
+    """rounds 1-4's orchestration of the same stages from python (every vector through the host-pointer seams): kept as the
+    independent cross-check of srs_scalars / dvp_setup_cache_dir in the tests"""
     assert td.tau % P and td.delta % P and td.epsilon % P  # src/srs.rs:199-201
     m = inst.num_constraints
     d, d2 = prover.domains()

@@ -60,6 +60,14 @@ int dvp_prover_msm_table_ptr(const dvp_prover* p, int which, const void** d_tabl
  * digit is negative | w << 20 | |digit| (|digit| = 2^(c-1) is stored as key 0); *windows = ceil(234 / c_bits) */
 int dvp_debug_recode_signed(const uint64_t* scalars, size_t n, int c_bits, uint32_t* out_words, int* windows);
 
+/* TEST / HARNESS ONLY: the SRS scalars (discrete logs of the bases: trapdoor material) of an IN-MEMORY circuit -- CSR matrices L, R, O
+ * over n_rows <= 2^log2_m rows (row_ptr[k]: n_rows + 1 entries), coefficient table (n_coeffs x 4 u64, canonical), n_wires -- in
+ * file order g_m | g_q | g_k_0 | g_k_1 | g_k_2 ((n_wires + 5 m) x 4 u64, out_cap in elements).  The same device pipeline
+ * dvp_setup_cache_dir runs on a parsed dump; dv-pari_amd/srs.py: srs_scalars (bench.py's synthetic circuit, the tests) calls it. */
+int dvp_setup_scalars(const uint64_t tau[4], const uint64_t delta[4], const uint64_t epsilon[4], uint32_t log2_m, uint32_t n_public,
+                      uint32_t n_rows, uint32_t n_wires, const uint64_t* coeffs, uint32_t n_coeffs, const uint32_t* const row_ptr[3],
+                      const uint32_t* const wire_ids[3], const uint32_t* const coeff_ids[3], uint64_t* out_scalars, size_t out_cap);
+
 /* TEST-ONLY (never bind this in a host): dvp_setup_cache_dir that also returns the discrete logs of the bases it wrote -- trapdoor
  * material, which dvp_setup_cache_dir itself zeroes on the device before it returns -- (host, (n_wires + 5 m) x 4 u64, file order
  * g_m | g_q | g_k_0 | g_k_1 | g_k_2; NULL = not wanted; out_cap in elements) and the circuit's sizes: parity tests pin the SRS

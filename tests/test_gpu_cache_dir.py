@@ -204,8 +204,9 @@ def test_toy_cache_dir_end_to_end(dvp, tmp_path):
 def test_setup_cache_dir_entry_scalars(dvp, tmp_path, shape):
     """dvp_setup_cache_dir (csrc/setup.hip: SRS::verifier_runs_setup behind the C ABI, src/srs.rs:177-361) against (i) the
     oracle's brute-force setup (domain tables by products over the whole domain, accumulate_m_values row by row) where the
-    big-int oracle can go, and (ii) the python orchestration over the per-operation seams (dvp.srs.srs_scalars), which the
-    GPU tests of the prover already pin to the oracle; then the files: every point file decodes to scalar x G."""
+    big-int oracle can go, (ii) the python orchestration over the per-operation seams (dvp.srs.srs_scalars_hostside, rounds 1-4's
+    route, which the GPU tests of the prover pinned to the oracle) and (iii) the in-memory entry of the same device pipeline
+    (dvp.srs.srs_scalars -> dvp_setup_scalars); then the files: every point file decodes to scalar x G."""
     A, g = dvp.artifacts, dvp.gnark_r1cs
     cache = tmp_path / "c"
     cache.mkdir()
@@ -221,10 +222,11 @@ def test_setup_cache_dir_entry_scalars(dvp, tmp_path, shape):
     td = dvp.srs.Trapdoor(*trap)
     inst, pv, (g_m, g_q, g_k) = dvp.srs.verifier_runs_setup_cache_dir(td, cache, n_pub, write_precomputes=True, return_scalars=True)
     m = inst.num_constraints
-    p_gm, p_gq, p_gk = dvp.srs.srs_scalars(pv, inst, td)
-    assert np.array_equal(g_m, p_gm) and np.array_equal(g_q, p_gq)
-    for j in range(3):
-        assert np.array_equal(g_k[j], p_gk[j]), j
+    for route in (dvp.srs.srs_scalars_hostside, dvp.srs.srs_scalars):
+        p_gm, p_gq, p_gk = route(pv, inst, td)
+        assert np.array_equal(g_m, p_gm) and np.array_equal(g_q, p_gq), route.__name__
+        for j in range(3):
+            assert np.array_equal(g_k[j], p_gk[j]), (route.__name__, j)
     if m <= 128:
         rows = []
         for i in range(inst.n_rows):

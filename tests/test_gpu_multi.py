@@ -80,23 +80,37 @@ def test_rccl_collectives_execute_on_one_gpu(dvp):
 
 def test_bench_self_launch_rehearsal(dvp):
     """`python bench.py --gpus N` with nothing around it must start its own ranks, and rank 0's line must say what ran.
-    Rehearsal knobs of a one-GPU box: every rank on cuda:0, gloo instead of RCCL; 4 ranks = a plan with one rank that skips
-    the extends and three that split them by vector (three broadcasts of device buffers in the extender group); the
-    in-library leg (ms_per_step_inproc, dvp_set_devices over a repeated id) runs in the child."""
+    Rehearsal knobs of a one-GPU box: every rank on cuda:0, gloo instead of RCCL; 4 ranks -- the most this box admits beside the
+    test process itself and the in-library child that rank 0 starts at the end (at most 6 processes may use its GPU: a 5-rank run was
+    killed by the guard; the 8-rank plan is walked on the CPU, tests/test_distributed_cpu.py) -- = a plan with one rank that skips
+    the extends and three that split them by vector (three broadcasts of device buffers in the extender group).  The line carries the plan, the MEASURED costs it was made from (one timed extend, one timed broadcast, one
+    timed MSM slice) and every rank's own stage times; the in-library leg (ms_per_step_inproc, dvp_set_devices over a repeated id)
+    runs in the child."""
     import json
     import subprocess
 
     env = dict(os.environ, DVP_BENCH_SHARE_GPU="1", DVP_DIST_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--log-m", "14"],
+    n = 4
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--log-m", "14"],
                          capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 4 and d["rccl_ranks"] == 4 and d["backend"] == "gloo" and len(d["ms_per_step_ranks"]) == 4
+    assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["backend"] == "gloo" and len(d["ms_per_step_ranks"]) == n
     assert d["ms_per_step_inproc"] is not None and d["ms_per_step"] > 0, d.get("inproc_error")
+    assert d["scaling_measured"] is True
+    plan = d["shard_plan"]
+    assert [p["rank"] for p in plan] == list(range(n))
+    m, n_wires = 1 << 14, d["config"]["n_wires"]
+    for key, total in (("commit_msm_range", n_wires + m), ("k_msm_range", 4 * m)):  # the slices tile both MSMs
+        cuts = sorted(tuple(p[key]) for p in plan if p[key][1] > p[key][0])
+        assert cuts[0][0] == 0 and cuts[-1][1] == total and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    costs = d["shard_plan_costs"]
+    assert costs["replicated"] > 0 and costs["split"] > 0 and costs["ms"]["extend_one_vector"] > 0 and costs["ms"]["broadcast_one_vector"] > 0
+    assert len(d["stages_ms_per_step_by_rank"]) == n and all(r["msm_total_ms_per_step"] > 0 for r in d["stages_ms_per_step_by_rank"])
 
 
 @pytest.mark.parametrize("world", [2])

@@ -328,7 +328,7 @@ def test_prove_2_20_full_size(dvp):
     the OpenSSL-pinned oracle (src/proving.rs:463,512,680), alpha by the oracle transcript, a0 / b0 by the barycentric
     formula in python big ints (src/ec_fft.rs:455-491), and the whole by the designated-verifier equation on discrete
     logs (src/srs.rs:374-428).  Then: reproducible bytes, tampering rejected, the sharded path (3 simulated ranks)
-    gives identical bytes."""
+    and the in-library path over eight shards (the 8-GPU node's shape on one device) give identical bytes."""
     import torch
     import fullsize as fs
 
@@ -368,6 +368,16 @@ def test_prove_2_20_full_size(dvp):
         if which == 0:
             pv.challenge(point.data_ptr(), point.data_ptr() + 64, st)
     assert pv.finish(point.data_ptr(), point.data_ptr() + 64, st) == proof
+    # the in-library multi-GPU path at full size with the shape of an 8-GPU node (dvp_set_devices([0] * 8): eight index-range shards
+    # of both MSMs with their own tables, eight host threads, partial points added on the home device) -- same bytes, both flavours
+    # of the transcript untouched by the device list
+    try:
+        dvp.set_devices([0] * 8)
+        assert pv.prove(pub, prv) == proof
+        assert pv.prove_dev(assignment.data_ptr(), st) == proof
+    finally:
+        dvp.set_devices([])
+    assert pv.prove_dev(assignment.data_ptr(), st) == proof
     pv.close()
 
 

@@ -93,6 +93,14 @@ def test_shard_plan_roles_and_coverage(dvp):
                 assert max(loads) <= 1.03 * (sum(loads) / world) or all(ext)
     assert all(need for _, _, need in d.shard_plan(2, 1 << 20, 1 << 20))       # small worlds: uniform
     assert not d.shard_plan(8, 1 << 20, 1 << 20)[0][2]                           # 8 ranks: some skip the extends
+    # MEASURED costs (distributed.measure_plan_costs: {"replicated", "split"} in (scalar, base) pairs) replace the typed-in defaults: the
+    # defaults as a dict give the default plan; a free extend makes every rank an extender; a dear exchange shrinks the extender group
+    m = 1 << 20
+    assert d.shard_plan(8, m, m, extend_pairs={"replicated": 0.42 * m, "split": 0.30 * m}) == d.shard_plan(8, m, m)
+    assert all(need for _, _, need in d.shard_plan(8, m, m, extend_pairs={"replicated": 0.0, "split": 0.0}))
+    n_default = sum(1 for p in d.shard_plan(8, m, m) if p[2])
+    n_dear = sum(1 for p in d.shard_plan(8, m, m, extend_pairs={"replicated": 0.42 * m, "split": 3.0 * m}) if p[2])
+    assert 1 <= n_dear < n_default
 
 
 def test_pin_xsk233_tool_agrees_with_the_oracle_rule():
