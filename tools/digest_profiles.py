@@ -170,3 +170,15 @@ print("traffic per launch: raw %.3f GB, fetch x2 %.3f GB, algorithmic %.3f GB" %
 print("issue:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in issue.items() if k.endswith("frac") or k.endswith("cycle") or k.endswith("ghz") or k.endswith("ceiling")})
 for r in list(csv.DictReader(open(os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))))[:8]:
     print(r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e6, "ms avg")
+
+# ---- round 5: every pair round (later rounds included), the request-size experiment, the other configs, and the stamp ----
+import subprocess
+subprocess.run([sys.executable, os.path.join(ROOT, "tools", "digest_rounds.py"), "refresh", tag, "by_round"], check=False)
+subprocess.run([sys.executable, os.path.join(ROOT, "tools", "digest_rounds.py"), "refresh_b", tag, "gather64", "configs"], check=False)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import profile_stamp
+try:
+    taken_at = open(os.path.join(SRC, "source_sha16.txt")).read().split()[0]
+except Exception:
+    taken_at = None
+print("stamp:", profile_stamp.write(tag, taken_at))

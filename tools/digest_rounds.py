@@ -8,7 +8,8 @@
   profiles/<tag>_config5_sparse_2p22_*
   profiles/<tag>_setup_2p20_*
 
-usage: python tools/digest_rounds.py <dir under gpurun_out/> <tag>     (dir = r5_first, or refresh once refresh_profiles.sh has run)"""
+usage: python tools/digest_rounds.py <dir under gpurun_out/> <tag> [by_round|gather64|configs ...]
+       (tools/digest_profiles.py calls it: by_round on gpurun_out/refresh, gather64 + configs on gpurun_out/refresh_b)"""
 import collections
 import csv
 import glob
@@ -18,7 +19,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r5_first")
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "refresh")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r05"
 DST = os.path.join(ROOT, "profiles")
 N_CU, N_SIMD = 256, 1024
@@ -32,7 +33,10 @@ def dispatches(name):
     for r in csv.DictReader(open(path)):
         d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "ms": (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6})
         d[r["Counter_Name"]] = float(r["Counter_Value"])
-    return [v for _, v in sorted(disp.items()) if "k_affine_round" in v["name"]]
+    # bench.py's untimed legs come after the proofs (microbenchmarks first, then stand-alone MSMs, proofs without tables ...): only the
+    # launches before the first microbenchmark dispatch belong to proofs of the timed configuration
+    first_extra = min([i for i, v in disp.items() if "k_ubench" in v["name"]], default=None)
+    return [v for i, v in sorted(disp.items()) if "k_affine_round" in v["name"] and (first_extra is None or i < first_extra)]
 
 
 def last_proof(seq):
@@ -167,7 +171,8 @@ def configs():
 
 
 if __name__ == "__main__":
-    for fn in (by_round, gather64, configs):
+    want = sys.argv[3:] or ["by_round", "gather64", "configs"]
+    for fn in [f for f in (by_round, gather64, configs) if f.__name__ in want]:
         try:
             fn()
         except FileNotFoundError as e:

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Runs ON THE MI355X BOX (round 5, first evidence pass; everything lands in gpurun_out/r5_first/):
+# Runs ON THE MI355X BOX, second half of the profile refresh (tools/refresh_profiles.sh is the first; two gpurun calls because one
+# would exceed a call's time limit); everything lands in gpurun_out/refresh_b/ and tools/digest_profiles.py reads it:
 #   1. tools/ubench/gather64.hip -- the load forms that might make a 64-byte point cost a 64-byte fabric request: rates un-profiled,
 #      then the request-size and hit / miss counters per variant (two separate --pmc passes, counters + kernel trace only)
 #   2. request-level and issue-side counters over a short bench run, ALL kernels (the digest reads k_affine_round<false>, the later
@@ -7,7 +8,7 @@
 #   3. rocprofv3 --kernel-trace --stats for BASELINE configs #3 (ecfft_bench 20), #5 (sparse_bench 22 8) and the setup (setup_time 20)
 set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r5_first
+OUT=$ROOT/gpurun_out/refresh_b
 rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
 G=$ROOT/scratch/gather64
@@ -22,35 +23,18 @@ echo "gather64 counters done"
 for d in g64_tcc g64_tcc2 g64_fetch; do
   PMC_TOP=40 python3 $ROOT/tools/pmc_digest.py $OUT/$d > $OUT/${d}_digest.txt && cp $OUT/$d/digest.json $OUT/${d}_digest.json || true
 done
-B="python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1"
-timeout -k 10 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --kernel-trace -d $OUT/pmc_tcc -o t --output-format csv -- $B > $OUT/pmc_tcc.json 2> $OUT/pmc_tcc.err
-timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum TCC_REQ_sum --kernel-trace -d $OUT/pmc_tcc2 -o t --output-format csv -- $B > $OUT/pmc_tcc2.json 2> $OUT/pmc_tcc2.err
-timeout -k 10 400 rocprofv3 --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum WRITE_SIZE --kernel-trace -d $OUT/pmc_wr -o t --output-format csv -- $B > $OUT/pmc_wr.json 2> $OUT/pmc_wr.err || echo "pmc wr pass failed"
-timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o q --output-format csv -- $B > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
-echo "bench counters done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/ecfft20 -o e --output-format csv -- python3 $ROOT/tools/ecfft_bench.py 20 > $OUT/ecfft20.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/sparse22 -o s --output-format csv -- python3 $ROOT/tools/sparse_bench.py 22 8 > $OUT/sparse22.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/setup20 -o s --output-format csv -- python3 $ROOT/tools/setup_time.py 20 > $OUT/setup20.log 2>&1
 echo "config stats done"
-# the raw counter tables are tens of MB: keep the per-dispatch rows of the two pair-round kernels and the stats CSVs only
 python3 - <<PY
-import csv, glob, os
+import glob, os
 out = "$OUT"
-for d in ("pmc_tcc", "pmc_tcc2", "pmc_wr", "pmc_sq"):
-    hits = glob.glob(os.path.join(out, d, "**", "*counter_collection.csv"), recursive=True)
-    if not hits: continue
-    rows = [r for r in csv.DictReader(open(hits[0])) if "k_affine_round" in r["Kernel_Name"] or "k_ubench" in r["Kernel_Name"]]
-    with open(os.path.join(out, d + "_pair_rounds.csv"), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp", "Grid_Size"], extrasaction="ignore")
-        w.writeheader()
-        for r in rows:
-            r["Kernel_Name"] = r["Kernel_Name"].split("(")[0]
-            w.writerow(r)
 for d in ("ecfft20", "sparse22", "setup20"):
     for f in glob.glob(os.path.join(out, d, "**", "*kernel_stats.csv"), recursive=True):
         os.replace(f, os.path.join(out, d + "_kernel_stats.csv"))
 PY
-for d in pmc_tcc pmc_tcc2 pmc_wr pmc_sq g64_tcc g64_tcc2 g64_fetch ecfft20 sparse22 setup20; do rm -rf $OUT/$d; done
+for d in g64_tcc g64_tcc2 g64_fetch ecfft20 sparse22 setup20; do rm -rf $OUT/$d; done
 ls -la $OUT
 cat $OUT/g64_tcc_digest.txt
 tail -2 $OUT/ecfft20.log $OUT/sparse22.log; tail -8 $OUT/setup20.log
