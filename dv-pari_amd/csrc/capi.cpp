@@ -23,7 +23,7 @@ static std::vector<Pending> g_prof_pending;
 static const char* kProfNames[PROF_NSLOTS] = {"msm_affine_round0", "msm_total", "extend_total", "prove_total", "msm_affine_rest", "msm_sort", "msm_tail"};
 
 ProfScope::ProfScope(int slot_, hipStream_t st_, uint64_t key_) : slot(slot_), st(st_), key(key_) {
-  if (!g_prof_enabled) return;
+  if (!g_prof_enabled || slot_ < 0) return;  // slot -1: a scope that times nothing
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, st);
 }
@@ -40,7 +40,7 @@ void prof_collect() {
     float ms = 0;
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       g_prof_ms[p.slot] += ms;
-      g_prof_n[p.slot] += 1;
+      g_prof_n[p.slot] += (p.slot == PROF_MSM_AFFINE_REST && p.key) ? p.key : 1;  // the later pair rounds of an MSM share one scope: key = their number
       if (p.slot == PROF_MSM_ACCUM_AFFINE && p.key) { Shape& sh = g_prof_round0[p.key]; sh.ms += ms; sh.n += 1; }
     }
     (void)hipEventDestroy(p.e0);

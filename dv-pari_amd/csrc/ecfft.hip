@@ -297,21 +297,26 @@ __global__ void __launch_bounds__(256) k_butterfly(const Fr* src /* == data, or 
 // layer d + 1 (j, shared by both of its pairs).  DEC = decompose order (wide layer first); recombine runs the narrow layer first.
 // BATCH vectors: lane = (quad of values, vector) with the vector index fastest, so the BATCH lanes that need the same constants
 // sit in the same wave and their loads are one request.
-template <bool DEC>
+// MAP: where the constants of half-block position i sit in a layer's table -- i itself for data held in vector order (TwId); a tile
+// of a long vector (k_extend_top) maps its rows and columns back to vector positions (TwTile)
+struct TwId {
+  __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return i; }
+};
+template <bool DEC, class MAP = TwId>
 __device__ __forceinline__ void radix4(Fr30& x0, Fr30& x1, Fr30& x2, Fr30& x3, const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow,
-                                       uint32_t j, uint32_t h2) {
+                                       uint32_t j, uint32_t h2, MAP f = MAP()) {
   if (DEC) {
-    bf_dec2(x0, x2, tw_load(tw_wide, j), x1, x3, tw_load(tw_wide, j + h2));
-    const Tw c = tw_load(tw_narrow, j);
+    bf_dec2(x0, x2, tw_load(tw_wide, f(j)), x1, x3, tw_load(tw_wide, f(j + h2)));
+    const Tw c = tw_load(tw_narrow, f(j));
     bf_dec2(x0, x1, c, x2, x3, c);
   } else {
     {
-      const Tw c = tw_load(tw_narrow, j);
+      const Tw c = tw_load(tw_narrow, f(j));
       bf_rec(x0, x1, c);
       bf_rec(x2, x3, c);
     }
-    bf_rec(x0, x2, tw_load(tw_wide, j));
-    bf_rec(x1, x3, tw_load(tw_wide, j + h2));
+    bf_rec(x0, x2, tw_load(tw_wide, f(j)));
+    bf_rec(x1, x3, tw_load(tw_wide, f(j + h2)));
   }
 }
 template <int BATCH, bool DEC>
@@ -424,14 +429,14 @@ constexpr uint32_t FUSE_ELEMS = 1u << FUSE_LOG;
 #endif
 constexpr int FUSE_TPB = DVP_FUSE_TPB;  // 64 KB of LDS per workgroup: two workgroups per CU, FUSE_TPB / 128 waves per SIMD
 
-template <bool DEC>
-__device__ __forceinline__ void lds_bfly(Fr30* x, const Fr30* __restrict__ tws, int lh, uint32_t pairs) {
+template <bool DEC, class MAP = TwId>
+__device__ __forceinline__ void lds_bfly(Fr30* x, const Fr30* __restrict__ tws, int lh, uint32_t pairs, MAP f = MAP()) {
   const uint32_t h = 1u << lh;
   for (uint32_t q = threadIdx.x; q < pairs; q += blockDim.x) {
     uint32_t i = q & (h - 1);
     uint32_t i0 = ((q >> lh) << (lh + 1)) | i, i1 = i0 + h;
     Fr30 e0 = x[i0], e1 = x[i1];
-    if (DEC) bf_dec(e0, e1, tw_load(tws, i)); else bf_rec(e0, e1, tw_load(tws, i));
+    if (DEC) bf_dec(e0, e1, tw_load(tws, f(i))); else bf_rec(e0, e1, tw_load(tws, f(i)));
     x[i0] = e0;
     x[i1] = e1;
   }
@@ -439,14 +444,14 @@ __device__ __forceinline__ void lds_bfly(Fr30* x, const Fr30* __restrict__ tws, 
 }
 // two layers per barrier inside the block (the radix-4 step of k_butterfly4 on the LDS copy): half the barriers and half the LDS
 // round trips of the per-layer loop.  lh2 = log2 of the narrow layer's pair distance; wide layer first when DEC.
-template <bool DEC>
-__device__ __forceinline__ void lds_bfly4(Fr30* x, const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow, int lh2, uint32_t quads) {
+template <bool DEC, class MAP = TwId>
+__device__ __forceinline__ void lds_bfly4(Fr30* x, const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow, int lh2, uint32_t quads, MAP f = MAP()) {
   const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
   for (uint32_t q = threadIdx.x; q < quads; q += blockDim.x) {
     const uint32_t j = q & (h2 - 1);
     const uint32_t i0 = ((q >> lh2) << (lh2 + 2)) | j;
     Fr30 x0 = x[i0], x1 = x[i0 + h2], x2 = x[i0 + h1], x3 = x[i0 + h1 + h2];
-    radix4<DEC>(x0, x1, x2, x3, tw_wide, tw_narrow, j, h2);
+    radix4<DEC, MAP>(x0, x1, x2, x3, tw_wide, tw_narrow, j, h2, f);
     x[i0] = x0; x[i0 + h2] = x1; x[i0 + h1] = x2; x[i0 + h1 + h2] = x3;
   }
   __syncthreads();
@@ -494,6 +499,65 @@ k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-
     } else {
       st30(data + base + k, x[k]);
       st30(data + base + k + half, x[k + half]);
+    }
+  }
+}
+
+// Fused TOP of an extend (round 5): the `tl` layers d0 .. d0 + tl - 1 of a long vector mix values that sit S = n >> (d0 + tl) apart
+// (the pair distance of the narrowest of them) inside blocks of n >> d0 values.  A workgroup takes a TILE of such a block -- R = 2^tl
+// rows S apart, C = FUSE_ELEMS / R consecutive columns (a row of the tile is C x 32 B of consecutive memory: whole 128-byte lines
+// from C = 4, i.e. tl <= 9) -- into LDS and runs all tl layers on it: ONE launch and one HBM round trip where k_butterfly8 took
+// ceil(tl / 3).  The 2^20-constraint prover's extends (top = 9 layers above the 2048-value blocks of k_extend_fused) go from
+// 3 + 1 + 3 launches to 1 + 1 + 1.  LDS position e = row * C + col; the constants of half-block position i of a layer sit at vector
+// position (i / C) * S + col0 + i % C (TwTile).  DEC: wide layer first (the first launch of an extend, with the input twist `pre`);
+// otherwise narrow first (the last launch, with the output twist `post`).  In place: a tile is read completely before it is written
+// and no two workgroups share a value.
+struct TwTile {
+  uint32_t lc, ls, col0;
+  __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return ((i >> lc) << ls) + col0 + (i & ((1u << lc) - 1u)); }
+};
+template <bool DEC>
+__global__ void __launch_bounds__(FUSE_TPB) __attribute__((amdgpu_waves_per_eu(FUSE_TPB / 128, FUSE_TPB / 128)))
+k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec, whole table */, uint32_t n, int ln, int d0, int tl,
+             const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
+  __shared__ Fr30 x[FUSE_ELEMS];
+  const int lc = FUSE_LOG - tl, ls = ln - d0 - tl;        // log2 of the tile's columns and of the row distance
+  const uint32_t groups = 1u << (ls - lc);                // tiles per block of n >> d0 values
+  const uint32_t gb = blockIdx.x >> (ls - lc), cg = blockIdx.x & (groups - 1u);
+  const size_t base = ((size_t)gb << (ln - d0)) + ((size_t)cg << lc);
+  const uint32_t cmask = (1u << lc) - 1u, half = FUSE_ELEMS >> 1;
+  auto gidx = [&](uint32_t e) -> size_t { return base + ((size_t)(e >> lc) << ls) + (e & cmask); };
+  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
+    const size_t g0 = gidx(k), g1 = gidx(k + half);
+    if (pre)
+      tw_in2(pre, (uint32_t)(g0 & (size_t)(n - 1)), (uint32_t)(g1 & (size_t)(n - 1)), src[g0], src[g1], x[k], x[k + half]);
+    else {
+      x[k] = ld30(src + g0);
+      x[k + half] = ld30(src + g1);
+    }
+  }
+  __syncthreads();
+  const TwTile f{(uint32_t)lc, (uint32_t)ls, cg << lc};
+  auto tw_of = [&](int L) { return tw + 2 * (size_t)(n - (n >> (d0 + L))); };  // layer d0 + L: rows 2^(tl - 1 - L) apart
+  if (DEC) {
+    int L = 0;
+    for (; L + 1 < tl; L += 2) lds_bfly4<true, TwTile>(x, tw_of(L), tw_of(L + 1), tl - L - 2 + lc, FUSE_ELEMS >> 2, f);
+    for (; L < tl; ++L) lds_bfly<true, TwTile>(x, tw_of(L), tl - L - 1 + lc, FUSE_ELEMS >> 1, f);
+  } else {
+    int L = tl - 1;
+    if (tl & 1) { lds_bfly<false, TwTile>(x, tw_of(L), tl - L - 1 + lc, FUSE_ELEMS >> 1, f); --L; }
+    for (; L >= 1; L -= 2) lds_bfly4<false, TwTile>(x, tw_of(L - 1), tw_of(L), tl - L - 1 + lc, FUSE_ELEMS >> 2, f);
+  }
+  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
+    const size_t g0 = gidx(k), g1 = gidx(k + half);
+    if (post) {
+      Fr o0, o1;
+      tw_out2(post, (uint32_t)(g0 & (size_t)(n - 1)), (uint32_t)(g1 & (size_t)(n - 1)), x[k], x[k + half], o0, o1);
+      data[g0] = o0;
+      data[g1] = o1;
+    } else {
+      st30(data + g0, x[k]);
+      st30(data + g1, x[k + half]);
     }
   }
 }
@@ -661,9 +725,22 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   const int lb = ln < FUSE_LOG ? ln : FUSE_LOG;  // layers handled inside LDS
   const int top = ln - lb;
   // the top layers in groups of 3 (radix 8), then one group of 2 or 1; the recombine direction mirrors the decompose's grouping
-  const int radix = (int)tune().ecfft_radix4;  // 0: one layer per pass, 1: two, 2 (default): three
+  const int radix = (int)tune().ecfft_radix4;  // 0: one layer per pass, 1: two, 2: three, 3 (default): the top in one LDS-tiled launch
+  // k_extend_top covers the last tl <= TOP_MAX top layers (the ones next to the fused bottom), whatever is above them goes in groups
+  constexpr int TOP_MIN = 4, TOP_MAX = FUSE_LOG - 2;  // >= 4 columns per tile row (128-byte lines); below 4 layers k_butterfly8 / 4 do as well
+  const int tl = (radix >= 3 && top >= TOP_MIN) ? (top < TOP_MAX ? top : TOP_MAX) : 0;
+  const int d0 = top - tl;  // layers 0 .. d0 - 1 in groups, d0 .. top - 1 tiled
+  auto pass_top = [&](const Fr30* base, bool dec, bool last) {
+    const Fr30* pre = pre_of();
+    const Fr30* post = last ? ms->wout : nullptr;
+    const uint32_t nn = (uint32_t)((size_t)batch * n);  // the batch vectors are contiguous: blocks of n >> d0 values all the way through
+    const dim3 g(nn >> FUSE_LOG), b(FUSE_TPB);
+    if (dec) hipLaunchKernelGGL(k_extend_top<true>, g, b, 0, st, src, data, base, n, ln, d0, tl, pre, post);
+    else hipLaunchKernelGGL(k_extend_top<false>, g, b, 0, st, src, data, base, n, ln, d0, tl, pre, post);
+    src = data;
+  };
   std::vector<int> groups;
-  for (int left = top; left > 0;) {
+  for (int left = d0; left > 0;) {
     const int g = radix >= 2 && left >= 3 ? 3 : (radix >= 1 && left >= 2 ? 2 : 1);
     groups.push_back(g);
     left -= g;
@@ -674,6 +751,7 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
       if (g == 3) pass8(ms->dec, d, true, false); else if (g == 2) pass4(ms->dec, d, true, false); else pass(ms->dec, d, true, false);
       d += g;
     }
+    if (tl) pass_top(ms->dec, true, false);
   }
   {
     size_t total = (size_t)batch * n;
@@ -682,7 +760,8 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
     src = data;
   }
   {
-    int d = top;
+    if (tl) pass_top(ms->rec, false, d0 == 0);
+    int d = d0;
     for (size_t k = groups.size(); k-- > 0;) {
       const int g = groups[k];
       d -= g;

@@ -1027,7 +1027,8 @@ __global__ void __launch_bounds__(SCAN_TPB) k_mscan_local(const uint32_t* __rest
     if (threadIdx.x == 0) bs[(size_t)(r - 1) * gridDim.x + blockIdx.x] = tot;
   }
 }
-__global__ void __launch_bounds__(SCAN_TPB) k_mscan_bsums(uint32_t* __restrict__ bs, uint32_t nb, uint32_t m, uint32_t* __restrict__ rp) {
+__global__ void __launch_bounds__(SCAN_TPB) k_mscan_bsums(uint32_t* __restrict__ bs, uint32_t nb, uint32_t m, uint32_t* __restrict__ rp,
+                                                          uint32_t* __restrict__ off0 /* item offsets (or nullptr): off0[m] = the padded total */) {
   __shared__ uint32_t sh[SCAN_TPB];
   const int r = blockIdx.x + 1;
   uint32_t* row = bs + (size_t)(r - 1) * nb;
@@ -1040,13 +1041,38 @@ __global__ void __launch_bounds__(SCAN_TPB) k_mscan_bsums(uint32_t* __restrict__
     if (idx < nb) row[idx] = ex + carry;
     carry += tot;
   }
-  if (threadIdx.x == 0) rp[(size_t)(2 * (r - 1) + 1) * ((size_t)m + 1) + m] = carry;  // o_r[nkeys]
+  if (threadIdx.x == 0) {
+    rp[(size_t)(2 * (r - 1) + 1) * ((size_t)m + 1) + m] = carry;  // o_r[nkeys]
+    if (r == 1 && off0) off0[m] = 2u * carry;
+  }
 }
-__global__ void __launch_bounds__(SCAN_TPB) k_mscan_add(uint32_t* __restrict__ rp, const uint32_t* __restrict__ bs, uint32_t m, int R) {
+// Round 5: the last launch of the scan also finishes what the SORT needs from the counts, which used to be six launches of their own
+// (a second three-launch scan, k_pad_odd_buckets, a memset and k_max_u32): the item offsets off0 -- the scan of the counts rounded up
+// to even is exactly twice o_1, the scan of ceil(c_0 / 2) --, the NONE in the spare slot of every odd bucket (a position the
+// scatter never writes, so it may be filled before the scatter runs) and the largest bucket (dmax, zeroed by the previous MSM's
+// tail kernel).
+__global__ void __launch_bounds__(SCAN_TPB) k_mscan_add(uint32_t* __restrict__ rp, const uint32_t* __restrict__ bs, uint32_t m, int R,
+                                                        const uint32_t* __restrict__ cnt0, uint32_t* __restrict__ off0, uint32_t* __restrict__ items,
+                                                        uint32_t* __restrict__ dmax) {
   const uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
   for (int r = 1; r <= R; ++r) {
     uint32_t* o = rp + (size_t)(2 * (r - 1) + 1) * ((size_t)m + 1);
     const uint32_t add = bs[(size_t)(r - 1) * gridDim.x + blockIdx.x];
+    if (r == 1 && off0) {
+      uint32_t mx = 0;
+#pragma unroll
+      for (int k = 0; k < SCAN_EPT; ++k)
+        if (base + k < m) {
+          const uint32_t v = o[base + k] + add, c = cnt0[base + k];
+          o[base + k] = v;
+          off0[base + k] = 2u * v;
+          if (c & 1u) items[2u * v + c] = AFF_NONE;
+          mx = max(mx, c);
+        }
+      for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+      if ((threadIdx.x & 63) == 0 && mx) atomicMax(dmax, mx);
+      continue;
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_EPT; ++k)
       if (base + k < m) o[base + k] += add;
@@ -1337,7 +1363,7 @@ template <> struct MergeMul<GfLdsK> { static __device__ __forceinline__ GfLdsK i
 template <> struct MergeMul<GfLdsQ> { static __device__ __forceinline__ GfLdsQ init(char* l) { return gf_ldsq_init(l); } static __device__ __forceinline__ bool lead(const GfLdsQ& c) { return c.r == 0; } };
 template <> struct MergeMul<GfLdsH> { static __device__ __forceinline__ GfLdsH init(char* l) { return gf_ldsh_init(l); } static __device__ __forceinline__ bool lead(const GfLdsH& c) { return c.r == 0; } };
 template <int GROUP, bool FIRST>
-__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GROUP > 1 ? 1 : 2, 2))) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */) {
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GROUP > 1 ? 1 : 2, 2))) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */, Ld* __restrict__ save0 /* FIRST: where bucket 0 is kept as it was (or nullptr) */) {
   using LT = typename std::conditional<GROUP == 1, GfLdsK, typename std::conditional<GROUP == 4, GfLdsQ, GfLdsH>::type>::type;
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1349,6 +1375,8 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GRO
   LT L = MergeMul<LT>::init(lds_raw);
   const bool lead = MergeMul<LT>::lead(L);  // the lane of the group that stores
   if (FIRST) {  // j == 0
+    // signed windows: bucket 0 (the digits of magnitude 2^(c-1)) is weighed separately by k_tail; the merge turns slot 0 into the total
+    if (save0 && tid == 0 && lead) *save0 = l;
     lam_from_ld(l, L);
     lam_from_ld(r, L);
   }
@@ -1378,7 +1406,7 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GRO
 template <bool HEX>
 __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf,
                                                  uint32_t* __restrict__ out_xy, uint32_t* __restrict__ out_inf, uint8_t* __restrict__ out_enc, int rule,
-                                                 const unsigned long long* __restrict__ err_src, unsigned long long* __restrict__ err_dst) {
+                                                 unsigned long long* __restrict__ ctrl /* msm_core's control words: [0] err, [1] d_max | rest_n, [2] err_out */, unsigned long long* __restrict__ err_dst) {
   using LT = typename std::conditional<HEX, GfLdsH, GfLdsQ>::type;
   constexpr int GS = HEX ? 4 : 2;             // log2 lanes per point
   constexpr uint32_t NG = EC_TPB >> GS;       // points in flight per pass
@@ -1479,7 +1507,13 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   }
   *out_inf = fin ? 0u : 1u;
   if (out_enc) store30(out_enc, w, rule);
-  if (err_dst) *err_dst = *err_src;  // a deferred MSM (msm_core, d_err_defer) hands its scalar-range word to the caller's block
+  // the scalar-range word: to the caller's block (a deferred MSM, msm_core's d_err_defer) and to err_out, which the host copy of a
+  // synchronous call reads; then the control words are left as the next MSM on this workspace expects them
+  const unsigned long long e = ctrl[0];
+  if (err_dst) *err_dst = e;
+  ctrl[2] = e;
+  ctrl[0] = ~0ull;
+  ctrl[1] = 0ull;
 }
 
 // sum of n affine points (the partial MSM results of n GPUs or ranks) -> affine: one quad of lanes, n - 1 mixed
@@ -1558,6 +1592,7 @@ struct MsmWorkspace {
   hipEvent_t ev_busy = nullptr;
   hipStream_t busy_stream = nullptr;
   bool busy_valid = false;
+  bool ctrl_clean = false;  // the control words at the head of the workspace are as an MSM expects them (msm_core)
   bool busy_for(hipStream_t st) { return busy_valid && busy_stream != st && hipEventQuery(ev_busy) == hipErrorNotReady; }
   uint32_t* pinned = nullptr;
   // round bookkeeping (counts, offsets, descriptors of the later pair rounds) runs on a side stream while the first round fills
@@ -1602,6 +1637,7 @@ struct MsmWorkspace {
     }
     if (!p) {
       DVP_HIP(hipMalloc(&p, need));
+      ctrl_clean = false;
       bytes = need;
       device = dev;
     }
@@ -1814,7 +1850,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   // carve the workspace
   size_t o = 0;
   auto carve = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes); return r; };
-  size_t o_err = carve(16);
+  size_t o_err = carve(32);  // err (u64) | d_max, rest_n (u32 each) | err_out (u64): the tail kernel's copy of err for the host
   size_t o_digits = carve(fx ? 16 : (size_t)p.W * n * 2);
   // signed flavour: level 1 of the sort reads the scalars themselves (k_part_hist_signed), a block per fx_S scalars
   const bool fused1 = fx && fx->signed_digits && tune().msm_sort_fused != 0;
@@ -1936,6 +1972,19 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   auto rc = [&](int r) -> uint32_t* { return r == 0 ? cnt : rp + (size_t)(2 * (r - 1)) * ((size_t)nk + 1); };
   auto ro = [&](int r) -> uint32_t* { return r == 0 ? off : rp + (size_t)(2 * (r - 1) + 1) * ((size_t)nk + 1); };
   int prepared = 0;  // pipelined: the bookkeeping of rounds < prepared is enqueued on the side stream (ev_side[0] = all of it is done)
+  uint32_t* d_max = (uint32_t*)(err + 1);
+  uint32_t* rest_n = d_max + 1;  // entries of k_bucket_pairs' list
+  // the largest bucket goes to the host on the aux stream while the caller's stream carries on
+  auto read_max = [&]() -> int {
+    DVP_TRY(g_ws.ensure_aux());
+    DVP_HIP(hipEventRecord(g_ws.ev, st));
+    DVP_HIP(hipStreamWaitEvent(g_ws.aux, g_ws.ev, 0));
+    DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
+    return DVP_OK;
+  };
+  // pipelined bookkeeping on the caller's stream: the scan of all rounds also yields the item offsets, the odd buckets' padding and the
+  // largest bucket (k_mscan_add)
+  const bool sort_done_by_mscan = pipelined && !side_stream;
   auto prepare_rounds = [&]() -> int {  // call once the sort's counts (cnt) are final on `st`
     if (!pipelined) return DVP_OK;
     hipStream_t bk = st;  // Tune::msm_round_pipeline == 2: the same four launches on the caller's stream
@@ -1948,9 +1997,12 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     // (c_r, o_r), r = 1 .. ra_plan, in one three-launch scan (round 0's outputs included: its even-aligned buckets make the sorted
     // item list the descriptor array, and the scan of ceil(c_0 / 2) is that list's offsets halved), then every round's descriptors
     const uint32_t nb = cdiv(nk, SCAN_BLK);
+    // (the caller's stream only: the side-stream flavour keeps the sort's own scan, padding and maximum)
+    uint32_t* off0 = side_stream ? nullptr : off;
     hipLaunchKernelGGL(k_mscan_local, dim3(nb), dim3(SCAN_TPB), 0, bk, cnt, nk, ra_plan, rp, bsum2);
-    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, bk, bsum2, nb, nk, rp);
-    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, bk, rp, bsum2, nk, ra_plan);
+    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, bk, bsum2, nb, nk, rp, off0);
+    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, bk, rp, bsum2, nk, ra_plan, (const uint32_t*)cnt, off0, items, d_max);
+    if (off0) DVP_TRY(read_max());  // the largest bucket is on its way to the host before the descriptors and the last scatter run
     DescPlan plan;
     for (int q = 0; q < 40; ++q) plan.at[q] = q < ra_plan ? desc_at[q] : 0;
     const size_t per_key = (e_est >> 2) / nk;  // round 1's outputs per bucket
@@ -1967,7 +2019,14 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   };
   ProfScope ps_total(PROF_MSM_TOTAL, st);
   ProfScope ps_sort(PROF_MSM_SORT, st);  // recode + counting sort
-  DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
+  // the control words [err | d_max, rest_n | err_out]: every MSM's tail kernel leaves err = ~0 and d_max = rest_n = 0 behind for the
+  // next one (two memset nodes per MSM, ~6 us each plus their dispatch gaps, sat on the critical path); a fresh allocation, or a call
+  // that returned before its tail kernel was enqueued, resets them here
+  if (!g_ws.ctrl_clean) {
+    DVP_HIP(hipMemsetAsync(err, 0xff, 8, st));
+    DVP_HIP(hipMemsetAsync(err + 1, 0, 8, st));
+  }
+  g_ws.ctrl_clean = false;
   if (fused1)
     ;  // no entry words in HBM: both level-1 kernels recompute them
   else if (fx && fx->signed_digits)
@@ -2006,33 +2065,29 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     hipLaunchKernelGGL(k_hist_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 2, st, plo, pstart, cstart, fb, hist16);
     hipLaunchKernelGGL(k_hist_scan2, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, cstart, fb, chunk_off, cnt);
     DVP_TRY(prepare_rounds());  // needs the counts only
-    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
+    if (!sort_done_by_mscan) DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
     if (staged2)
       hipLaunchKernelGGL(k_scatter_local2_staged, dim3(gmax), dim3(SORT_TPB), FX_STAGE2_LDS, st, plo, pid, pstart, cstart, fb, off,
                          chunk_off, hist16, items);
     else
       hipLaunchKernelGGL(k_scatter_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 4, st, plo, pid, pstart, cstart, fb, off, chunk_off, items);
-    hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
+    if (!sort_done_by_mscan) hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   } else {
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
     hipLaunchKernelGGL(k_hist_scan, dim3(cdiv(nk, 256)), dim3(256), 0, st, hist16, nchunks, p.c, p.W, chunk_off, cnt);
     DVP_TRY(prepare_rounds());  // needs the counts only
-    DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
+    if (!sort_done_by_mscan) DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
-    hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
+    if (!sort_done_by_mscan) hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   }
   ps_sort.stop();
   // ---- bucket accumulation: batched-affine pair rounds while a round still carries >= aff_min additions,
   // then the projective fan-in-K reducer on what is left (it has a short critical path and balances skew)
-  uint32_t* d_max = (uint32_t*)(err + 1);
-  uint32_t* rest_n = d_max + 1;  // entries of k_bucket_pairs' list
-  DVP_HIP(hipMemsetAsync(d_max, 0, 8, st));
-  hipLaunchKernelGGL(k_max_u32, dim3(64), dim3(256), 0, st, cnt, nk, d_max);
-  DVP_TRY(g_ws.ensure_aux());
-  DVP_HIP(hipEventRecord(g_ws.ev, st));
-  DVP_HIP(hipStreamWaitEvent(g_ws.aux, g_ws.ev, 0));
-  DVP_HIP(hipMemcpyAsync(g_ws.pinned, d_max, 4, hipMemcpyDeviceToHost, g_ws.aux));
+  if (!sort_done_by_mscan) {
+    hipLaunchKernelGGL(k_max_u32, dim3(64), dim3(256), 0, st, cnt, nk, d_max);  // (d_max: zeroed by the previous MSM's tail kernel)
+    DVP_TRY(read_max());
+  }
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
   int cur = 0;  // index of the live (cnt, off) pair
@@ -2066,7 +2121,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     const uint32_t r_max = cdiv(cdiv(out_max, aff_cap), aff_bmax_only);
     const uint32_t grid = r_max * (aff_cap / aff_tpb) + 1;
     {
-      ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : PROF_MSM_AFFINE_REST, st, (uint64_t)n);  // r == 0 is the dominant kernel: it gathers the bases
+      // r == 0 is the dominant kernel (it gathers the bases) and is timed launch by launch; the later rounds share ONE scope (ps_rest,
+      // below): an event pair around every round put ~10 us of packet processing between two rounds that otherwise follow each
+      // other back to back (kernel trace: 10-13 us gaps after every round, none between the merge levels)
+      ProfScope ps0(r == 0 ? PROF_MSM_ACCUM_AFFINE : -1, st, (uint64_t)n);
       WaveTrace wt{wt_buf, wt_cap, g_wave_trace_tag.fetch_add(wt_on ? 1u : 0u)};
       if (r == 0 && wt.buf)
         hipLaunchKernelGGL((k_affine_round<true, true>), dim3(grid), dim3(aff_tpb), aff_lds, st, pts_in, dsc, d_total, aff_cap, aff_bmax, Tsq, prefix, outp, sign_mask, wt);
@@ -2131,9 +2189,19 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     return DVP_OK;
   };
   if (r_evt >= 0 && r_evt < launched) DVP_TRY(gate_event());
-  for (int r = launched; r < ra; ++r) {
-    DVP_TRY(run_round(r));
-    if (r == r_evt) DVP_TRY(gate_event());
+  {
+    int r = launched;
+    if (r == 0 && ra > 0) {  // (small MSMs: the first round was not enqueued ahead of the largest-bucket read)
+      DVP_TRY(run_round(0));
+      if (r_evt == 0) DVP_TRY(gate_event());
+      r = 1;
+    }
+    ProfScope ps_rest(ra > r ? PROF_MSM_AFFINE_REST : -1, st, (uint64_t)(ra > r ? ra - r : 0));
+    for (; r < ra; ++r) {
+      DVP_TRY(run_round(r));
+      if (r == r_evt) DVP_TRY(gate_event());
+    }
+    ps_rest.stop();
   }
   if (pipelined && prepared) {
     // what the rounds left is described by the arrays of round `ra`: they head the ring of three the reducer works in
@@ -2194,13 +2262,14 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   ProfScope ps_tail(PROF_MSM_TAIL, st);  // merge tree, Frobenius tail, final add tree
   const int merge_levels = fx ? fx->key_bits() : p.c;
-  if (sign_mask)  // bucket 0 (digits of magnitude 2^(c-1)) before the merge turns slot 0 into the total: k_tail weighs it by 2^(c-1)
-    DVP_HIP(hipMemcpyAsync(tail + 2 * (size_t)p.c, bkt, sizeof(Ld), hipMemcpyDeviceToDevice, st));
+  // bucket 0 (digits of magnitude 2^(c-1)) is kept aside by the first merge level, before it turns slot 0 into the total: k_tail weighs
+  // it by 2^(c-1) (a 96-byte device-to-device copy node of its own cost 14 us per MSM)
+  Ld* save0 = sign_mask ? tail + 2 * (size_t)p.c : nullptr;
   for (int j = 0; j < merge_levels; ++j) {
     uint32_t total = (nk >> (j + 1)) * (uint32_t)(j + 1);
     const uint32_t quad_max = tn.msm_quad_max > 0 ? (uint32_t)tn.msm_quad_max : MERGE_QUAD_MAX;
     const uint32_t hex_max = tn.msm_hex_max >= 0 ? (uint32_t)tn.msm_hex_max : MERGE_HEX_MAX;
-#define DVP_MERGE(G, F, LDSB) hipLaunchKernelGGL((k_merge<G, F>), dim3(cdiv((size_t)G * total, EC_TPB)), dim3(EC_TPB), LDSB, st, bkt, j, total)
+#define DVP_MERGE(G, F, LDSB) hipLaunchKernelGGL((k_merge<G, F>), dim3(cdiv((size_t)G * total, EC_TPB)), dim3(EC_TPB), LDSB, st, bkt, j, total, save0)
     if (total <= hex_max) { if (j == 0) DVP_MERGE(16, true, EC_LDS_Q); else DVP_MERGE(16, false, EC_LDS_Q); }
     else if (total <= quad_max) { if (j == 0) DVP_MERGE(4, true, EC_LDS_Q); else DVP_MERGE(4, false, EC_LDS_Q); }
     else { if (j == 0) DVP_MERGE(1, true, EC_LDS); else DVP_MERGE(1, false, EC_LDS); }
@@ -2212,13 +2281,14 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   (void)cntT;
   if (sign_mask && tn.msm_hex_max != 0)  // c points: one row of 16 lanes each
     hipLaunchKernelGGL(k_tail<true>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, -3, Tsq, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf,
-                       (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, (const unsigned long long*)err, d_err_defer);
+                       (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, err, d_err_defer);
   else
     hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
-                       (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, (const unsigned long long*)err, d_err_defer);
+                       (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, err, d_err_defer);
   ps_tail.stop();
   ps_total.stop();
   DVP_HIP(hipGetLastError());
+  g_ws.ctrl_clean = true;  // the tail kernel is enqueued: it resets the control words
   // the scalar-range flag is the only thing that needs the host
   // into the workspace's pinned words (a pageable destination makes the runtime stage the copy and take a host round trip of its own
   // between the two copies: 60 us per MSM)
@@ -2230,7 +2300,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   volatile unsigned long long* h_err = (volatile unsigned long long*)(g_ws.pinned + 2);
   if (h_copy) DVP_HIP(hipMemcpyAsync(h_copy, d_copy, copy_bytes, hipMemcpyDeviceToHost, st));
-  DVP_HIP(hipMemcpyAsync((void*)h_err, err, 8, hipMemcpyDeviceToHost, st));
+  DVP_HIP(hipMemcpyAsync((void*)h_err, err + 2, 8, hipMemcpyDeviceToHost, st));  // err_out
   DVP_HIP(hipStreamSynchronize(st));
   count_host_wait(0);
   const unsigned long long e = *h_err;

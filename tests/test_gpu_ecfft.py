@@ -85,25 +85,27 @@ def test_multiblock_extend_enter_exit_vs_oracle(dvp, log_n, shifted):
     t.close()
 
 
-@pytest.mark.parametrize("log_m", [12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("log_m", [12, 13, 14, 15, 16, 17, 18, 19, 21])
 def test_extend_pass_groupings_agree(dvp, nat, log_m):
     """The unfused top of an extend runs three layers per pass (k_butterfly8), then two (k_butterfly4) or one (k_butterfly) for
     what is left: log_m - 11 = 1..6 top layers covers every grouping ([1], [2], [3], [3,1], [3,2], [3,3]).  Every batch shape
     of the kernels (1..5 vectors) must give the same values with three, two and one layer per pass (DVP_ECFFT_RADIX4 = 2 / 1 /
     0), and the oracle's, element for element, up to m = 2^14; extreme inputs (0, p - 1) ride along: the lazy 30-bit-limb
-    values inside an extend (fr.cuh) are only reduced by its last pass."""
+    values inside an extend (fr.cuh) are only reduced by its last pass.  Round 5: DVP_ECFFT_RADIX4 = 3 (the default) runs 4..9 top
+    layers in ONE LDS-tiled launch (k_extend_top): log_m = 15..19 are its tile shapes with 128 .. 8 columns (the prover's own 2^20
+    has 4: test_extend_2_20_and_enter_2_16_vs_oracle), log_m = 21 the case with a grouped pass above the tiled ones."""
     m = 1 << log_m
     t = dvp.ec_fft.FFTree(2 * m)
     ot = co.FFTree(log_m + 1) if log_m <= 14 else None
-    for batch in (1, 2, 3, 4, 5):
+    for batch in ((1, 2, 3, 4, 5) if log_m < 21 else (1, 3)):
         ev = rand_fr_np(batch * m, 31 * log_m + batch).reshape(batch, m, 4)
         ev[0, :7] = to_limbs([0, o.P - 1, 1, o.P - 2, 0, o.P - 1, o.P - 1])
         ev[batch - 1, m // 2:] = to_limbs([o.P - 1] * (m // 2))
         outs = []
-        for radix in (2, 1, 0):
+        for radix in (3, 2, 1, 0):
             with nat.tune(DVP_ECFFT_RADIX4=radix):
                 outs.append(t.extend(ev))
-        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), batch
+        assert all(np.array_equal(outs[0], x) for x in outs[1:]), batch
         if ot is not None and batch in (1, 3):
             for b in range(batch):
                 assert np.array_equal(outs[0][b], ot.extend(ev[b])), (batch, b)
