@@ -85,6 +85,7 @@ struct Tune {
   long long msm_hex_max = -1;   // DVP_MSM_HEX_MAX: merge levels up to this many additions use a row of 16 lanes each (-1 = default, 0 = never)
   long long msm_quad_max = 0;   // DVP_MSM_QUAD_MAX: merge levels up to this many additions use a quad of lanes each (0 = default)
   long long msm_fixed_min = 1ll << 16; // DVP_MSM_FIXED_MIN: smallest shard the prover sends through the fixed-base tables
+  long long fr_bi_shape = 6;           // DVP_FR_BI_SHAPE: workgroup x elements per thread of k_batch_inverse: 0 = 512 x 16 (rounds 3-4), 1 = 256 x 8, 2 = 256 x 4, 3 = 512 x 8, 4 = 128 x 8, 5 = 128 x 4, 6 = 256 x 16 (default: 2^21 elements 128 us against 139), 7 = 1024 x 8
   long long horner_max_pub = -1;       // DVP_HORNER_MAX_PUB: public-input count up to which i(X) on D' is evaluated by Horner (-1 = default)
   long long prove_host_transcript = 0; // DVP_PROVE_HOST_TRANSCRIPT: 1 = dvp_prove_dev waits for the commitment MSM and hashes the transcript on the host (rounds 1-4); 0 = on the device, one stream wait per proof
   long long msm_aligned_signed = 1;    // DVP_MSM_ALIGNED_SIGNED: the aligned-window tables hold 2^(c w) P and the windows are signed binary digits (0 = the tau-adic aligned windows over rows tau^(o_w) P)

@@ -519,11 +519,17 @@ struct TwTile {
 template <bool DEC>
 __global__ void __launch_bounds__(FUSE_TPB) __attribute__((amdgpu_waves_per_eu(FUSE_TPB / 128, FUSE_TPB / 128)))
 k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec, whole table */, uint32_t n, int ln, int d0, int tl,
-             const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
+             uint32_t batch, const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
   __shared__ Fr30 x[FUSE_ELEMS];
   const int lc = FUSE_LOG - tl, ls = ln - d0 - tl;        // log2 of the tile's columns and of the row distance
   const uint32_t groups = 1u << (ls - lc);                // tiles per block of n >> d0 values
-  const uint32_t gb = blockIdx.x >> (ls - lc), cg = blockIdx.x & (groups - 1u);
+  // workgroup -> (vector, tile of that vector).  The same tile of the `batch` vectors reads the same constants (64 bytes per pair
+  // and layer: as many bytes as the data), and consecutive workgroups go to the 8 XCDs in turn: eight tiles of vector 0, the same
+  // eight of vector 1, .. -- so that the workgroups sharing constants land on the SAME XCD one dispatch round apart and the second
+  // and third find them in its L2 (a tile-major order put them on three different XCDs: three fetches from memory)
+  const uint32_t per8 = 8u * batch, grp8 = blockIdx.x / per8, rem = blockIdx.x - grp8 * per8;
+  const uint32_t vec = rem >> 3, tv = (grp8 << 3) | (rem & 7u);  // (n >> FUSE_LOG tiles per vector: a multiple of 16 here)
+  const uint32_t gb = (vec << d0) + (tv >> (ls - lc)), cg = tv & (groups - 1u);
   const size_t base = ((size_t)gb << (ln - d0)) + ((size_t)cg << lc);
   const uint32_t cmask = (1u << lc) - 1u, half = FUSE_ELEMS >> 1;
   auto gidx = [&](uint32_t e) -> size_t { return base + ((size_t)(e >> lc) << ls) + (e & cmask); };
@@ -735,8 +741,8 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
     const Fr30* post = last ? ms->wout : nullptr;
     const uint32_t nn = (uint32_t)((size_t)batch * n);  // the batch vectors are contiguous: blocks of n >> d0 values all the way through
     const dim3 g(nn >> FUSE_LOG), b(FUSE_TPB);
-    if (dec) hipLaunchKernelGGL(k_extend_top<true>, g, b, 0, st, src, data, base, n, ln, d0, tl, pre, post);
-    else hipLaunchKernelGGL(k_extend_top<false>, g, b, 0, st, src, data, base, n, ln, d0, tl, pre, post);
+    if (dec) hipLaunchKernelGGL(k_extend_top<true>, g, b, 0, st, src, data, base, n, ln, d0, tl, batch, pre, post);
+    else hipLaunchKernelGGL(k_extend_top<false>, g, b, 0, st, src, data, base, n, ln, d0, tl, batch, pre, post);
     src = data;
   };
   std::vector<int> groups;

@@ -18,29 +18,43 @@ constexpr int INV_CHUNK = 16;  // elements per thread sharing one Fermat inversi
 // thread the inverse of its own product.  A wave pays for an inversion (232 squarings + ~116 products) whether one lane
 // needs it or all 64, so the first version -- every thread its own inversion -- spent 22 of its 27 products per element
 // there; this one spends ~3 (8192 elements per inversion): 3 + 2 conversions + ~3 per element.
-constexpr int BI_TPB = 512, BI_PER_LANE = BI_TPB / 64;
+// Shape (round 5): the kernel is a chain -- CHUNK loads and products per thread, the wave-0 stretch with the inversion, CHUNK more
+// loads and three products each -- on ONE workgroup per CU at 512 x 16 (2^21 elements: 256 workgroups), 223 us in the prover's
+// challenge phase for 30 us' worth of products.  Smaller workgroups with fewer elements per thread run more, shorter chains side by
+// side (Tune::fr_bi_shape; the inversions are per workgroup and run in parallel).
 __device__ __forceinline__ Fr fr_shfl(const Fr& a, int src_lane) {
   Fr r;
 #pragma unroll
   for (int k = 0; k < 8; ++k) r.v[k] = (uint32_t)__shfl((int)a.v[k], src_lane);
   return r;
 }
+template <int BI_TPB, int BI_CHUNK>
 __global__ void __launch_bounds__(BI_TPB) k_batch_inverse(Fr* __restrict__ v, size_t n) {
+  constexpr int BI_PER_LANE = BI_TPB / 64;
+  constexpr int INV_CHUNK = BI_CHUNK;
   __shared__ Fr s_acc[BI_TPB], s_pre2[BI_TPB];
   const int t = threadIdx.x;
   const size_t base = (size_t)blockIdx.x * (BI_TPB * INV_CHUNK);
+  // Round 5: no conversions.  The values stay canonical and fr_mul (= a b / R) is applied to them as they are: with acc_0 = 1 the
+  // running product after k factors is P_k / R^k, and with J = the TRUE inverse of the thread's product the way back is
+  // 1 / e_k = P_(k-1) / P_k = fr_mul(J, pre_k), J <- fr_mul(J, e_k) -- every power of R cancels.  Three products per element where
+  // the Montgomery-form version paid six (to_mont on the way in, twice, from_mont on the way out): the kernel is bound by them.
   Fr pre[INV_CHUNK];
-  Fr acc = fr_one_mont();
+  Fr acc = fr_zero();
+  acc.v[0] = 1;
 #pragma unroll
   for (int k = 0; k < INV_CHUNK; ++k) {
     const size_t i = base + (size_t)k * BI_TPB + t;
     Fr e = (i < n) ? v[i] : fr_zero();
     pre[k] = acc;
-    if (!fr_is_zero(e)) acc = fr_mul(acc, fr_to_mont(e));  // a zero stays out of the product (its output is zero)
+    if (!fr_is_zero(e)) acc = fr_mul(acc, e);  // a zero stays out of the product (its output is zero)
   }
   s_acc[t] = acc;
   __syncthreads();
-  if (t < 64) {
+  // the wave that inverts: not always wave 0 -- the workgroups sharing a CU would all run their inversions on its SIMD 0
+  const int inv_wave = (int)(blockIdx.x % (unsigned)BI_PER_LANE);
+  if ((threadIdx.x >> 6) == inv_wave) {
+    const int t = threadIdx.x & 63;
     // lane t owns the thread products t, 64 + t, ... (conflict-free LDS columns)
     Fr a2 = fr_one_mont();
 #pragma unroll
@@ -68,15 +82,18 @@ __global__ void __launch_bounds__(BI_TPB) k_batch_inverse(Fr* __restrict__ v, si
     }
   }
   __syncthreads();
-  Fr inv = s_acc[t];
+  // wave-level stretch above: s_acc[t] = R^2 / (thread product) (the Montgomery-form inverse of a value read as x R); two products
+  // with the plain 1 strip the two factors of R: the true inverse
+  Fr one = fr_zero();
+  one.v[0] = 1;
+  Fr inv = fr_mul(fr_mul(s_acc[t], one), one);
 #pragma unroll
   for (int k = INV_CHUNK - 1; k >= 0; --k) {
     const size_t i = base + (size_t)k * BI_TPB + t;
     Fr e = (i < n) ? v[i] : fr_zero();  // re-read instead of kept: 16 more live elements would not fit the register file
     if (!fr_is_zero(e)) {
-      Fr r = fr_mul(inv, pre[k]);
-      inv = fr_mul(inv, fr_to_mont(e));
-      v[i] = fr_from_mont(r);
+      v[i] = fr_mul(inv, pre[k]);
+      inv = fr_mul(inv, e);
     }
   }
 }
@@ -161,7 +178,19 @@ __global__ void __launch_bounds__(256) k_ubench_fr30(Fr30* __restrict__ out, int
 
 int batch_inverse_dev(Fr* d, size_t n, hipStream_t st) {
   if (!n) return DVP_OK;
-  hipLaunchKernelGGL(k_batch_inverse, dim3(cdiv(n, (size_t)BI_TPB * INV_CHUNK)), dim3(BI_TPB), 0, st, d, n);
+#define DVP_BI(TPB, CH) hipLaunchKernelGGL((k_batch_inverse<TPB, CH>), dim3(cdiv(n, (size_t)TPB * CH)), dim3(TPB), 0, st, d, n)
+  switch ((int)tune().fr_bi_shape) {
+    case 0: DVP_BI(512, 16); break;  // rounds 3-4
+    case 1: DVP_BI(256, 8); break;
+    case 2: DVP_BI(256, 4); break;
+    case 3: DVP_BI(512, 8); break;
+    case 4: DVP_BI(128, 8); break;
+    case 5: DVP_BI(128, 4); break;
+    case 6: DVP_BI(256, 16); break;
+    case 7: DVP_BI(1024, 8); break;
+    default: DVP_BI(256, 16); break;
+  }
+#undef DVP_BI
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }

@@ -999,12 +999,25 @@ k_round0_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
 // on nothing but c_0, so one three-launch scan carries all of them (a column of R running sums per key) where the rounds used to
 // pay three launches each.  rp: (c_r, o_r) for r = 1 .. R, each nkeys + 1 words (o_r[nkeys] = total), at rp + 2 (r - 1) (nkeys + 1).
 __global__ void __launch_bounds__(SCAN_TPB) k_mscan_local(const uint32_t* __restrict__ cnt0, uint32_t m, int R, uint32_t* __restrict__ rp,
-                                                          uint32_t* __restrict__ bs /* [R][nb] */) {
+                                                          uint32_t* __restrict__ bs /* [R][nb], then nb block maxima of cnt0 */) {
   __shared__ uint32_t sh[SCAN_TPB];
   const uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
   uint32_t v[SCAN_EPT];
 #pragma unroll
   for (int k = 0; k < SCAN_EPT; ++k) v[k] = (base + k < m) ? cnt0[base + k] : 0;
+  {  // the largest count of this block (k_mscan_bsums reduces the blocks' maxima: no atomics -- 2 048 waves on one word cost 20 us)
+    uint32_t mx = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_EPT; ++k) mx = max(mx, v[k]);
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SCAN_TPB / 64; ++w) mx = max(mx, sh[w]);
+      bs[(size_t)R * gridDim.x + blockIdx.x] = mx;
+    }
+    __syncthreads();
+  }
   for (int r = 1; r <= R; ++r) {
     uint32_t* c = rp + (size_t)(2 * (r - 1)) * ((size_t)m + 1);
     uint32_t* o = c + ((size_t)m + 1);
@@ -1028,7 +1041,8 @@ __global__ void __launch_bounds__(SCAN_TPB) k_mscan_local(const uint32_t* __rest
   }
 }
 __global__ void __launch_bounds__(SCAN_TPB) k_mscan_bsums(uint32_t* __restrict__ bs, uint32_t nb, uint32_t m, uint32_t* __restrict__ rp,
-                                                          uint32_t* __restrict__ off0 /* item offsets (or nullptr): off0[m] = the padded total */) {
+                                                          uint32_t* __restrict__ off0 /* item offsets (or nullptr): off0[m] = the padded total */,
+                                                          uint32_t* __restrict__ dmax /* the largest count (or nullptr) */) {
   __shared__ uint32_t sh[SCAN_TPB];
   const int r = blockIdx.x + 1;
   uint32_t* row = bs + (size_t)(r - 1) * nb;
@@ -1045,21 +1059,32 @@ __global__ void __launch_bounds__(SCAN_TPB) k_mscan_bsums(uint32_t* __restrict__
     rp[(size_t)(2 * (r - 1) + 1) * ((size_t)m + 1) + m] = carry;  // o_r[nkeys]
     if (r == 1 && off0) off0[m] = 2u * carry;
   }
+  if (r == 1 && dmax) {  // the largest bucket, from the block maxima k_mscan_local left behind the R rows of block sums
+    const uint32_t* bm = bs + (size_t)gridDim.x * nb;
+    uint32_t mx = 0;
+    for (uint32_t i = threadIdx.x; i < nb; i += SCAN_TPB) mx = max(mx, bm[i]);
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SCAN_TPB / 64; ++w) mx = max(mx, sh[w]);
+      *dmax = mx;
+    }
+  }
 }
 // Round 5: the last launch of the scan also finishes what the SORT needs from the counts, which used to be six launches of their own
 // (a second three-launch scan, k_pad_odd_buckets, a memset and k_max_u32): the item offsets off0 -- the scan of the counts rounded up
 // to even is exactly twice o_1, the scan of ceil(c_0 / 2) --, the NONE in the spare slot of every odd bucket (a position the
-// scatter never writes, so it may be filled before the scatter runs) and the largest bucket (dmax, zeroed by the previous MSM's
-// tail kernel).
+// scatter never writes, so it may be filled before the scatter runs); the largest bucket comes out of k_mscan_local's block maxima
+// (k_mscan_bsums).
 __global__ void __launch_bounds__(SCAN_TPB) k_mscan_add(uint32_t* __restrict__ rp, const uint32_t* __restrict__ bs, uint32_t m, int R,
-                                                        const uint32_t* __restrict__ cnt0, uint32_t* __restrict__ off0, uint32_t* __restrict__ items,
-                                                        uint32_t* __restrict__ dmax) {
+                                                        const uint32_t* __restrict__ cnt0, uint32_t* __restrict__ off0, uint32_t* __restrict__ items) {
   const uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
   for (int r = 1; r <= R; ++r) {
     uint32_t* o = rp + (size_t)(2 * (r - 1) + 1) * ((size_t)m + 1);
     const uint32_t add = bs[(size_t)(r - 1) * gridDim.x + blockIdx.x];
     if (r == 1 && off0) {
-      uint32_t mx = 0;
 #pragma unroll
       for (int k = 0; k < SCAN_EPT; ++k)
         if (base + k < m) {
@@ -1067,10 +1092,7 @@ __global__ void __launch_bounds__(SCAN_TPB) k_mscan_add(uint32_t* __restrict__ r
           o[base + k] = v;
           off0[base + k] = 2u * v;
           if (c & 1u) items[2u * v + c] = AFF_NONE;
-          mx = max(mx, c);
         }
-      for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d));
-      if ((threadIdx.x & 63) == 0 && mx) atomicMax(dmax, mx);
       continue;
     }
 #pragma unroll
@@ -1907,7 +1929,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   }
   size_t o_gdesc = carve(affine_mode ? desc_n * sizeof(uint32_t) : 16);  // one descriptor word per output slot
   size_t o_rp = carve(pipelined ? (size_t)ra_plan * 2 * ((size_t)p.nkeys + 1) * 4 : 16);  // (counts, offsets) of rounds 1 .. ra_plan
-  size_t o_bsum2 = carve(((size_t)(ra_plan > 0 ? ra_plan : 1) * ((size_t)p.nkeys / SCAN_BLK + 1) + 8) * 4);  // scan scratch of the side stream: a row of block sums per round
+  size_t o_bsum2 = carve(((size_t)((ra_plan > 0 ? ra_plan : 1) + 1) * ((size_t)p.nkeys / SCAN_BLK + 1) + 8) * 4);  // scan scratch of the side stream: a row of block sums per round
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
   size_t o_rest = carve(((size_t)p.nkeys + 1) * 4);  // k_bucket_pairs' list of buckets with more than two entries
   size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
@@ -2000,9 +2022,9 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     // (the caller's stream only: the side-stream flavour keeps the sort's own scan, padding and maximum)
     uint32_t* off0 = side_stream ? nullptr : off;
     hipLaunchKernelGGL(k_mscan_local, dim3(nb), dim3(SCAN_TPB), 0, bk, cnt, nk, ra_plan, rp, bsum2);
-    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, bk, bsum2, nb, nk, rp, off0);
-    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, bk, rp, bsum2, nk, ra_plan, (const uint32_t*)cnt, off0, items, d_max);
+    hipLaunchKernelGGL(k_mscan_bsums, dim3(ra_plan), dim3(SCAN_TPB), 0, bk, bsum2, nb, nk, rp, off0, off0 ? d_max : (uint32_t*)nullptr);
     if (off0) DVP_TRY(read_max());  // the largest bucket is on its way to the host before the descriptors and the last scatter run
+    hipLaunchKernelGGL(k_mscan_add, dim3(nb), dim3(SCAN_TPB), 0, bk, rp, bsum2, nk, ra_plan, (const uint32_t*)cnt, off0, items);
     DescPlan plan;
     for (int q = 0; q < 40; ++q) plan.at[q] = q < ra_plan ? desc_at[q] : 0;
     const size_t per_key = (e_est >> 2) / nk;  // round 1's outputs per bucket

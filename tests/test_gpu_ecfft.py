@@ -231,6 +231,16 @@ def test_batch_inverse_and_barycentric(dvp, nat):
     a = to_limbs(vals)
     dvp.check(dvp.lib.dvp_fr_batch_inverse(nat.ptr(a), len(vals)))
     assert from_limbs(a) == o.fr_batch_inverse(vals)
+    # every workgroup shape of k_batch_inverse (DVP_FR_BI_SHAPE) on a length that leaves ragged last blocks, zeros included
+    big = [rnd.randrange(o.P) for _ in range(20011)]
+    for z in (0, 63, 64, 4095, 4096, 8191, 8192, 20010):
+        big[z] = 0
+    exp = o.fr_batch_inverse(big)
+    for shape in (0, 1, 2, 3, 4, 5, 6, 7):
+        with nat.tune(DVP_FR_BI_SHAPE=shape):
+            b = to_limbs(big)
+            dvp.check(dvp.lib.dvp_fr_batch_inverse(nat.ptr(b), len(big)))
+            assert from_limbs(b) == exp, shape
     ot = o.FFTree(6)
     tb = o.domain_tables(ot)
     ev = [rnd.randrange(o.P) for _ in range(tb["m"])]
