@@ -64,25 +64,34 @@ GF_DEV uint32_t gf_andxor(uint32_t m, uint32_t b, uint32_t acc) {
 // c[0..15] (466 significant bits) -> reduced element.  z^233 = z^74 + 1:
 // word j >= 8 sits at bit 32j = 233 + (32(j-8)+23), so it folds into bit offsets 32(j-8)+23 and
 // 32(j-8)+97 = 32(j-5)+1.
-// TOP: the highest word that can be nonzero (a square of a reduced element ends in word 14)
+// Round 5: word by word.  The words 12 .. 15 fold into 7 .. 11 first (T8 .. T11 below are the unreduced words 8 .. 11 with those
+// folds applied); after that every output word takes the fold of TWO neighbouring high words, whose shifted images do not overlap --
+// (T[i+8] << 23) | (T[i+7] >> 9) and (T[i+5] << 1) | (T[i+4] >> 31) -- so each fold is ONE v_alignbit_b32 and the sums are 3-input
+// xors: ~36 instructions where the word-serial loop (four shifts and four xors per high word) took ~72.
+// TOP: the highest word that can be nonzero (a square of a reduced element, or a Karatsuba product, ends in word 14).
+GF_DEV uint32_t gf_xor3_(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 template <int TOP = 15>
-GF_DEV Gf gf_reduce16(uint32_t* c) {
-#pragma unroll
-  for (int j = TOP; j >= 8; --j) {
-    uint32_t t = c[j];
-    c[j - 8] ^= t << 23;
-    c[j - 7] ^= t >> 9;
-    c[j - 5] ^= t << 1;
-    c[j - 4] ^= t >> 31;
-  }
-  uint32_t t = c[7] >> 9;
-  c[0] ^= t;
-  c[2] ^= t << 10;
-  c[3] ^= t >> 22;
-  c[7] &= 0x1FFu;
+GF_DEV Gf gf_reduce16(const uint32_t* c) {
+  const uint32_t T15 = TOP >= 15 ? c[15] : 0u;
+  const uint32_t T14 = c[14], T13 = c[13], T12 = c[12];
+  const uint32_t T11 = TOP >= 15 ? c[11] ^ (T15 >> 31) : c[11];
+  const uint32_t T10 = c[10] ^ (TOP >= 15 ? __builtin_amdgcn_alignbit(T15, T14, 31) : T14 >> 31);
+  const uint32_t T9 = c[9] ^ __builtin_amdgcn_alignbit(T14, T13, 31);
+  const uint32_t T8 = TOP >= 15 ? gf_xor3_(c[8], __builtin_amdgcn_alignbit(T13, T12, 31), T15 >> 9) : c[8] ^ __builtin_amdgcn_alignbit(T13, T12, 31);
   Gf r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.w[i] = c[i];
+  r.w[0] = c[0] ^ (T8 << 23);
+  r.w[1] = c[1] ^ __builtin_amdgcn_alignbit(T9, T8, 9);
+  r.w[2] = c[2] ^ __builtin_amdgcn_alignbit(T10, T9, 9);
+  r.w[3] = gf_xor3_(c[3], __builtin_amdgcn_alignbit(T11, T10, 9), T8 << 1);
+  r.w[4] = gf_xor3_(c[4], __builtin_amdgcn_alignbit(T12, T11, 9), __builtin_amdgcn_alignbit(T9, T8, 31));
+  r.w[5] = gf_xor3_(c[5], __builtin_amdgcn_alignbit(T13, T12, 9), __builtin_amdgcn_alignbit(T10, T9, 31));
+  r.w[6] = gf_xor3_(c[6], __builtin_amdgcn_alignbit(T14, T13, 9), __builtin_amdgcn_alignbit(T11, T10, 31));
+  r.w[7] = gf_xor3_(c[7], TOP >= 15 ? __builtin_amdgcn_alignbit(T15, T14, 9) : T14 >> 9, __builtin_amdgcn_alignbit(T12, T11, 31));
+  const uint32_t t = r.w[7] >> 9;  // bits 233 .. 255
+  r.w[0] ^= t;
+  r.w[2] ^= t << 10;
+  r.w[3] ^= t >> 22;
+  r.w[7] &= 0x1FFu;
   return r;
 }
 
@@ -490,23 +499,34 @@ GF_DEV void gf_k_shl3(uint32_t* acc) {
 // are still zero and six words are shifted; the four-word rows reach bit 215, the shifts in front of rows 6 .. 3 leave at most
 // 195, 218, 221, 224 bits (seven words), and only the last three fill word 7 (227, 230, 233 bits).  60 funnel shifts per half
 // product instead of 70 -- half-rate instructions (v_alignbit_b32), 30 fewer of ~460 per product.
+// (GF_K_UNROLL = 1 -- the three-trip row loops unrolled, four scalar loop instructions per row fewer -- was measured in round 5:
+// the pair rounds ran EIGHT times slower (162 against 20 ms per proof; msm.o 2.1 -> 2.8 MB): the rolled loops are what keeps the
+// inlined products inside the register budget and the instruction cache)
+#ifndef GF_K_UNROLL
+#define GF_K_UNROLL 0
+#endif
+#if GF_K_UNROLL
+#define GF_K_LOOP _Pragma("unroll")
+#else
+#define GF_K_LOOP _Pragma("unroll 1")
+#endif
 GF_DEV void gf_k_mul_tab(uint32_t* acc, const uint32_t* a, const GfLdsK& c) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0;
   gf_k_row<3>(acc, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
-#pragma unroll 1
+GF_K_LOOP
   for (int k = 9; k >= 7; --k) {
     gf_k_shl3<6>(acc);
     gf_k_row<3>(acc, a, c, 3 * k - 10, 0);
   }
-#pragma unroll 1
+GF_K_LOOP
   for (int k = 6; k >= 4; --k) {
     gf_k_shl3<7>(acc);
     gf_k_row<4>(acc, a, c, 3 * k - 10, 0);
   }
   gf_k_shl3<7>(acc);
   gf_k_row<4>(acc, a, c, 0, 1);  // k = 3: bits 9..11 -> << 1
-#pragma unroll 1
+GF_K_LOOP
   for (int k = 2; k >= 0; --k) {
     gf_k_shl3<8>(acc);
     gf_k_row<4>(acc, a, c, 0, 10 - 3 * k);

@@ -120,3 +120,84 @@ def test_pin_xsk233_tool_agrees_with_the_oracle_rule():
     assert pin.pin(k, vec, out=lines.append) == 0 and lines[0].startswith("CURRENT RULE CONFIRMED")
     bad = bytes([vec[0] ^ 4]) + vec[1:]
     assert pin.pin(k, bad, out=lines.append) == 2
+
+
+def test_gf233_word_by_word_reduction_formulas():
+    """gf233.cuh (round 5): gf_reduce16 and the Karatsuba combine of the hot multiplier fold the high words with ONE funnel shift per
+    fold instead of a word-serial loop.  The formulas, restated on Python ints word for word, against plain polynomial reduction
+    modulo z^233 + z^74 + 1: random and all-ones inputs at the full 512 / 466 bits, and (L, M, H) triples at their largest sizes
+    (233, 233, 231 bits) -- the bounds that let the combine drop the words 11 and 15."""
+    import random
+    M32 = 0xFFFFFFFF
+
+    def alignbit(hi, lo, s):
+        return (((hi << 32) | lo) >> s) & M32
+
+    def reduce_poly(x):
+        while x.bit_length() > 233:
+            b = x.bit_length() - 1
+            x ^= (1 << b) | (1 << (b - 233 + 74)) | (1 << (b - 233))
+        return x
+
+    def words(x, n):
+        return [(x >> (32 * i)) & M32 for i in range(n)]
+
+    def tail(r):
+        t = r[7] >> 9
+        r[0] ^= t
+        r[2] ^= (t << 10) & M32
+        r[3] ^= t >> 22
+        r[7] &= 0x1FF
+        return sum(w << (32 * i) for i, w in enumerate(r))
+
+    def reduce16(c):
+        T15, T14, T13, T12 = c[15], c[14], c[13], c[12]
+        T11 = c[11] ^ (T15 >> 31)
+        T10 = c[10] ^ alignbit(T15, T14, 31)
+        T9 = c[9] ^ alignbit(T14, T13, 31)
+        T8 = c[8] ^ alignbit(T13, T12, 31) ^ (T15 >> 9)
+        r = [c[0] ^ ((T8 << 23) & M32), c[1] ^ alignbit(T9, T8, 9), c[2] ^ alignbit(T10, T9, 9),
+             c[3] ^ alignbit(T11, T10, 9) ^ ((T8 << 1) & M32), c[4] ^ alignbit(T12, T11, 9) ^ alignbit(T9, T8, 31),
+             c[5] ^ alignbit(T13, T12, 9) ^ alignbit(T10, T9, 31), c[6] ^ alignbit(T14, T13, 9) ^ alignbit(T11, T10, 31),
+             c[7] ^ alignbit(T15, T14, 9) ^ alignbit(T12, T11, 31)]
+        return tail(r)
+
+    def combine(L, H, M):
+        M = [M[i] ^ L[i] ^ H[i] for i in range(8)]
+        ms = [(M[0] << 21) & M32] + [alignbit(M[i], M[i - 1], 11) for i in range(1, 8)]
+        hs = [(H[0] << 10) & M32] + [alignbit(H[i], H[i - 1], 22) for i in range(1, 8)]
+        T14, T13, T12, T11 = hs[7], hs[6], hs[5], hs[4]
+        T10 = ms[7] ^ hs[3] ^ (T14 >> 31)
+        T9 = ms[6] ^ hs[2] ^ alignbit(T14, T13, 31)
+        T8 = ms[5] ^ hs[1] ^ alignbit(T13, T12, 31)
+        r = [L[0] ^ ((T8 << 23) & M32), L[1] ^ alignbit(T9, T8, 9), L[2] ^ alignbit(T10, T9, 9),
+             L[3] ^ ms[0] ^ alignbit(T11, T10, 9) ^ ((T8 << 1) & M32), L[4] ^ ms[1] ^ alignbit(T12, T11, 9) ^ alignbit(T9, T8, 31),
+             L[5] ^ ms[2] ^ alignbit(T13, T12, 9) ^ alignbit(T10, T9, 31), L[6] ^ ms[3] ^ alignbit(T14, T13, 9) ^ alignbit(T11, T10, 31),
+             L[7] ^ ms[4] ^ hs[0] ^ (T14 >> 9) ^ alignbit(T12, T11, 31)]
+        return tail(r)
+
+    rnd = random.Random(2025)
+    for it in range(4000):
+        bits = (512, 466, 465)[it % 3]
+        x = (1 << bits) - 1 if it < 3 else rnd.getrandbits(bits)
+        assert reduce16(words(x, 16)) == reduce_poly(x), it
+        L, Mm, H = rnd.getrandbits(233), rnd.getrandbits(233), rnd.getrandbits(231)
+        if it % 4 == 0:
+            L, Mm, H = L | (1 << 232), Mm | (1 << 232), H | (1 << 230)
+        if it == 1:
+            L, Mm, H = (1 << 233) - 1, (1 << 233) - 1, (1 << 231) - 1
+        assert combine(words(L, 8), words(H, 8), words(Mm, 8)) == reduce_poly(L ^ ((Mm ^ L ^ H) << 117) ^ (H << 234)), it
+    # the accumulator of a half product is shifted only as far as it is filled (gf_k_mul_tab): the bit lengths the comments claim
+    ln = 64 + 119  # the three-word rows k = 10 .. 7: an entry of 119 bits two words up
+    for k in (9, 8, 7):
+        ln += 3
+        assert ln <= 6 * 32, k  # shifted as six words
+        ln = max(ln, 64 + 119)
+    for k in (6, 5, 4, 3):
+        ln += 3
+        assert ln <= 7 * 32, k  # seven words
+        ln = max(ln, 96 + 119)
+    for k in (2, 1, 0):
+        ln += 3
+        ln = max(ln, 96 + 119)
+    assert ln == 233
