@@ -514,22 +514,23 @@ GF_DEV void gf_k_mul_tab(uint32_t* acc, const uint32_t* a, const GfLdsK& c) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0;
   gf_k_row<3>(acc, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
+  // (the loops count the shift amounts themselves: one scalar addition per row instead of two)
 GF_K_LOOP
-  for (int k = 9; k >= 7; --k) {
+  for (int rsh = 17; rsh >= 11; rsh -= 3) {  // k = 9, 8, 7: 3 k - 10
     gf_k_shl3<6>(acc);
-    gf_k_row<3>(acc, a, c, 3 * k - 10, 0);
+    gf_k_row<3>(acc, a, c, rsh, 0);
   }
 GF_K_LOOP
-  for (int k = 6; k >= 4; --k) {
+  for (int rsh = 8; rsh >= 2; rsh -= 3) {  // k = 6, 5, 4
     gf_k_shl3<7>(acc);
-    gf_k_row<4>(acc, a, c, 3 * k - 10, 0);
+    gf_k_row<4>(acc, a, c, rsh, 0);
   }
   gf_k_shl3<7>(acc);
   gf_k_row<4>(acc, a, c, 0, 1);  // k = 3: bits 9..11 -> << 1
 GF_K_LOOP
-  for (int k = 2; k >= 0; --k) {
+  for (int lsh = 4; lsh <= 10; lsh += 3) {  // k = 2, 1, 0: 10 - 3 k
     gf_k_shl3<8>(acc);
-    gf_k_row<4>(acc, a, c, 0, 10 - 3 * k);
+    gf_k_row<4>(acc, a, c, 0, lsh);
   }
 }
 // x = lo + hi z^117
