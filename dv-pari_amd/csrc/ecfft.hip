@@ -444,6 +444,9 @@ __device__ __forceinline__ void lds_bfly(Fr30* x, const Fr30* __restrict__ tws, 
 }
 // two layers per barrier inside the block (the radix-4 step of k_butterfly4 on the LDS copy): half the barriers and half the LDS
 // round trips of the per-layer loop.  lh2 = log2 of the narrow layer's pair distance; wide layer first when DEC.
+// (Round 5 measured THREE layers per barrier, the radix-8 step of k_butterfly8 on the LDS copy, in this kernel and in k_extend_top:
+// eight values and seven constant pairs per thread spill 250 B per lane at the 128 VGPRs of 512-thread workgroups and still cost a
+// wave per SIMD at 384 threads -- the prover's three extends 0.77 -> 0.99 / 1.16 ms, enter 3.4 -> 3.9 / 4.3 ms: not kept.)
 template <bool DEC, class MAP = TwId>
 __device__ __forceinline__ void lds_bfly4(Fr30* x, const Fr30* __restrict__ tw_wide, const Fr30* __restrict__ tw_narrow, int lh2, uint32_t quads, MAP f = MAP()) {
   const uint32_t h2 = 1u << lh2, h1 = h2 << 1;
