@@ -460,16 +460,21 @@ GF_DEV void gf_k_tab_build(const GfLdsK& c, const uint32_t* b) {
   gf_k_store(c, 5, t4);
   gf_k_store(c, 7, t6);
 }
-// one digit position of a half operand: NW lookups (all issued before the first xor), 4 NW words into NW + 3
+// one digit position of a half operand: NW lookups (all issued before the first xor), 4 NW words into NW + 3.
+// Round 5: in two halves, so that a row is  lookups issued -> accumulator shifted -> lookups xored in: the shift (7 funnel shifts,
+// ~35 cycles of the SIMD) does not depend on the lookups and runs while the LDS serves them; hipcc's own order was shift, then
+// lookups, then wait (gf_k_pin keeps it from moving the shift back up).
 template <int NW>
-GF_DEV void gf_k_row(uint32_t* acc, const uint32_t* a, const GfLdsK& c, int rsh, int lsh) {
-  gf_u32x4 v[NW];
+GF_DEV void gf_k_row_ld(gf_u32x4* v, const uint32_t* a, const GfLdsK& c, int rsh, int lsh) {
 #pragma unroll
   for (int j = 0; j < NW; ++j) {
     uint32_t sh = (a[j] >> rsh) << lsh;
     v[j] = gf_lds_ld(__builtin_amdgcn_bitop3_b32(sh, 0x1C00u, c.lane_base, 0xEA));  // (sh & 0x1C00) | lane_base
   }
   asm volatile("" ::: "memory");
+}
+template <int NW>
+GF_DEV void gf_k_row_acc(uint32_t* acc, const gf_u32x4* v) {
   acc[0] ^= v[0].x;
   acc[1] = gf_xor3(acc[1], v[0].y, v[1].x);
   if (NW == 4) {
@@ -485,12 +490,34 @@ GF_DEV void gf_k_row(uint32_t* acc, const uint32_t* a, const GfLdsK& c, int rsh,
     acc[5] ^= v[2].w;
   }
 }
+template <int NW>
+GF_DEV void gf_k_row(uint32_t* acc, const uint32_t* a, const GfLdsK& c, int rsh, int lsh) {
+  gf_u32x4 v[NW];
+  gf_k_row_ld<NW>(v, a, c, rsh, lsh);
+  gf_k_row_acc<NW>(acc, v);
+}
+// the accumulator words as they are, as far as the optimiser is concerned, only from here on
+template <int N>
+GF_DEV void gf_k_pin(uint32_t* acc) {
+  if (N == 6) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]));
+  else if (N == 7) asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]));
+  else asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
+}
 // the low N words of the accumulator, three bits up (the words above them are still zero, see gf_k_mul_tab)
 template <int N = 8>
 GF_DEV void gf_k_shl3(uint32_t* acc) {
 #pragma unroll
   for (int i = N - 1; i > 0; --i) acc[i] = __builtin_amdgcn_alignbit(acc[i], acc[i - 1], 29);
   acc[0] <<= 3;
+}
+// lookups of a row, then the shift of the N filled words, then the xors
+template <int NW, int N>
+GF_DEV void gf_k_shl3_row(uint32_t* acc, const uint32_t* a, const GfLdsK& c, int rsh, int lsh) {
+  gf_u32x4 v[NW];
+  gf_k_row_ld<NW>(v, a, c, rsh, lsh);
+  gf_k_pin<N>(acc);
+  gf_k_shl3<N>(acc);
+  gf_k_row_acc<NW>(acc, v);
 }
 // acc[0..7] = a (4 words, a[3] < 2^21) * (half operand whose table is in LDS); digit k of a word = bits [3k, 3k+3),
 // k = 10 is the 2-bit top digit, a[3] has digits 0..6 only.
@@ -516,22 +543,12 @@ GF_DEV void gf_k_mul_tab(uint32_t* acc, const uint32_t* a, const GfLdsK& c) {
   gf_k_row<3>(acc, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
   // (the loops count the shift amounts themselves: one scalar addition per row instead of two)
 GF_K_LOOP
-  for (int rsh = 17; rsh >= 11; rsh -= 3) {  // k = 9, 8, 7: 3 k - 10
-    gf_k_shl3<6>(acc);
-    gf_k_row<3>(acc, a, c, rsh, 0);
-  }
+  for (int rsh = 17; rsh >= 11; rsh -= 3) gf_k_shl3_row<3, 6>(acc, a, c, rsh, 0);  // k = 9, 8, 7: 3 k - 10
 GF_K_LOOP
-  for (int rsh = 8; rsh >= 2; rsh -= 3) {  // k = 6, 5, 4
-    gf_k_shl3<7>(acc);
-    gf_k_row<4>(acc, a, c, rsh, 0);
-  }
-  gf_k_shl3<7>(acc);
-  gf_k_row<4>(acc, a, c, 0, 1);  // k = 3: bits 9..11 -> << 1
+  for (int rsh = 8; rsh >= 2; rsh -= 3) gf_k_shl3_row<4, 7>(acc, a, c, rsh, 0);  // k = 6, 5, 4
+  gf_k_shl3_row<4, 7>(acc, a, c, 0, 1);  // k = 3: bits 9..11 -> << 1
 GF_K_LOOP
-  for (int lsh = 4; lsh <= 10; lsh += 3) {  // k = 2, 1, 0: 10 - 3 k
-    gf_k_shl3<8>(acc);
-    gf_k_row<4>(acc, a, c, 0, lsh);
-  }
+  for (int lsh = 4; lsh <= 10; lsh += 3) gf_k_shl3_row<4, 8>(acc, a, c, 0, lsh);  // k = 2, 1, 0: 10 - 3 k
 }
 // x = lo + hi z^117
 GF_DEV void gf_k_split(const Gf& x, uint32_t* lo, uint32_t* hi) {
