@@ -537,10 +537,46 @@ GF_DEV void gf_k_shl3_row(uint32_t* acc, const uint32_t* a, const GfLdsK& c, int
 #else
 #define GF_K_LOOP _Pragma("unroll 1")
 #endif
+GF_DEV void gf_k_rows_9_0(uint32_t* acc, const uint32_t* a, const GfLdsK& c);
 GF_DEV void gf_k_mul_tab(uint32_t* acc, const uint32_t* a, const GfLdsK& c) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0;
   gf_k_row<3>(acc, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
+  gf_k_rows_9_0(acc, a, c);
+}
+// Table build and the first row of the product in one (round 5).  Row k = 10 looks up the 2-bit top digits of the words 0 .. 2:
+// entries 0 .. 3 only.  A wave's LDS operations execute in order, so with the row's three lookups placed right behind the stores of
+// the entries 1, 2, 3 their data is back four stores (4 x 13 LDS cycles) sooner than behind all seven, and the other four stores
+// run under the row's xors -- every half product used to start with the whole table's stores in front of its first lookups.
+GF_DEV void gf_k_tab_build_mul(uint32_t* acc, const uint32_t* a, const uint32_t* b, const GfLdsK& c) {
+  uint32_t t2[4], t3[4], t4[4], t6[4];
+  gf_k_store(c, 1, b);
+  gf_k_shl1(b, t2);
+  gf_k_store(c, 2, t2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t3[i] = t2[i] ^ b[i];
+  gf_k_store(c, 3, t3);
+  asm volatile("" ::: "memory");
+  gf_u32x4 v[3];
+  gf_k_row_ld<3>(v, a, c, 20, 0);  // k = 10: (w >> 30) << 10 == (w >> 20) & 0xC00
+  gf_k_shl1(t2, t4);
+  gf_k_store(c, 4, t4);
+  gf_k_shl1(t3, t6);
+  gf_k_store(c, 6, t6);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t4[i] ^= b[i];
+    t6[i] ^= b[i];
+  }
+  gf_k_store(c, 5, t4);
+  gf_k_store(c, 7, t6);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0;
+  gf_k_row_acc<3>(acc, v);
+  gf_k_rows_9_0(acc, a, c);
+}
+GF_DEV void gf_k_rows_9_0(uint32_t* acc, const uint32_t* a, const GfLdsK& c) {
   // (the loops count the shift amounts themselves: one scalar addition per row instead of two)
 GF_K_LOOP
   for (int rsh = 17; rsh >= 11; rsh -= 3) gf_k_shl3_row<3, 6>(acc, a, c, rsh, 0);  // k = 9, 8, 7: 3 k - 10
@@ -600,17 +636,14 @@ GF_DEV Gf gf_mul(const Gf& a, const Gf& b, const GfLdsK& c) {
   gf_k_split(a, a0, a1);
   gf_k_split(b, b0, b1);
   uint32_t L[8], H[8], M[8];
-  gf_k_tab_build(c, b0);
-  gf_k_mul_tab(L, a0, c);
-  gf_k_tab_build(c, b1);
-  gf_k_mul_tab(H, a1, c);
+  gf_k_tab_build_mul(L, a0, b0, c);
+  gf_k_tab_build_mul(H, a1, b1, c);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     a0[i] ^= a1[i];
     b0[i] ^= b1[i];
   }
-  gf_k_tab_build(c, b0);
-  gf_k_mul_tab(M, a0, c);
+  gf_k_tab_build_mul(M, a0, b0, c);
   return gf_k_combine(L, H, M);
 }
 // a1 * b and a2 * b: each half table of b is built once and serves both products
@@ -620,11 +653,9 @@ GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLdsK& c, Gf
   gf_k_split(a2, q0, q1);
   gf_k_split(b, b0, b1);
   uint32_t L1[8], H1[8], M1[8], L2[8], H2[8], M2[8];
-  gf_k_tab_build(c, b0);
-  gf_k_mul_tab(L1, p0, c);
+  gf_k_tab_build_mul(L1, p0, b0, c);
   gf_k_mul_tab(L2, q0, c);
-  gf_k_tab_build(c, b1);
-  gf_k_mul_tab(H1, p1, c);
+  gf_k_tab_build_mul(H1, p1, b1, c);
   gf_k_mul_tab(H2, q1, c);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -632,8 +663,7 @@ GF_DEV void gf_mul2(const Gf& a1, const Gf& a2, const Gf& b, const GfLdsK& c, Gf
     q0[i] ^= q1[i];
     b0[i] ^= b1[i];
   }
-  gf_k_tab_build(c, b0);
-  gf_k_mul_tab(M1, p0, c);
+  gf_k_tab_build_mul(M1, p0, b0, c);
   gf_k_mul_tab(M2, q0, c);
   r1 = gf_k_combine(L1, H1, M1);
   r2 = gf_k_combine(L2, H2, M2);
