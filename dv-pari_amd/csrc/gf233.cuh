@@ -708,22 +708,62 @@ struct GfSqrTables {
   const Gf* t116;
   const Gf* th;  // the half-trace (also GF(2)-linear): th[pos][byte] = H(byte * z^(8 pos))
 };
-GF_DEV Gf gf_sqr_tab(const Gf& a, const Gf* __restrict__ T) {
-  Gf r = gf_zero();
+// Round 5: the lookups of one word of a (four bytes: eight 16-byte loads) are issued together and xored in afterwards, with 3-input
+// xors.  The first version walked the bytes in a rolled loop -- load, wait, xor, thirty times: thirty dependent round trips to the L2 per
+// pass, three passes per inversion, and every wave of a pair round reaches its inversion at the same time, so nothing hid them.
+template <int NB, bool FENCE = true>
+GF_DEV void gf_sqr_tab_word(Gf& r, uint32_t word, const Gf* __restrict__ Tw) {  // NB byte lookups of one word, issued together
+  gf_u32x4 lo[4], hi[4];
 #pragma unroll
-  for (int w = 0; w < 8; ++w) {  // static word index (a runtime index would push a.w to scratch)
-    const uint32_t word = a.w[w];
-#pragma unroll 1
-    for (int b = 0; b < 4; ++b) {
-      if (4 * w + b >= 30) break;
-      uint32_t byte = (word >> (8 * b)) & 0xFFu;
-      const gf_u32x4* e = (const gf_u32x4*)(T + (4 * w + b) * 256 + byte);
-      gf_u32x4 lo = e[0], hi = e[1];
-      r.w[0] ^= lo.x; r.w[1] ^= lo.y; r.w[2] ^= lo.z; r.w[3] ^= lo.w;
-      r.w[4] ^= hi.x; r.w[5] ^= hi.y; r.w[6] ^= hi.z; r.w[7] ^= hi.w;
+  for (int b = 0; b < 4; ++b) {
+    if (b < NB) {
+      const uint32_t byte = (word >> (8 * b)) & 0xFFu;
+      const gf_u32x4* e = (const gf_u32x4*)(Tw + b * 256 + byte);
+      lo[b] = e[0];
+      hi[b] = e[1];
+    } else {
+      lo[b] = (gf_u32x4){0, 0, 0, 0};
+      hi[b] = (gf_u32x4){0, 0, 0, 0};
     }
   }
+  if (FENCE) asm volatile("" ::: "memory");  // (keeps the next word's loads behind this word's: the register budget of a throughput kernel)
+#pragma unroll
+  for (int b = 0; b < 4; b += 2) {
+    r.w[0] = gf_xor3_(r.w[0], lo[b].x, lo[b + 1].x); r.w[1] = gf_xor3_(r.w[1], lo[b].y, lo[b + 1].y);
+    r.w[2] = gf_xor3_(r.w[2], lo[b].z, lo[b + 1].z); r.w[3] = gf_xor3_(r.w[3], lo[b].w, lo[b + 1].w);
+    r.w[4] = gf_xor3_(r.w[4], hi[b].x, hi[b + 1].x); r.w[5] = gf_xor3_(r.w[5], hi[b].y, hi[b + 1].y);
+    r.w[6] = gf_xor3_(r.w[6], hi[b].z, hi[b + 1].z); r.w[7] = gf_xor3_(r.w[7], hi[b].w, hi[b + 1].w);
+  }
+}
+GF_DEV Gf gf_sqr_tab(const Gf& a, const Gf* __restrict__ T) {
+  Gf r = gf_zero();
+  Gf t = a;  // walked by ROTATING the words through t.w[0] (a runtime word index would push a to scratch; unrolling the words lets the
+             // scheduler pull sixty loads and their 64-bit addresses in front of the products around them: 390 B of scratch per lane)
+#pragma unroll 1
+  for (int w = 0; w < 7; ++w) {
+    gf_sqr_tab_word<4>(r, t.w[0], T + (size_t)w * 1024);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) t.w[i] = t.w[i + 1];
+  }
+  gf_sqr_tab_word<2>(r, t.w[0], T + 7 * 1024);  // bits 224 .. 232: two bytes
   return r;
+}
+// the same for a latency CHAIN (one point per quad / row of lanes on a lone wave: k_tail, the deep merge levels): the words unrolled, so
+// that the scheduler issues the sixty loads of a pass as early as its registers allow -- two or three round trips to the L2 per pass
+// instead of eight (a kernel at 3 waves per SIMD has no registers for that: the note in gf_sqr_tab)
+GF_DEV Gf gf_sqr_tab_wide(const Gf& a, const Gf* __restrict__ T) {
+  Gf r = gf_zero();
+#pragma unroll
+  for (int w = 0; w < 7; ++w) gf_sqr_tab_word<4, false>(r, a.w[w], T + (size_t)w * 1024);
+  gf_sqr_tab_word<2, false>(r, a.w[7], T + 7 * 1024);
+  return r;
+}
+template <class LT> struct GfIsChain { static constexpr bool value = false; };
+template <> struct GfIsChain<GfLdsQ> { static constexpr bool value = true; };
+template <> struct GfIsChain<GfLdsH> { static constexpr bool value = true; };
+template <class LT>
+GF_DEV Gf gf_sqr_tab(const Gf& a, const Gf* __restrict__ T, const LT&) {
+  return GfIsChain<LT>::value ? gf_sqr_tab_wide(a, T) : gf_sqr_tab(a, T);
 }
 // a^(2^k) for any k: table passes for the 116 / 58 / 29 parts, plain squarings for the rest (< 29)
 GF_DEV Gf gf_sqr_n_fast(Gf a, int k, const GfSqrTables& T) {
@@ -743,9 +783,9 @@ GF_DEV Gf gf_inv_fast(const Gf& a, const GfSqrTables& T, const LT& L) {
   Gf b14 = gf_mul(gf_sqr_n(b7, 7), b7, L);
   Gf b28 = gf_mul(gf_sqr_n(b14, 14), b14, L);
   Gf b29 = gf_mul(gf_sqr(b28), b1, L);
-  Gf b58 = gf_mul(gf_sqr_tab(b29, T.t29), b29, L);
-  Gf b116 = gf_mul(gf_sqr_tab(b58, T.t58), b58, L);
-  Gf b232 = gf_mul(gf_sqr_tab(b116, T.t116), b116, L);
+  Gf b58 = gf_mul(gf_sqr_tab(b29, T.t29, L), b29, L);
+  Gf b116 = gf_mul(gf_sqr_tab(b58, T.t58, L), b58, L);
+  Gf b232 = gf_mul(gf_sqr_tab(b116, T.t116, L), b116, L);
   return gf_sqr(b232);
 }
 

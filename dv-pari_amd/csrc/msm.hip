@@ -1508,7 +1508,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
       a.x = gf_mul(p.X, zi, H);
       a.y = gf_mul(p.Y, gf_sqr(zi), H);
       const Gf lam1 = gf_add(gf_add(a.x, gf_mul(p.Y, inv, H)), gf_one());
-      w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
+      w = gf_sqr_tab_wide(gf_sqr_tab_wide(lam1, T.t116), T.t116);
       if (rule) w = codec_present(w, rule, T);
     } else {
       Gf zi = gf_inv_fast(p.Z, T, H);
@@ -1516,7 +1516,7 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
       a.y = gf_mul(p.Y, gf_sqr(zi), H);
       if (out_enc) {  // x = 0 (the point of order two): the same formula as k_encode_point, where 1 / 0 reads 0
         const Gf lam1 = gf_add(gf_add(a.x, gf_mul(a.y, gf_inv_fast(a.x, T, H), H)), gf_one());
-        w = gf_sqr_tab(gf_sqr_tab(lam1, T.t116), T.t116);
+        w = gf_sqr_tab_wide(gf_sqr_tab_wide(lam1, T.t116), T.t116);
         if (rule) w = codec_present(w, rule, T);
       }
     }
