@@ -490,10 +490,17 @@ k_hist_local2(const uint16_t* __restrict__ plo, const uint32_t* __restrict__ pst
   __syncthreads();
   uint32_t hi = fx_chunk_partition(cstart, FX_NP, g);
   uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * FX_CHUNK, hi_e = min(pstart[hi + 1], lo_e + FX_CHUNK);
-  for (uint32_t j = lo_e + threadIdx.x; j < hi_e; j += SORT_TPB) {
-    uint32_t d = plo[j];
-    atomicAdd(&lds_cnt[d >> 1], 1u << (16 * (d & 1)));
+  // Round 5: eight entries per load (16 bytes) over the 16-byte-aligned body of the chunk, single entries for its ragged ends -- one
+  // load per thread and chunk instead of eight 2-byte ones (100 MB at 1.3 TB/s: the kernel waited for its loads)
+  auto count = [&](uint32_t d) { atomicAdd(&lds_cnt[d >> 1], 1u << (16 * (d & 1))); };
+  const uint32_t body_lo = min(hi_e, (lo_e + 7u) & ~7u), body_hi = max(body_lo, hi_e & ~7u);
+  for (uint32_t j = lo_e + threadIdx.x; j < body_lo; j += SORT_TPB) count(plo[j]);
+  for (uint32_t j = body_lo + 8u * threadIdx.x; j < body_hi; j += 8u * SORT_TPB) {
+    const uint4 v = *(const uint4*)(plo + j);
+    count(v.x & 0xffffu); count(v.x >> 16); count(v.y & 0xffffu); count(v.y >> 16);
+    count(v.z & 0xffffu); count(v.z >> 16); count(v.w & 0xffffu); count(v.w >> 16);
   }
+  for (uint32_t j = body_hi + threadIdx.x; j < hi_e; j += SORT_TPB) count(plo[j]);
   __syncthreads();
   uint32_t* out = (uint32_t*)(hist + (size_t)g * nb);
   for (uint32_t k = threadIdx.x; k < (nb >> 1); k += SORT_TPB) out[k] = lds_cnt[k];
@@ -687,12 +694,21 @@ k_scatter_local2_staged(const uint16_t* __restrict__ plo, const uint32_t* __rest
   }
   __syncthreads();
   const uint32_t lo_e = pstart[hi] + (g - cstart[hi]) * FX_CHUNK, hi_e = min(pstart[hi + 1], lo_e + FX_CHUNK);
-  for (uint32_t j = lo_e + t; j < hi_e; j += SORT_TPB) {
-    uint32_t b = plo[j];
-    uint32_t pos = atomicAdd(&cur[b], 1u);
-    st_id[pos] = pid[j];
+  auto place = [&](uint32_t b, uint32_t id) {
+    const uint32_t pos = atomicAdd(&cur[b], 1u);
+    st_id[pos] = id;
     st_b[pos] = (uint16_t)b;
+  };
+  // Round 5: eight entries per thread and trip over the aligned body of the chunk (one 16-byte load of keys, two of ids) instead of
+  // eight trips of a 2-byte and a 4-byte load; which entry of a bin lands where inside the bin changes, the bin's content does not
+  const uint32_t body_lo = min(hi_e, (lo_e + 7u) & ~7u), body_hi = max(body_lo, hi_e & ~7u);
+  for (uint32_t j = lo_e + t; j < body_lo; j += SORT_TPB) place(plo[j], pid[j]);
+  for (uint32_t j = body_lo + 8u * t; j < body_hi; j += 8u * SORT_TPB) {
+    const uint4 k = *(const uint4*)(plo + j), a = *(const uint4*)(pid + j), c = *(const uint4*)(pid + j + 4);
+    place(k.x & 0xffffu, a.x); place(k.x >> 16, a.y); place(k.y & 0xffffu, a.z); place(k.y >> 16, a.w);
+    place(k.z & 0xffffu, c.x); place(k.z >> 16, c.y); place(k.w & 0xffffu, c.z); place(k.w >> 16, c.w);
   }
+  for (uint32_t j = body_hi + t; j < hi_e; j += SORT_TPB) place(plo[j], pid[j]);
   __syncthreads();
   for (uint32_t pos = t; pos < tot; pos += SORT_TPB) items[gdst[st_b[pos]] + pos] = st_id[pos];
 }
