@@ -1128,11 +1128,30 @@ k_round_desc_all(const uint32_t* __restrict__ rp, uint32_t nkeys, int R, DescPla
   const uint32_t key = gid / LPK, lane = gid % LPK;
   if (key >= nkeys) return;
   const size_t stride = (size_t)nkeys + 1;
-  for (int r = 1; r < R; ++r) {
-    const uint32_t* c = rp + (size_t)(2 * (r - 1)) * stride;
-    const uint32_t cr = c[key], o = c[stride + key], oo = c[3 * stride + key], nout = (cr + 1) >> 1;
-    uint32_t* d = desc + plan.at[r];
-    for (uint32_t j = lane; j < nout; j += LPK) d[oo + j] = (o + 2 * j) | ((2 * j + 1 < cr) ? DESC_PAIR : 0u);
+  // the counts and offsets of up to eight rounds are asked for at once and the descriptors written afterwards: a round's three loads
+  // used to sit in front of its stores, round after round
+  for (int r0 = 1; r0 < R; r0 += 8) {
+    uint32_t cr[8], o[8], oo[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = r0 + q;
+      if (r < R) {
+        const uint32_t* c = rp + (size_t)(2 * (r - 1)) * stride;
+        cr[q] = c[key];
+        o[q] = c[stride + key];
+        oo[q] = c[3 * stride + key];
+      } else {
+        cr[q] = 0; o[q] = 0; oo[q] = 0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = r0 + q;
+      if (r >= R) break;
+      const uint32_t nout = (cr[q] + 1) >> 1;
+      uint32_t* d = desc + plan.at[r];
+      for (uint32_t j = lane; j < nout; j += LPK) d[oo[q] + j] = (o[q] + 2 * j) | ((2 * j + 1 < cr[q]) ? DESC_PAIR : 0u);
+    }
   }
 }
 
