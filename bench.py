@@ -511,9 +511,14 @@ def main():
     w_eff = (sum(per_scalar(c, sg) * n for (c, _), (_, sg), n in zip(plans, tables, sizes)) / max(sum(sizes), 1)
              if all(c for c, _ in plans) else 12)
     # per addition: 5 products + 1 squaring (~0.13 product) + 1/B of a table-driven inversion (~15 product-equivalents);
-    # B is chosen on the device (25..48 in a first round; 36 is typical at this size)
-    per_add = 5.13 + 15.0 / 36.0
+    # B = slots per thread, chosen on the device so that a round is whole chip-fulls (msm.hip: aff_slots_per_thread): restated here
+    def aff_b(total_slots, cap=256 * 3 * 256, bmax=136, bmin=8):
+        units = max(1, -(-int(total_slots) // cap))
+        r = -(-units // bmax)
+        return max(bmin, -(-units // r))
     adds_per_launch = pairs_per_launch * w_eff * 0.5
+    shape_adds = [n * per_scalar(c, True) * 0.5 / n_shards for (c, _), n in zip(plans, sizes)] if all(c for c, _ in plans) else [adds_per_launch]
+    per_add = sum(a * (5.13 + 15.0 / aff_b(a)) for a in shape_adds) / max(sum(shape_adds), 1.0)
     mul_eq = adds_per_launch * per_add
     launch_s = acc_avg_ms * 1e-3
     mul_frac = (mul_eq / launch_s) / mul_rate if (acc_n and mul_rate) else None
@@ -555,8 +560,10 @@ def main():
             "frac": gather_frac,
         },
         "work_model": {
-            "note": "W/2 affine additions per (scalar, base) pair, each 5 products + 1 squaring + 1/B shared inversion ~ 5.55 product "
-                    "equivalents; ceiling = dvp_ubench_gf_mul measured in this run (Karatsuba LDS multiplier alone, same occupancy)",
+            "note": "W/2 affine additions per (scalar, base) pair, each 5 products + 1 squaring + 1/B of a shared inversion (B = slots per "
+                    "thread as the device picks them: 65 / 129 at 2^20 since the end of round 5, 33 / 43 before) = product_equivalents_per_addition; "
+                    "ceiling = dvp_ubench_gf_mul measured in this run (Karatsuba LDS multiplier alone, same occupancy)",
+            "product_equivalents_per_addition": per_add,
             "additions_per_launch": adds_per_launch,
             "mul_equivalents_per_launch": mul_eq,
             "achieved_mul_per_s": mul_eq / launch_s if acc_n else 0.0,
@@ -600,12 +607,16 @@ def main():
     later_launches = prof("msm_affine_rest")[1]
 
     def later_additions(pairs, c):  # rounds 1 .. : round r adds entries / 2^(r+1) pairs, and runs while that is >= 2^19 (Tune::msm_aff_min)
-        e, tot, r = pairs * per_scalar(c, True) / n_shards, 0.0, 1
+        e, tot, work, r = pairs * per_scalar(c, True) / n_shards, 0.0, 0.0, 1
         while e / 2 ** (r + 1) >= (1 << 19):
-            tot += e / 2 ** (r + 1)
+            a = e / 2 ** (r + 1)
+            tot += a
+            work += a * (5.13 + 15.0 / aff_b(a))  # product equivalents: the inversion is shared by the B slots of a thread
             r += 1
-        return tot
-    later_adds = sum(later_additions(n, c) for (c, _), n in zip(plans, sizes)) if all(c for c, _ in plans) else 0.0  # per proof
+        return tot, work
+    later = [later_additions(n, c) for (c, _), n in zip(plans, sizes)] if all(c for c, _ in plans) else []
+    later_adds = sum(a for a, _ in later)  # per proof
+    later_work = sum(w for _, w in later)
     later_s = rest_ms / args.steps * 1e-3
     roof["later_rounds"] = {
         "kernel": "dvp::k_affine_round<false> (pair rounds after the first: inputs are the previous round's outputs, read in slot order)",
@@ -616,9 +627,10 @@ def main():
                             "design reads each point twice and parks a 32-byte prefix product -- ~400 B per addition measured (by_round)",
         "achieved_gb_s": later_adds * 128.0 / later_s / 1e9 if later_s else None,
         "frac_of_hbm_peak": later_adds * 128.0 / later_s / 1e9 / 8000.0 if later_s else None,
-        "work_model_frac": (later_adds * (5.13 + 15.0 / 16.0) / later_s) / mul_rate if (mul_rate and later_s) else None,
-        "work_model_note": "5 products + 1 squaring + 1/B of an inversion per addition, B = 48 .. 8 slots per thread over the rounds (15/16 product-"
-                           "equivalents of inversion share on average), against dvp_ubench_gf_mul of this run",
+        "work_model_frac": (later_work / later_s) / mul_rate if (mul_rate and later_s) else None,
+        "product_equivalents_per_addition": later_work / later_adds if later_adds else None,
+        "work_model_note": "5 products + 1 squaring + 1/B of an inversion per addition, B = the slots per thread the device picks for each round "
+                           "(65 .. 8 over the rounds at 2^20), against dvp_ubench_gf_mul of this run",
     }
     if rounds_prof and log_m == 20 and n_shards == 1:
         roof["later_rounds"]["by_round"] = [

@@ -1172,7 +1172,7 @@ k_round_desc(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
 // grid is a whole number of chip-fulls: all threads of a round take the same time, so with a fixed B the last
 // partial wave of blocks ran on a mostly idle chip (2.2 chip-fulls cost 3: the first version averaged 64 % of its
 // 12 waves per CU).  With `cap` = resident threads of the chip, R = ceil(total / (cap * AFF_BMAX)) chip-fulls of
-// B = ceil(total / (cap * R)) slots each: B is 25..48 in the big rounds and shrinks to 1..8 in the last ones, where a
+// B = ceil(total / (cap * R)) slots each: B is 33..136 in the big rounds (25..48 through round 4) and shrinks to 1..8 in the last ones, where a
 // round is pure latency and short threads are what is wanted.
 // Round 4 (tools/wave_trace.py, profiles/r04_wave_trace_*): the instruction arbiter of a SIMD serves its OLDEST wave first.  Of
 // three resident waves with identical work the first finished after 1.32 ms, the second after 1.55, the third after 1.93; every
@@ -1193,7 +1193,11 @@ __device__ __forceinline__ void aff_set_prio(uint32_t v) {
     default: __builtin_amdgcn_s_setprio(2); break;
   }
 }
-constexpr uint32_t AFF_BMAX = 48;  // default (Tune::msm_aff_bmax)
+// default (Tune::msm_aff_bmax).  48 through round 4 (swept flat 32 .. 128 then); re-swept at the end of round 5, with the product 15 %
+// shorter: 48 / 64 / 68 / 72 / 136 / 255 -> 19.14 / 19.15 / 18.99 / 18.99 / 18.98 / 19.00 ms per 2^20 proof and 66.8 / - / - / 66.0 / 64.7-65.0 /
+// 65.0 ms at 2^22 -- from 68 the first round of the commitment MSM and the second of the K MSM are ONE chip-full of 65 slots per thread
+// instead of two of 33, from 130 the K MSM's first round is one of 129: fewer drains and a smaller inversion share
+constexpr uint32_t AFF_BMAX = 136;
 // bmax_bmin: bits 0..7 = most slots per thread, bits 8..15 = fewest (a small round then runs on fewer threads, each sharing its
 // inversion among more additions: Tune::msm_aff_bmin)
 __device__ __forceinline__ uint32_t aff_slots_per_thread(uint32_t total, uint32_t cap, uint32_t bmax_bmin) {
