@@ -512,7 +512,15 @@ def main():
              if all(c for c, _ in plans) else 12)
     # per addition: 5 products + 1 squaring (~0.13 product) + 1/B of a table-driven inversion (~15 product-equivalents);
     # B = slots per thread, chosen on the device so that a round is whole chip-fulls (msm.hip: aff_slots_per_thread): restated here
-    def aff_b(total_slots, cap=256 * 3 * 256, bmax=136, bmin=8):
+    def tune_get(name, dflt):
+        v = C.c_longlong(0)
+        try:
+            return int(v.value) if dvp.lib.dvp_tune_get(name.encode(), C.byref(v)) == 0 and v.value > 0 else dflt
+        except Exception:
+            return dflt
+    lib_bmax, lib_bmin = tune_get("DVP_MSM_AFF_BMAX", 136), tune_get("DVP_MSM_AFF_BMIN", 8)
+
+    def aff_b(total_slots, cap=256 * 3 * 256, bmax=lib_bmax, bmin=lib_bmin):
         units = max(1, -(-int(total_slots) // cap))
         r = -(-units // bmax)
         return max(bmin, -(-units // r))

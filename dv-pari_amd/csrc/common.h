@@ -76,7 +76,7 @@ struct Tune {
   long long cache_replicas = 1;  // DVP_CACHE_REPLICAS: provers dvp_prove_cache_dir may hold per cache_dir (1 = callers take turns on one prover, the default since the end of round 4: with the witness in host memory a second prover's latency chains land in the first one's pair rounds and two callers got 23.3-23.8 ms per proof where taking turns gives 21.2-21.4; 2 = a second one is opened when two callers overlap)
   long long msm_aff_tpb = 256;  // DVP_MSM_AFF_TPB: workgroup size of the pair rounds (64, 128 or 256)
   long long msm_aff_bmin = 8;   // DVP_MSM_AFF_BMIN: fewest slots a round thread owns (small rounds then use fewer threads, each sharing its inversion among more additions)
-  long long msm_aff_bmax = 48;  // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns
+  long long msm_aff_bmax = 136; // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns (48 through round 4; msm.hip: AFF_BMAX)
   long long ecfft_radix4 = 3;   // DVP_ECFFT_RADIX4: the unfused top of an extend: 3 = up to nine layers in ONE LDS-tiled launch (k_extend_top; what is above them as under 2), 2 = three layers per pass (k_butterfly8, then k_butterfly4 / k_butterfly for what is left), 1 = two, 0 = one
   long long msm_accum_quad_max = 0;    // DVP_MSM_ACCUM_QUAD_MAX: reducer launches with at most this many tasks (upper bound) use a quad of lanes per task (0 = default)
   long long msm_bucket_pairs_max = 12;  // DVP_MSM_BUCKET_PAIRS_MAX: what the pair rounds leave goes through k_bucket_pairs / k_bucket_rest (one thread per bucket) when no bucket holds more points than this; above it, and with 0, through the fan-in-K reducer
