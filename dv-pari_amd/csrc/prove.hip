@@ -1,13 +1,13 @@
 // Proof::prove on gfx950 -- the orchestration of src/proving.rs:426-688 with every vector stage on
-// the device and only the BLAKE3 transcript (src/proving.rs:79-198) and the 118-byte proof assembly on
-// the host.  Stage map (reference line -> kernel):
+// the device; since round 5 the BLAKE3 transcript (src/proving.rs:79-198) runs there too (k_transcript; the host
+// flavour stays behind DVP_PROVE_HOST_TRANSCRIPT) and the host only assembles the 118 bytes.  Stage map (reference line -> kernel):
 //   get_matrix_evaluations_from_witness   :348-403  -> k_r1cs_eval  (CSR rows, one thread per row; the
 //                                                      Vandermonde fold C' = C - D is applied on the fly)
 //   multi_scalar_mul(assignment, g_m)     :462-463  \  one MSM over [w | q2] x [g_m | g_q]
 //   multi_scalar_mul(q_vals2, g_q)        :511-512  /  (commit_p = msm_q + msm_gm, :515)
 //   extend_evals                          :410-422  -> dvp_ecfft batched extend (4 vectors)
 //   r_vals2 / q_vals2                     :492-508  -> k_quotient
-//   transcript -> alpha                   :517-558  -> host BLAKE3 + k_alpha_denoms (domain check)
+//   transcript -> alpha                   :517-558  -> k_transcript (or host BLAKE3) + k_alpha_denoms (domain check)
 //   barycentric evaluations a0,b0,i0      :561-594  -> k_bary3_partial / k_bary3_final
 //     (Z(alpha) comes from the isogeny chain instead of a Horner pass over z_poly)
 //   denom_invs, denom_invs2               :599-616  -> k_alpha_denoms + batch inverse
