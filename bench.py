@@ -45,7 +45,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
+LINE_LIMIT = 6000  # the driver keeps an 8 126-character tail of stdout: the ONE line must fit with room to spare
 LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE",
                  "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
                  "TORCHELASTIC_USE_AGENT_STORE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCHELASTIC_ERROR_FILE", "OMP_NUM_THREADS")
@@ -81,7 +82,7 @@ def cpu_mhz() -> float:
 
 
 def load_profile(name):
-    for tag in (PROFILE_TAG, "r04", "r03"):
+    for tag in (PROFILE_TAG, "r05", "r04", "r03"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{name}.json")))
             d["_profile_tag"] = tag
@@ -100,6 +101,93 @@ def last_json_line(text):
             except Exception:
                 pass
     return None
+
+
+def _sig(x, digits=6):
+    """floats to `digits` significant digits, recursively (the line is data: 17-digit floats are noise that costs bytes)"""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def headline(full, detail_path=None):
+    """The ONE line the driver parses: the contract's keys first, then short numeric extras.  Everything else this run measured
+    (per-round tables, both models' inputs, the CPU baseline's stages, shard plans) is in the sidecar `detail` names."""
+    roof = full.get("roofline") or {}
+    wm, gm, lr = roof.get("work_model") or {}, roof.get("gather_model") or {}, roof.get("later_rounds") or {}
+    cfg = full.get("config") or {}
+    cpu = full.get("cpu_baseline")
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["config"] = _pick(cfg, ("workload", "log2_constraints", "n_wires", "msm_pairs_per_proof", "witness", "entry", "proofs_in_flight",
+                                "ms_per_step_one_shot_msm", "cold_call_s"))
+    if isinstance(cfg.get("sharding"), str):
+        out["config"]["sharding"] = cfg["sharding"][:120]
+    out["roofline"] = {"kernel": str(roof.get("kernel", ""))[:64], "bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"),
+                       "unit": roof.get("unit"), "frac": roof.get("frac"), "traffic": roof.get("traffic"),
+                       "avg_launch_ms": roof.get("avg_launch_ms"), "launches": roof.get("launches"),
+                       "algorithmic_bytes_per_launch": roof.get("algorithmic_bytes_per_launch"), "limiter": roof.get("limiter"),
+                       "work_model_frac": wm.get("frac"), "gather_model_frac": gm.get("frac"),
+                       "later_rounds": _pick(lr, ("ms_per_step", "launches_per_step", "achieved_gb_s", "frac_of_hbm_peak", "work_model_frac"))}
+    if roof.get("per_msm"):
+        out["roofline"]["per_msm"] = [_pick(p_, ("pairs", "avg_launch_ms", "frac", "work_model_frac")) for p_ in roof["per_msm"]]
+    if cpu:
+        out["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "kind", "end_to_end_s", "composed_value", "msm_points_per_s",
+                                          "best_cpu_pippenger_constraints_per_s"))
+        out["cpu_baseline"]["sample"] = str(cpu.get("sample", ""))[:400]
+    out["stages_ms_per_step"] = full.get("stages_ms_per_step")
+    if full.get("msm_standalone"):
+        out["msm_standalone"] = full["msm_standalone"]
+    by = {}
+    for name, d in (full.get("roofline_by_config") or {}).items():
+        if name.startswith("config_2"):
+            by[name] = _pick(d, ("ms", "achieved_gb_s", "frac_of_hbm_peak"))
+        elif name.startswith("config_3"):
+            by[name] = {op: _pick(d[op], ("ms", "frac_of_hbm_peak", "work_model_frac")) for op in ("enter", "exit", "extend_x4") if op in d}
+            by[name]["round_trip_exact"] = d.get("round_trip_exact")
+        elif name.startswith("config_4"):
+            by[name] = _pick(d, ("ms_per_step", "achieved_gb_s", "frac_of_hbm_peak"))
+            if "extends" in d:
+                by[name]["extends"] = _pick(d["extends"], ("ms_per_step", "frac_of_hbm_peak", "work_model_frac"))
+    if by:
+        out["roofline_by_config"] = by
+    out.update(_pick(full, ("hbm_resident_gb", "tables_gb", "ms_per_step_host_witness", "msm_mpoints_per_s", "host_waits_per_proof", "scaling_measured",
+                            "rccl_ranks", "backend", "ms_per_step_ranks", "ms_per_step_inproc", "inproc_error", "replicas")))
+    tif = full.get("throughput_two_in_flight")
+    if isinstance(tif, dict) and "constraints_per_s" in tif:
+        out["throughput_two_in_flight"] = _pick(tif, ("ms_per_proof", "constraints_per_s"))
+    if full.get("profiles"):
+        out["profiles"] = _pick(full["profiles"], ("tag", "sources_match"))
+    out["detail"] = detail_path
+    return _sig(out)
+
+
+def write_detail(full):
+    """the sidecar: everything the run measured, as one JSON document.  profiles/<tag>_bench_detail.json is the committed copy (written
+    when the tree is writable: the builder's runs), gpurun_out/bench_detail.json travels back from a GPU box"""
+    name = None
+    single = full.get("n_gpus") == 1 and (full.get("config") or {}).get("log2_constraints") == 20
+    suffix = "" if full.get("n_gpus") == 1 else f"_n{full.get('n_gpus')}" + ("_inproc" if "in-library" in str((full.get("config") or {}).get("sharding")) else "")
+    targets = [os.path.join(ROOT, "gpurun_out", f"bench_detail{suffix}.json")]
+    if single and os.environ.get("DVP_BENCH_WRITE_PROFILE") == "1":
+        targets.append(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_bench_detail.json"))
+    for path in targets:
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(full, f, indent=1)
+            name = os.path.relpath(path, ROOT)
+        except OSError as ex:
+            log(f"[bench] could not write {path}: {ex}")
+    return name
 
 
 def launch_ranks(args):
@@ -154,7 +242,12 @@ def main():
     ap.add_argument("--log-m", type=int, default=20, help="log2 of the number of constraints (default 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs after the timed loop (microbenchmarks, stand-alone MSMs, second table flavour)")
+    ap.add_argument("--extras", choices=("all", "ubench", "none"), default="all", help="ubench: only the two multiplier / gather microbenchmarks "
+                    "(what a counter pass under rocprofv3 --pmc needs: no child process, no extra proofs)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--replicas", action="store_true", help="N > 1: every rank proves its OWN proofs (N independent provers, no data-path collective); "
+                    "`value` is then the aggregate constraints/s of the N replicas (weak scaling).  Without the flag the two MSMs of ONE proof are sharded "
+                    "over the ranks (strong scaling, the default: BASELINE config #4) and the replicas figure is measured after the timed loop")
     ap.add_argument("--inproc", action="store_true", help="one process, in-library multi-GPU over devices 0..gpus-1 (dvp_set_devices)")
     ap.add_argument("--in-flight", type=int, default=2, help="2 (default): the extras leg after the timed loop also measures throughput with two proofs in flight "
                     "(throughput_two_in_flight); 1 skips it.  `value` is always one proof at a time")
@@ -218,12 +311,14 @@ def main():
         # one GPU: Proof::prove itself (dvp_prove_dev: the drop-in entry with the witness resident; rounds 1-4 timed the PHASED entries
         # here -- begin / msm_partial / challenge / msm_partial / finish, what a rank of a sharded proof calls -- which wait for the
         # host five times per proof where dvp_prove_dev waits once); N ranks: the phased entries with the MSMs sharded
-        if args.inproc or world == 1:
+        if args.inproc or world == 1 or args.replicas:
             return pv.prove_dev(assignment.data_ptr(), stream)
         return dvp.distributed.prove_sharded(gpu_backend, assignment, plan_costs=plan_costs)
 
     plan_costs = None
-    if world > 1:  # communicator set-up is not part of a proof: one throw-away exchange even with --warmup 0
+    if world > 1 and args.replicas:
+        dvp.distributed.probe_collectives(dev)
+    elif world > 1:  # communicator set-up is not part of a proof: one throw-away exchange even with --warmup 0
         dvp.distributed.probe_collectives(dev)
         # what the shard plan charges an extender rank is MEASURED here (one timed extend, one timed broadcast of an m-vector, one timed
         # MSM slice; max over ranks) instead of typed in: the plan adapts to the real xGMI cost of the vector exchange
@@ -255,6 +350,9 @@ def main():
         elapsed = max(float(x[0].item()) for x in allt)
         rank_ms = [float(x[1].item()) / args.steps * 1e3 for x in allt]
         dist_info = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+    if world > 1 and args.replicas:
+        dist_info["replicas"] = {"n": world, "constraints_per_s": m * args.steps * world / elapsed, "ms_per_proof_each": rank_ms}
+    elif world > 1:
         # every rank's own stage times (HIP events of its own launches) and its slice of the plan, so that a bad plan shows in one run
         mine = {"rank": rank}
         for nm in ("msm_total", "msm_sort", "msm_affine_round0", "msm_affine_rest", "msm_tail", "extend_total"):
@@ -291,6 +389,27 @@ def main():
     hbm_resident_gb = (total_b - free_b) / 1e9
 
     ms_inproc, inproc_err = None, None
+    if world > 1 and not args.replicas:
+        # the OTHER way to use N GPUs (what DESIGN 7 recommends for throughput): N independent provers, one per rank, no data-path
+        # collective -- measured here, outside the timed loop, between two barriers; max over ranks
+        if os.environ.get("DVP_BENCH_NO_REPLICAS") != "1":
+            own_proof = pv.prove_dev(assignment.data_ptr(), stream)  # rebuilds this rank's full fixed-base tables (untimed)
+            assert own_proof == proof, "a rank's own proof differs from the sharded one"
+            k_rep = max(2, min(args.steps, 10))
+            dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k_rep):
+                pv.prove_dev(assignment.data_ptr(), stream)
+            torch.cuda.synchronize()
+            own_rep = time.perf_counter() - t1
+            dist.barrier()
+            t = torch.tensor([time.perf_counter() - t1, own_rep], dtype=torch.float64, device=dev)
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            rep_elapsed = max(float(x[0].item()) for x in allt)
+            dist_info["replicas"] = {"n": world, "proofs_each": k_rep, "constraints_per_s": m * k_rep * world / rep_elapsed,
+                                     "ms_per_proof_each": [float(x[1].item()) / k_rep * 1e3 for x in allt]}
     if world > 1:
         # release this rank's GPU before the in-library measurement: every rank drops its prover and leaves the group
         del gpu_backend
@@ -302,7 +421,7 @@ def main():
         dvp.distributed.forget_groups()
         if rank != 0:
             return
-        if os.environ.get("DVP_BENCH_NO_INPROC") != "1":
+        if os.environ.get("DVP_BENCH_NO_INPROC") != "1" and not args.replicas:
             time.sleep(1.0)  # the other ranks are exiting: their HBM comes back with their processes
             ms_inproc, inproc_err = run_inproc_child(args, share_gpu)
             if inproc_err:
@@ -310,21 +429,36 @@ def main():
 
     # correctness of what was timed: the proof must verify
     assert dvp.srs.verify(td, pub, proof), "bench proof does not verify"
-    n_shards = world * n_dev_inproc
+    n_shards = (1 if args.replicas else world) * n_dev_inproc
     ms_per_step = elapsed / args.steps * 1e3
-    value = m * args.steps / elapsed
+    value = m * args.steps / elapsed * (world if (args.replicas and world > 1) else 1)
     single = world == 1 and n_dev_inproc == 1
     # `value` / `ms_per_step` are ONE PROOF AT A TIME: the quantity BASELINE's metric measures (the reference's prove() is one proof
     # per call), and the loop that stages_ms_per_step, the roofline block and every committed profile describe.  Throughput with
     # two proofs in flight is an extra, measured after the timed loop and reported under its own key (throughput_two_in_flight).
     n_in_flight = 1
-    extras = single and not args.no_extras
+    extras = single and not args.no_extras and args.extras != "none"
+    heavy = extras and args.extras == "all"  # the legs that run further proofs / MSMs / a child process
 
     # ---- outside the timed region ---------------------------------------------------------------------------------------
     host_ms = mul_rate = gather_rate = fr_rate = ms_one_shot = cold = ecfft_live = None
     msm_standalone = None
     in_flight = None
     if extras:
+        # the two ceilings of the dominant kernel: the multiplier alone, and random 64-byte gathers out of the table the
+        # K-MSM's first pair round reads (the larger of the two tables)
+        r = C.c_double(0)
+        dvp.check(dvp.lib.dvp_ubench_gf_mul(200, C.byref(r)), "dvp_ubench_gf_mul")
+        mul_rate = r.value
+        tp, tb = C.c_void_p(0), C.c_uint64(0)
+        dvp.check(dvp.lib.dvp_prover_msm_table_ptr(pv._h, 1, C.byref(tp), C.byref(tb)), "dvp_prover_msm_table_ptr")
+        if tp.value and tb.value >= (1 << 20):
+            dvp.check(dvp.lib.dvp_ubench_gather(tp, tb.value, 4, C.byref(r)), "dvp_ubench_gather")
+            gather_rate = r.value
+        # the ECFFT's multiplier alone (ceiling of the work model of extend / enter / exit)
+        dvp.check(dvp.lib.dvp_ubench_fr_mul(400, C.byref(r)), "dvp_ubench_fr_mul")
+        fr_rate = r.value
+    if heavy:
         # the same proof through the host-pointer seam (dvp_prove = Proof::prove's signature, src/proving.rs:426: witness in
         # host memory, +32 B/wire of H2D)
         pv.prove(pub, prv)
@@ -339,16 +473,6 @@ def main():
         # which says nothing about the seam
         host_ms = sorted(host_times)[len(host_times) // 2]
         assert p2 == proof
-        # the two ceilings of the dominant kernel: the multiplier alone, and random 64-byte gathers out of the table the
-        # K-MSM's first pair round reads (the larger of the two tables)
-        r = C.c_double(0)
-        dvp.check(dvp.lib.dvp_ubench_gf_mul(200, C.byref(r)), "dvp_ubench_gf_mul")
-        mul_rate = r.value
-        tp, tb = C.c_void_p(0), C.c_uint64(0)
-        dvp.check(dvp.lib.dvp_prover_msm_table_ptr(pv._h, 1, C.byref(tp), C.byref(tb)), "dvp_prover_msm_table_ptr")
-        if tp.value and tb.value >= (1 << 20):
-            dvp.check(dvp.lib.dvp_ubench_gather(tp, tb.value, 4, C.byref(r)), "dvp_ubench_gather")
-            gather_rate = r.value
         # BASELINE metric, second half: stand-alone one-shot MSM (multi_scalar_mul, src/curve.rs:141-158; no pre-rotated
         # tables), device-resident random scalars x real SRS bases; config #2 is the 2^16 case
         if log_m >= 18:
@@ -376,9 +500,6 @@ def main():
                         best = dt
                 msm_standalone[f"2^{lg}"] = {"ms": best * 1e3, "mpoints_per_s": n_pts / best / 1e6}
             del d_bases, d_sc
-        # the ECFFT's multiplier alone (ceiling of the work model of extend / enter / exit)
-        dvp.check(dvp.lib.dvp_ubench_fr_mul(400, C.byref(r)), "dvp_ubench_fr_mul")
-        fr_rate = r.value
         # BASELINE config #3, live: 2^20-coefficient enter / exit round trip and the prover's own op, extend (x4 vectors, m = 2^20)
         if log_m >= 20:
             n3 = 1 << 20
@@ -435,7 +556,8 @@ def main():
                 dvp.check(dvp.lib.dvp_setup_cache_dir(nat.ptr(t_), nat.ptr(d_), nat.ptr(e_), os.fsencode(tmp), len(pub), 0), "dvp_setup_cache_dir")
                 setup_s = time.perf_counter() - t1
                 np.save(os.path.join(tmp, "witness.npy"), w_host)
-                env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+                # not a second profiled process: a profiler's preload would make the child collect counters while this one holds the GPU
+                env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS and k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF"))}
                 rr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_call.py"), tmp, os.path.join(tmp, "witness.npy"), str(len(pub))],
                                     capture_output=True, text=True, env=env, timeout=240)
                 lines = [l for l in rr.stdout.splitlines() if l.startswith("{")]
@@ -493,8 +615,7 @@ def main():
                 free_b3, total_b3 = torch.cuda.mem_get_info(dev)
                 in_flight = {"provers": 2, "proofs": 2 * k_each, "ms_per_proof": dt2 / (2 * k_each) * 1e3,
                              "constraints_per_s": m * 2 * k_each / dt2, "hbm_resident_gb": (total_b3 - free_b3) / 1e9,
-                             "note": "two provers on two host threads and two streams of this GPU, started together; aggregate over both; "
-                                     "each proof's own latency is about twice ms_per_proof"}
+                             }
             finally:
                 pv_b.close()
 
@@ -540,15 +661,9 @@ def main():
     else:
         limiter = None
     roof = {
-        "kernel": "dvp::k_affine_round<true> (first pair round of each MSM; the later rounds are k_affine_round<false>)",
+        "kernel": "dvp::k_affine_round<true>",
         "bound": bound,
         "limiter": limiter,
-        "bound_note": "achieved / peak / frac is the algorithmic-bytes figure against the HBM streaming peak that the metric contract asks for "
-                      "(tiny by construction: 96 B per pair); what binds the kernel is `limiter`, the larger of work_model.frac (GF(2^233) "
-                      "products on the integer VALU + LDS against the multiplier microbenchmark) and gather_model.frac (random 64-byte "
-                      "point reads against the gather microbenchmark on the same table), both ceilings measured in this run.  With the "
-                      "default 3-5 GB tables the gathers sit at about a third of their ceiling and the kernel is product-bound at the "
-                      "clock the chip holds under this load (issue.effective_clock_ghz against the microbenchmark's)",
         "achieved": achieved,
         "peak": 8000.0,
         "unit": "GB/s",
@@ -558,9 +673,6 @@ def main():
         "avg_launch_ms": acc_avg_ms,
         "algorithmic_bytes_per_launch": alg_bytes,
         "gather_model": {
-            "note": "an affine pair addition reads both operands (64-byte points at random table positions) in pass 1 (x for the shared "
-                    "inversion's running product) and again in pass 2 (x, y for the chord): 4 line gathers per addition; ceiling = "
-                    "dvp_ubench_gather on the K-MSM's own table, every CU busy, measured in this run",
             "gathers_per_launch": gathers,
             "achieved_gathers_per_s": gathers / launch_s if acc_n else 0.0,
             "ceiling_gathers_per_s": gather_rate,
@@ -568,9 +680,6 @@ def main():
             "frac": gather_frac,
         },
         "work_model": {
-            "note": "W/2 affine additions per (scalar, base) pair, each 5 products + 1 squaring + 1/B of a shared inversion (B = slots per "
-                    "thread as the device picks them: 65 / 129 at 2^20 since the end of round 5, 33 / 43 before) = product_equivalents_per_addition; "
-                    "ceiling = dvp_ubench_gf_mul measured in this run (Karatsuba LDS multiplier alone, same occupancy)",
             "product_equivalents_per_addition": per_add,
             "additions_per_launch": adds_per_launch,
             "mul_equivalents_per_launch": mul_eq,
@@ -603,7 +712,7 @@ def main():
             "fetch_x2_bytes_per_launch": traffic["traffic_bytes_per_launch_fetch_x2"],
             "ratio_to_algorithmic": roof["traffic"] / alg_bytes,
         }
-        for k in ("tcc_requests", "reading"):
+        for k in ("tcc_requests",):
             if k in traffic:
                 roof["traffic_detail"][k] = traffic[k]
     sq = load_profile("pmc_sq_k_affine_round0")
@@ -627,18 +736,14 @@ def main():
     later_work = sum(w for _, w in later)
     later_s = rest_ms / args.steps * 1e-3
     roof["later_rounds"] = {
-        "kernel": "dvp::k_affine_round<false> (pair rounds after the first: inputs are the previous round's outputs, read in slot order)",
+        "kernel": "dvp::k_affine_round<false>",
         "ms_per_step": rest_ms / args.steps, "launches_per_step": later_launches / args.steps,
         "additions_per_step": later_adds,
         "algorithmic_bytes_per_addition": 128.0,
-        "algorithmic_note": "a later round reads two 64-byte points per addition (and writes one): 128 B read is the figure used; the shared-inversion "
-                            "design reads each point twice and parks a 32-byte prefix product -- ~400 B per addition measured (by_round)",
         "achieved_gb_s": later_adds * 128.0 / later_s / 1e9 if later_s else None,
         "frac_of_hbm_peak": later_adds * 128.0 / later_s / 1e9 / 8000.0 if later_s else None,
         "work_model_frac": (later_work / later_s) / mul_rate if (mul_rate and later_s) else None,
         "product_equivalents_per_addition": later_work / later_adds if later_adds else None,
-        "work_model_note": "5 products + 1 squaring + 1/B of an inversion per addition, B = the slots per thread the device picks for each round "
-                           "(65 .. 8 over the rounds at 2^20), against dvp_ubench_gf_mul of this run",
     }
     if rounds_prof and log_m == 20 and n_shards == 1:
         roof["later_rounds"]["by_round"] = [
@@ -647,12 +752,10 @@ def main():
                                                          "valu_insts_per_simd_cycle", "resident_wave_frac", "valu_insts_per_addition")}}
             for msm in rounds_prof["msms"] for r in msm["rounds"]]
         roof["later_rounds"]["by_round_source"] = f"profiles/{rounds_prof['_profile_tag']}_pmc_pair_rounds_by_round.json (committed rocprofv3 --pmc passes; not measured in this run)"
-        roof["later_rounds"]["reading"] = rounds_prof.get("reading")
     g64 = load_profile("gather64_load_forms")
     if g64:
         roof["request_size_experiment"] = {"source": f"profiles/{g64['_profile_tag']}_gather64_load_forms.json (tools/ubench/gather64.hip under rocprofv3 --pmc)",
-                                           "fabric_read_bytes_per_64_byte_point": {v["variant"]: round(v["fabric_read_bytes_per_point"], 1) for v in g64["variants"]},
-                                           "reading": g64["reading"]}
+                                           "fabric_read_bytes_per_64_byte_point": {v["variant"]: round(v["fabric_read_bytes_per_point"], 1) for v in g64["variants"]}}
     out = {
         "metric": "R1CS constraints/sec (prove)",
         "value": value,
@@ -662,7 +765,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if (args.replicas and world > 1) else "strong",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
@@ -673,35 +776,26 @@ def main():
             "msm_pairs_per_proof": inst.n_wires + 5 * m,
             "sharding": ("in-library (dvp_set_devices): MSM index ranges per device, one host thread each, partial points added on device 0"
                          if n_dev_inproc > 1 else
+                         "independent replicas: one whole proof per rank per step, no data-path collective" if (args.replicas and world > 1) else
                          "MSM index ranges per rank, all-gather of partial points + local add; extends by vector among the ranks that need q2 / r2 "
                          "(from three such ranks up: one broadcast per vector); challenge "
                          "phase (inversions, barycentric sums, K scalars) by index with one all-gather of 128-byte records" if world > 1 else "single GPU"),
             "msm_windows": {"commit_msm": {"c_bits": plans[0][0], "windows": plans[0][1], "signed_windows": tables[0][1], "table_gb": round(tables[0][0] / 1e9, 2)},
                             "k_msm": {"c_bits": plans[1][0], "windows": plans[1][1], "signed_windows": tables[1][1], "table_gb": round(tables[1][0] / 1e9, 2)}},
             "witness": "resident in HBM",
-            "entry": "dvp_prove_dev (Proof::prove with the witness resident)" if (args.inproc or world == 1) else "phased entries, MSMs sharded over the ranks",
+            "entry": "dvp_prove_dev (Proof::prove with the witness resident)" if (args.inproc or world == 1 or args.replicas) else "phased entries, MSMs sharded over the ranks",
             "proofs_in_flight": 1,
             "latency_ms_one_proof": ms_per_step,
             "ms_per_step_one_shot_msm": ms_one_shot,
-            "ms_per_step_one_shot_msm_note": "the same proof with the fixed-base tables switched off (DVP_MSM_FIXED_MIN): one-shot MSMs over the decoded bases",
             "cold_call_s": (cold or {}).get("cold_call_s"),
             "cold_call": cold,
-            "cold_call_note": "first dvp_prove_cache_dir(cache_dir, public, private) of a FRESH process (tools/cold_call.py) on a directory written in this run "
-                              "with the same trapdoor: R1CS dump + five SRS point files read (page cache), 6 m points decoded on the GPU, both fixed-base tables "
-                              "built, one proof, bytes compared with the timed loop's; second_call_s is the same call again",
             "constraints_per_s_two_in_flight": (in_flight or {}).get("constraints_per_s"),
         },
         "hbm_resident_gb": hbm_resident_gb,
-        "hbm_resident_note": "device memory in use on this rank's GPU after the timed loops (every prover in flight: tables, bases, MSM workspaces, trees; the torch context)",
         "tables_gb": round((tables[0][0] + tables[1][0]) / 1e9, 2),
-        "tables_note": "fixed-base tables: aligned windows of signed binary digits, W rows 2^(o_w) P per base (the sliding-window flavours of "
-                       "rounds 2-3, 94-97 GB at this size for the same proof time, were removed in round 4)",
         "ms_per_step_host_witness": host_ms,
         "throughput_two_in_flight": in_flight,
         "host_waits_per_proof": host_waits,
-        "host_waits_note": "stream = synchronisations of the proof's own stream (the GPU idles until the host has reacted): ONE per proof since round 5, the "
-                           "K MSM's final one, which brings [a0 b0 i0 r0 | flags | both encodings | alpha] along -- the transcript (BLAKE3, Z(alpha)) runs on "
-                           "the device; side_stream = an MSM's read of its largest bucket, taken on a side stream while its first pair round runs",
         "roofline": roof,
         "stages_ms_per_step": {
             "msm_total": msm_ms / args.steps,
@@ -737,9 +831,6 @@ def main():
                           "frac_of_hbm_peak": x4_b / (ecfft_live["extend_x4_ms"] * 1e-3) / 1e9 / 8000.0,
                           "work_model_frac": (x4_w / (ecfft_live["extend_x4_ms"] * 1e-3)) / fr_rate if fr_rate else None},
             "round_trip_exact": ecfft_live["round_trip_exact"],
-            "bytes_note": "SURVEY 8d: extend(m) = 64 m per vector + 256 m of butterfly constants; enter(n) = log2(n) x 320 n, exit(n) = twice that",
-            "work_note": "multiply-adds r = a b / R' + c on 30-bit limbs (2 per butterfly) against dvp_ubench_fr_mul of this run: the ECFFT is bound by the half-rate "
-                         "v_mad_u64_u32, not by HBM",
             "fr_multiplier_muladds_per_s": fr_rate, "profile": f"profiles/{PROFILE_TAG}_config3_ecfft_2p20_kernel_stats.csv"}
     if ext_ms and fr_rate:
         n_ext_v = 3
@@ -770,8 +861,6 @@ def main():
     except Exception as ex:
         out["profiles"] = {"tag": PROFILE_TAG, "warning": f"no profile stamp: {ex!r}"[:200]}
     out["scaling_measured"] = bool(world > 1 or n_dev_inproc > 1)
-    if not out["scaling_measured"]:
-        out["scaling_note"] = "one GPU: no multi-GPU figure is part of this line (python bench.py --gpus N shards both MSMs over N ranks; the builder's boxes have one GPU)"
     if dist_info:
         out.update(dist_info)
         out["ms_per_step_ranks"] = rank_ms
@@ -904,34 +993,26 @@ def main():
             "cpu_affinity_mask": mask,
             "cgroup_cpu_quota": quota,
             "kind": "port",
-            "sample": (f"ONE real CPU Proof::prove of the 2^{log_m}-constraint instance on {cores} threads: {at_size['end_to_end_s']:.2f} s, its 118 bytes equal "
-                       f"the GPU prover's (stages in end_to_end[-1].stages_s).  Cross-check by composition -- " if at_size else "")
-                      + f"{n_s}-point reference-shaped MSM (one width-5 tau-NAF scalar multiplication per point + add tree, oracle/dvp_oracle.c) in "
-                      f"{dt:.1f}s = {pts_per_s:.0f} points/s on {cores} threads = {us_core:.1f} us*core per point"
-                      + (f" (~{us_core * mhz / 1e3:.0f} k cycles at {mhz:.0f} MHz; xs233's own xsk233_mul_frob is quoted at ~29.6 k cycles, so the "
-                         f"reference's C library would be ~{us_core * mhz / 1e3 / 29.6:.1f}x faster than this port)" if mhz else "")
-                      + f"; a proof needs {pts_per_constraint:.2f} point multiplications per constraint = {msm_s_per_proof:.2f}s; plus the four "
-                      f"extends as {passes} butterfly passes over 2^{ext_n.bit_length() - 1} elements in 4x64-bit Montgomery arithmetic "
-                      f"({ns_per_frmul:.0f} ns*core per Fr product) scaled to 2^{log_m} = {ext_s_per_proof:.2f}s per proof; plus the pointwise stages (quotient, three barycentric "
-                      f"evaluations with their batch inversions, K scalars) run on 2^{pw_n.bit_length() - 1} elements and scaled = {pointwise_s_per_proof:.3f}s",
+            "sample": ((f"one real CPU Proof::prove at 2^{log_m} on {cores} threads: {at_size['end_to_end_s']:.2f} s, its 118 bytes equal the GPU proof's; "
+                        if at_size else "") +
+                       f"composition cross-check: {n_s}-point per-point-scalar-mul MSM in {dt:.1f} s ({us_core:.1f} us*core/point) -> {msm_s_per_proof:.2f} s, "
+                       f"extends {ext_s_per_proof:.2f} s, pointwise {pointwise_s_per_proof:.3f} s per proof"),
+            "cpu_mhz": mhz,
+            "msm_sample_points": n_s, "msm_sample_s": dt, "pippenger_sample_points": n_p,
             "end_to_end_s": e2e_runs[-1]["end_to_end_s"],
             "end_to_end": e2e_runs,
-            "end_to_end_note": "a REAL Proof::prove on the host cores (oracle/dvp_oracle.c: sequential R1CS mat-vec and barycentric loops as in the "
-                               "reference, threaded extends / pointwise maps / batch inversions / per-point scalar multiplications), inputs = the "
-                               "cache_dir tables and decoded SRS of a GPU setup at that size; its 118 proof bytes are compared with the GPU "
-                               "prover's.  Since round 5 one of the runs is AT THE BENCH SIZE and `value` is its constraints per second; `composed_value` "
-                               "(bounded samples scaled up, rounds 1-4's headline) stays as the cross-check: measured_over_composed says how well it predicts",
             "msm_points_per_s": pts_per_s,
             "msm_us_core_per_point": us_core,
             "extend_s_per_proof": ext_s_per_proof,
             "pointwise_s_per_proof": pointwise_s_per_proof,
             "best_cpu_pippenger_points_per_s": pip_pts_per_s,
             "best_cpu_pippenger_constraints_per_s": m / ((inst.n_wires + 5 * m) / pip_pts_per_s + ext_s_per_proof + pointwise_s_per_proof),
-            "best_cpu_note": f"host bucket method (tau-adic windows, per-thread bucket sets, oracle/dvp_oracle.c: dvo_msm_pippenger) on {n_p} points",
             "openssl_ec_point_mul_points_per_s": ossl,
-            "openssl_note": "OpenSSL 3 EC_POINT_mul on sect233k1, one per point + EC_POINT_add (the reference's MSM shape on a third-party library)",
         }
-    print(json.dumps(out), flush=True)
+    detail_path = write_detail(out)
+    line = json.dumps(headline(out, detail_path))
+    assert len(line) < LINE_LIMIT, f"bench line is {len(line)} characters (limit {LINE_LIMIT}): move keys to the sidecar"
+    print(line, flush=True)
 
 
 if __name__ == "__main__":

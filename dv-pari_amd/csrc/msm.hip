@@ -1692,6 +1692,10 @@ struct MsmWorkspace {
     int dev;
     DVP_HIP(hipGetDevice(&dev));
     if (p && (dev != device || bytes < need)) {
+      // a deferred MSM's kernels may still be running in this allocation (the first proof: the K MSM is larger than the commitment
+      // MSM in flight): wait for them explicitly rather than lean on hipFree's implicit device-wide synchronisation
+      // (busy_valid was already consumed by the caller's hipStreamWaitEvent: the event itself is what says whether they ended)
+      if (ev_busy) (void)hipEventSynchronize(ev_busy);
       (void)hipFree(p);
       p = nullptr;
       bytes = 0;

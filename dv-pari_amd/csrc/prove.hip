@@ -1391,13 +1391,31 @@ static int prove_dev_device_transcript(dvp_prover* p, const void* d_assignment, 
   ProfScope ps(PROF_PROVE_TOTAL, st);
   DVP_TRY(prove_begin_impl(p, d_assignment, 1, stream, true, /*pub_to_host=*/false));
   DVP_TRY(prover_msm_partial(p, 0, 0, dvp_prover_msm_size(p, 0), p->pts, p->pts_inf32, p->enc, stream, p->msm_err));
-  DVP_TRY(challenge_dev(p, st));
+  // from here on the commitment MSM is in flight on `st` and in its workspace: every error return below drains the stream first
+  {
+    const int rc_c = challenge_dev(p, st);
+    if (rc_c != DVP_OK) {
+      (void)hipStreamSynchronize(st);
+      return rc_c;
+    }
+  }
+  // the block in pinned host memory still holds the PREVIOUS proof's words: mark the flags so that a K MSM which returns before its
+  // copy (plan limits, an allocation failure) is not mistaken for one that brought this proof's block along
+  constexpr unsigned long long FIN_STALE = ~0ull - 1;  // the device writes ~0 (fine) or an index < 2^32
+  {
+    const unsigned long long stale[2] = {FIN_STALE, FIN_STALE};
+    memcpy(p->fin_host + FIN_OFF_FLAGS, stale, 16);
+  }
   const int rc_k = prover_msm_partial(p, 1, 0, dvp_prover_msm_size(p, 1), p->pts + 1, p->pts_inf32 + 1, p->enc + 30, stream);
   ps.stop();
-  if (rc_k == DVP_EHIP) return rc_k;  // nothing was brought to the host
   const int64_t k_idx = g_last_error_index;
   unsigned long long f[2], e0;
   memcpy(f, p->fin_host + FIN_OFF_FLAGS, 16);
+  if (f[0] == FIN_STALE || f[1] == FIN_STALE) {  // nothing was brought to the host
+    (void)hipStreamSynchronize(st);
+    g_last_error_index = k_idx;
+    return rc_k != DVP_OK ? rc_k : DVP_EHIP;
+  }
   memcpy(&e0, p->fin_host + FIN_OFF_MSMERR, 8);
   memcpy(p->abir0_host, p->fin_host, 4 * sizeof(Fr));
   memcpy(p->commit_p_host, p->fin_host + FIN_OFF_ENC, 30);

@@ -133,6 +133,13 @@ class GpuBackend:
         self.prover.msm_partial(which, lo, hi, self.part.data_ptr(), self.part.data_ptr() + 64, st)
         return self.part
 
+    def msm_partial_one_shot(self, which, lo, hi):
+        """the same slice through the one-shot path (no fixed-base table is built or replaced): measure_plan_costs' probe"""
+        from ._native import tune
+
+        with tune(DVP_MSM_FIXED_MIN=1 << 40):
+            return self.msm_partial(which, lo, hi)
+
     def combine(self, gathered):
         """gathered: [world, 10] int64 -- the all-gathered 80-byte records (x || y, u32 infinity flag, pad) -- -> one point
         tensor [10]: their sum by world - 1 additions (dvp_points_sum_dev)"""
@@ -254,12 +261,13 @@ def measure_plan_costs(backend, assignment, group=None, reps: int = 3):
     t_full = timed(lambda: backend.begin(assignment, True))
     t_none = timed(lambda: backend.begin(assignment, False))
 
-    def one_vector():
-        backend.begin(assignment, False)
-        backend.extend_vectors([0])
-    t_one = timed(one_vector) - t_none
+    # one vector's extend ALONE between the events (begin is enqueued once, before them): no difference of two noisy timings,
+    # which at small sizes came out <= 0 and skewed the plan
+    FLOOR_MS = 1e-3
+    backend.begin(assignment, False)
+    t_one = max(FLOOR_MS, timed(lambda: backend.extend_vectors([0])))
     # quotient alone = full - none - n_ext vectors (the batched extend shares its constants, so this is a slight over-estimate)
-    t_quot = max(0.0, t_full - t_none - n_ext * t_one)
+    t_quot = max(FLOOR_MS, t_full - t_none - n_ext * t_one)
     t_bcast = 0.0
     if world > 1:
         buf = backend.extended_tensor(0)
@@ -272,7 +280,15 @@ def measure_plan_costs(backend, assignment, group=None, reps: int = 3):
     zero_pt = torch.zeros(10, dtype=torch.int64, device=dev)
     zero_pt[8] = 1  # the point at infinity as a commitment: alpha is then the transcript of the zero encoding -- any alpha serves a timing
     backend.challenge(zero_pt) if hasattr(backend, "challenge") else None
-    t_msm = timed(lambda: backend.msm_partial(1, lo, hi))
+    # the slice goes through the ONE-SHOT path: the fixed-base path would build a table for this uniform slice that prove_sharded
+    # throws away as soon as the plan gives the rank another range (with --warmup 0 that rebuild landed in the timed loop); the
+    # plan only needs the exchange rate between milliseconds and pairs, and `one_shot_over_fixed` (measured at 2^20: 25.5 / 19.0 ms
+    # per proof, MSM share) brings it to the fixed-base path's
+    one_shot_over_fixed = 1.4
+    if hasattr(backend, "msm_partial_one_shot"):
+        t_msm = timed(lambda: backend.msm_partial_one_shot(1, lo, hi)) / one_shot_over_fixed
+    else:
+        t_msm = timed(lambda: backend.msm_partial(1, lo, hi))
     pairs_per_ms = (hi - lo) / t_msm if t_msm > 0 else float(m)
     fig = torch.tensor([t_full, t_none, t_one, t_quot, t_bcast, 1.0 / pairs_per_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -280,7 +296,7 @@ def measure_plan_costs(backend, assignment, group=None, reps: int = 3):
     t_full, t_none, t_one, t_quot, t_bcast, ms_per_pair = (float(x) for x in fig.tolist())
     ext_ranks_guess = max(3, min(world, n_ext))
     own = -(-n_ext // ext_ranks_guess)  # vectors an extender extends itself under the split
-    split_ms = own * t_one + (n_ext - own) * t_bcast + t_quot
+    split_ms = max(FLOOR_MS, own * t_one + (n_ext - own) * t_bcast + t_quot)
     return {"replicated": (t_full - t_none) / ms_per_pair, "split": split_ms / ms_per_pair,
             "ms": {"begin_with_extends": t_full, "begin_without": t_none, "extend_one_vector": t_one, "quotient": t_quot,
                    "broadcast_one_vector": t_bcast, "msm_ms_per_million_pairs": ms_per_pair * 1e6, "split_extender_extra": split_ms},

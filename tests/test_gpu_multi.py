@@ -102,6 +102,8 @@ def test_bench_self_launch_rehearsal(dvp):
     assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["backend"] == "gloo" and len(d["ms_per_step_ranks"]) == n
     assert d["ms_per_step_inproc"] is not None and d["ms_per_step"] > 0, d.get("inproc_error")
     assert d["scaling_measured"] is True
+    assert len(lines[0]) < 6000
+    d = {**json.load(open(os.path.join(ROOT, d["detail"]))), **d}  # the line is the headline; plans and per-rank stages are in the sidecar it names
     plan = d["shard_plan"]
     assert [p["rank"] for p in plan] == list(range(n))
     m, n_wires = 1 << 14, d["config"]["n_wires"]
@@ -111,6 +113,9 @@ def test_bench_self_launch_rehearsal(dvp):
     costs = d["shard_plan_costs"]
     assert costs["replicated"] > 0 and costs["split"] > 0 and costs["ms"]["extend_one_vector"] > 0 and costs["ms"]["broadcast_one_vector"] > 0
     assert len(d["stages_ms_per_step_by_rank"]) == n and all(r["msm_total_ms_per_step"] > 0 for r in d["stages_ms_per_step_by_rank"])
+    # the replicas figure (N independent provers, measured after the timed loop) rides in the same line
+    rep = d["replicas"]
+    assert rep["n"] == n and rep["constraints_per_s"] > 0 and len(rep["ms_per_proof_each"]) == n
 
 
 @pytest.mark.parametrize("world", [2])

@@ -614,13 +614,18 @@ def test_device_transcript_error_order(dvp):
     pv.set_srs(dvp.srs.verifier_runs_setup(pv, inst, td))
     st = torch.cuda.current_stream().cuda_stream
     good = dvp.fr.vec([1] + pub + prv)
-    proof = pv.prove_dev(torch.from_numpy(good.view(np.int64)).cuda().data_ptr(), st)
+
+    def dev(a):  # the device copy is bound to a name that outlives the prove_dev call reading it
+        return torch.from_numpy(a.view(np.int64)).cuda()
+    d_good = dev(good)
+    proof = pv.prove_dev(d_good.data_ptr(), st)
     assert dvp.srs.verify(td, pub, proof)
     # (1) a wire no row reads correctly any more: unsatisfied row index
     bad = good.copy()
     bad[5, 0] ^= np.uint64(1)
+    d_bad = dev(bad)
     with pytest.raises(dvp.DvpError) as ei:
-        pv.prove_dev(torch.from_numpy(bad.view(np.int64)).cuda().data_ptr(), st)
+        pv.prove_dev(d_bad.data_ptr(), st)
     assert ei.value.status == -3 and ei.value.index >= 0
     # (2) a non-canonical wire (value + p < 2^256): the rows are evaluated on whatever the limbs hold, so either a row is reported
     # (-3, as the reference asserts satisfaction first) or the commitment MSM's deferred range word names the wire (-1, index)
@@ -628,13 +633,14 @@ def test_device_transcript_error_order(dvp):
     v = int.from_bytes(good[k].tobytes(), "little") + o.P
     bad = good.copy()
     bad[k] = np.array([(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    d_bad2 = dev(bad)
     with pytest.raises(dvp.DvpError) as ei:
-        pv.prove_dev(torch.from_numpy(bad.view(np.int64)).cuda().data_ptr(), st)
+        pv.prove_dev(d_bad2.data_ptr(), st)
     assert ei.value.status == -3 or (ei.value.status, ei.value.index) == (-1, k)
     with dvp.tune(DVP_PROVE_HOST_TRANSCRIPT=1):
         with pytest.raises(dvp.DvpError) as ej:
-            pv.prove_dev(torch.from_numpy(bad.view(np.int64)).cuda().data_ptr(), st)
+            pv.prove_dev(d_bad2.data_ptr(), st)
     assert (ej.value.status, ej.value.index) == (ei.value.status, ei.value.index)
     # the prover is usable afterwards and gives the same bytes
-    assert pv.prove_dev(torch.from_numpy(good.view(np.int64)).cuda().data_ptr(), st) == proof
+    assert pv.prove_dev(d_good.data_ptr(), st) == proof
     pv.close()

@@ -7,5 +7,5 @@ TAG=$1; shift
 OUT=$ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --pmc "$@" --kernel-trace -d $OUT -o q --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.log
+timeout -k 10 500 rocprofv3 --pmc "$@" --kernel-trace -d $OUT -o q --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --extras ubench > $OUT/bench.json 2> $OUT/err.log
 python3 $ROOT/tools/pmc_digest.py $OUT

@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=$ROOT/gpurun_out/stats_$TAG
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench.json 2> $OUT/err.log
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --extras ubench "$@" > $OUT/bench.json 2> $OUT/err.log
 python3 - <<PY
 import csv,glob
 f=glob.glob("$OUT/**/*kernel_stats.csv",recursive=True)[0]
