@@ -78,6 +78,7 @@ struct Tune {
   long long msm_aff_bmin = 8;   // DVP_MSM_AFF_BMIN: fewest slots a round thread owns (small rounds then use fewer threads, each sharing its inversion among more additions)
   long long msm_aff_bmax = 136; // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns (48 through round 4; msm.hip: AFF_BMAX)
   long long ecfft_radix4 = 3;   // DVP_ECFFT_RADIX4: the unfused top of an extend: 3 = up to nine layers in ONE LDS-tiled launch (k_extend_top; what is above them as under 2), 2 = three layers per pass (k_butterfly8, then k_butterfly4 / k_butterfly for what is left), 1 = two, 0 = one
+  long long ecfft_fold = 1;     // DVP_ECFFT_FOLD: enter / exit fold their pointwise stages into the first / last pass of their extends (0 = the separate launches of rounds 1-5: the parity tests run both)
   long long msm_accum_quad_max = 0;    // DVP_MSM_ACCUM_QUAD_MAX: reducer launches with at most this many tasks (upper bound) use a quad of lanes per task (0 = default)
   long long msm_bucket_pairs_max = 12;  // DVP_MSM_BUCKET_PAIRS_MAX: what the pair rounds leave goes through k_bucket_pairs / k_bucket_rest (one thread per bucket) when no bucket holds more points than this; above it, and with 0, through the fan-in-K reducer
   long long msm_sort_fused = 1;  // DVP_MSM_SORT_FUSED: level 1 of the signed flavour's sort recomputes the entry words from the scalars (0 = k_recode_signed writes them to HBM first)

@@ -417,6 +417,72 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DVP_BF
   }
 }
 
+// ---- what the first launch of an extend reads and the last one writes (round 6) -----------------------------------------------
+// SM = 0 is the extend proper: the input twist on the way in (x = pre[p] * src[g]), the output twist on the way out.  exit and enter
+// used to wrap every extend in separate pointwise launches (k_exit_pre / _mid / _mulc / _post, a device-to-device copy, k_enter_combine:
+// seven HBM passes and a copy around the four extends of an exit level); all of them are products with per-position tables, so they
+// fold into the twists: the tables are multiplied together once (k_exit_fuse_tables) and the LDS kernels' first / last pass do the rest.
+//   load (every SM):   x = pre[p] * src[g << lshift]       lshift = 1 reads the even entries of an interleaved vector
+//   SM 1 ("mid"):      out[g] = tb[p] * aux[(g << ashift) + aoff] + post[p] * x                 (post = -(wout * xnn_odd * z0inv))
+//   SM 2 ("post"):     u = post[p] * x;  out[(2c) h + i] = u;  out[(2c + 1) h + i] = tb[p] * (aux[2 g] - u),   g = c h + i
+//   SM 3 ("combine"):  enter's recombination, vectors 2c (lo) and 2c + 1 (hi) of one workgroup:
+//                      out[c 2h + 2i] = aux[lo] + tb[i] * aux[hi];  out[c 2h + 2i + 1] = post[i] * x_lo + tc[i] * x_hi
+// Products are lazy (fr.cuh): a sum of two of them is below 2.2 p, two conditional subtractions bring it home.
+template <int SM>
+struct ExtIo {
+  const Fr30* pre = nullptr;
+  int lshift = 0;
+  const Fr30* post = nullptr;
+  Fr* out = nullptr;
+  const Fr30* tb = nullptr;
+  const Fr30* tc = nullptr;
+  const Fr* aux = nullptr;
+  int ashift = 0, aoff = 0, lh = 0;
+};
+__device__ __forceinline__ Fr fr30_canon2(const Fr30& a) { return fr_cond_sub_p(fr_cond_sub_p(fr30_to_fr(a))); }
+template <int SM>
+__device__ __forceinline__ void io_load2(const ExtIo<SM>& io, const Fr* src, size_t g0, size_t g1, uint32_t p0, uint32_t p1, Fr30& r0, Fr30& r1) {
+  if (io.pre) tw_in2(io.pre, p0, p1, src[g0 << io.lshift], src[g1 << io.lshift], r0, r1);
+  else {
+    r0 = ld30(src + g0);
+    r1 = ld30(src + g1);
+  }
+}
+// the last launch's stores for SM 0 .. 2 (two values of one thread; SM 3 pairs values across vectors: k_extend_fused does it itself)
+template <int SM>
+__device__ __forceinline__ void io_store2(const ExtIo<SM>& io, Fr* data, size_t g0, size_t g1, uint32_t p0, uint32_t p1, const Fr30& x0, const Fr30& x1) {
+  if (SM == 0) {
+    if (io.post) {
+      Fr o0, o1;
+      tw_out2(io.post, p0, p1, x0, x1, o0, o1);
+      data[g0] = o0;
+      data[g1] = o1;
+    } else {
+      st30(data + g0, x0);
+      st30(data + g1, x1);
+    }
+  } else if (SM == 1) {
+    const Fr30 z = fr30_zero();
+    Fr30 a0, a1, y0, y1;
+    fr30_muladd_x2(io.tb[p0], fr30_from(io.aux[(g0 << io.ashift) + io.aoff]), z, io.tb[p1], fr30_from(io.aux[(g1 << io.ashift) + io.aoff]), z, a0, a1);
+    fr30_muladd_x2(io.post[p0], x0, a0, io.post[p1], x1, a1, y0, y1);
+    io.out[g0] = fr30_canon2(y0);
+    io.out[g1] = fr30_canon2(y1);
+  } else if (SM == 2) {
+    Fr u0, u1;
+    tw_out2(io.post, p0, p1, x0, x1, u0, u1);
+    const Fr d0 = fr_sub(io.aux[g0 << 1], u0), d1 = fr_sub(io.aux[g1 << 1], u1);
+    const uint32_t hm = (1u << io.lh) - 1u;
+    const size_t o0 = ((g0 >> io.lh) << (io.lh + 1)) + (g0 & hm), o1 = ((g1 >> io.lh) << (io.lh + 1)) + (g1 & hm);
+    io.out[o0] = u0;
+    io.out[o1] = u1;
+    Fr v0, v1;
+    tw_out2(io.tb, p0, p1, fr30_from(d0), fr30_from(d1), v0, v1);
+    io.out[o0 + (hm + 1u)] = v0;
+    io.out[o1 + (hm + 1u)] = v1;
+  }
+}
+
 // Fused bottom of an extend: the last `lb` decompose layers and the first `lb` recombine layers only mix
 // elements inside aligned blocks of 2^lb <= 2048 values, so a workgroup keeps 2048 consecutive values
 // (64 KB) in LDS and runs all 2*lb butterfly layers on them in ONE launch and ONE HBM round trip (the
@@ -460,23 +526,18 @@ __device__ __forceinline__ void lds_bfly4(Fr30* x, const Fr30* __restrict__ tw_w
   __syncthreads();
 }
 
+template <int SM>
 __global__ void __launch_bounds__(FUSE_TPB) __attribute__((amdgpu_waves_per_eu(FUSE_TPB / 128, FUSE_TPB / 128)))
 k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-of-place extend */, Fr* data, const Fr30* __restrict__ dec,
-               const Fr30* __restrict__ rec, uint32_t n, int ln, int lb, size_t total, const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
+               const Fr30* __restrict__ rec, uint32_t n, int ln, int lb, size_t total, const ExtIo<SM> io) {
   __shared__ Fr30 x[FUSE_ELEMS];
   const size_t base = (size_t)blockIdx.x * FUSE_ELEMS;
   const uint32_t elems = (uint32_t)min((size_t)FUSE_ELEMS, total - base);
   const uint32_t pos0 = (uint32_t)(base & (size_t)(n - 1));  // position of the block's first value inside its vector (n is a power of two)
   // two values per thread and trip (k, k + elems / 2): their twist products are independent
   const uint32_t half = elems >> 1;  // elems is even: a batch of vectors of n >= 2 values
-  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
-    if (pre)
-      tw_in2(pre, (pos0 + k) & (n - 1), (pos0 + k + half) & (n - 1), src[base + k], src[base + k + half], x[k], x[k + half]);
-    else {
-      x[k] = ld30(src + base + k);
-      x[k + half] = ld30(src + base + k + half);
-    }
-  }
+  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x)
+    io_load2(io, src, base + k, base + k + half, (pos0 + k) & (n - 1), (pos0 + k + half) & (n - 1), x[k], x[k + half]);
   __syncthreads();
   auto tw_of = [&](const Fr30* b, int L) { return b + 2 * (size_t)(n - (n >> (ln - lb + L))); };
   const bool whole = elems == FUSE_ELEMS || (elems & 3u) == 0;  // (a short last block still holds whole sub-blocks of every layer it runs)
@@ -493,17 +554,25 @@ k_extend_fused(const Fr* src /* == data unless this is the first pass of an out-
       for (; L >= 1; L -= 2) lds_bfly4<false>(x, tw_of(rec, L - 1), tw_of(rec, L), lb - L - 1, elems >> 2);
     for (; L >= 0; --L) lds_bfly<false>(x, tw_of(rec, L), lb - L - 1, elems >> 1);
   }
-  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
-    if (post) {
-      Fr o0, o1;
-      tw_out2(post, (pos0 + k) & (n - 1), (pos0 + k + half) & (n - 1), x[k], x[k + half], o0, o1);
-      data[base + k] = o0;
-      data[base + k + half] = o1;
-    } else {
-      st30(data + base + k, x[k]);
-      st30(data + base + k + half, x[k + half]);
+  if (SM == 3) {
+    // enter's combine: the block holds whole (lo, hi) pairs of vectors of n = 2^lh <= 1024 values (the host checks); thread q owns
+    // position i of pair cl
+    const int lh = io.lh;
+    const uint32_t hm = n - 1u;
+    for (uint32_t q = threadIdx.x; q < half; q += blockDim.x) {
+      const uint32_t i = q & hm, e_lo = ((q >> lh) << (lh + 1)) + i, e_hi = e_lo + n;
+      const Fr30 z = fr30_zero();
+      Fr30 a, b, ye, yo;
+      fr30_muladd_x2(io.post[i], x[e_lo], z, io.tb[i], fr30_from(io.aux[base + e_hi]), fr30_from(io.aux[base + e_lo]), a, ye);
+      yo = fr30_muladd(io.tc[i], x[e_hi], a);
+      const size_t o = base + ((size_t)(q >> lh) << (lh + 1)) + 2u * i;
+      io.out[o] = fr30_canon2(ye);
+      io.out[o + 1] = fr30_canon2(yo);
     }
+    return;
   }
+  for (uint32_t k = threadIdx.x; k < half; k += blockDim.x)
+    io_store2(io, data, base + k, base + k + half, (pos0 + k) & (n - 1), (pos0 + k + half) & (n - 1), x[k], x[k + half]);
 }
 
 // Fused TOP of an extend (round 5): the `tl` layers d0 .. d0 + tl - 1 of a long vector mix values that sit S = n >> (d0 + tl) apart
@@ -519,10 +588,10 @@ struct TwTile {
   uint32_t lc, ls, col0;
   __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return ((i >> lc) << ls) + col0 + (i & ((1u << lc) - 1u)); }
 };
-template <bool DEC>
+template <bool DEC, int SM>
 __global__ void __launch_bounds__(FUSE_TPB) __attribute__((amdgpu_waves_per_eu(FUSE_TPB / 128, FUSE_TPB / 128)))
 k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec, whole table */, uint32_t n, int ln, int d0, int tl,
-             uint32_t batch, const Fr30* __restrict__ pre, const Fr30* __restrict__ post) {
+             uint32_t batch, const ExtIo<SM> io) {
   __shared__ Fr30 x[FUSE_ELEMS];
   const int lc = FUSE_LOG - tl, ls = ln - d0 - tl;        // log2 of the tile's columns and of the row distance
   const uint32_t groups = 1u << (ls - lc);                // tiles per block of n >> d0 values
@@ -530,20 +599,17 @@ k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec,
   // and layer: as many bytes as the data), and consecutive workgroups go to the 8 XCDs in turn: eight tiles of vector 0, the same
   // eight of vector 1, .. -- so that the workgroups sharing constants land on the SAME XCD one dispatch round apart and the second
   // and third find them in its L2 (a tile-major order put them on three different XCDs: three fetches from memory)
+  // (a vector of fewer than eight tiles -- the many short vectors of an enter / exit level -- is walked tile by tile)
+  const uint32_t tpv = n >> FUSE_LOG;  // tiles per vector
   const uint32_t per8 = 8u * batch, grp8 = blockIdx.x / per8, rem = blockIdx.x - grp8 * per8;
-  const uint32_t vec = rem >> 3, tv = (grp8 << 3) | (rem & 7u);  // (n >> FUSE_LOG tiles per vector: a multiple of 16 here)
+  const uint32_t vec = tpv >= 8u ? rem >> 3 : blockIdx.x / tpv, tv = tpv >= 8u ? ((grp8 << 3) | (rem & 7u)) : blockIdx.x - vec * tpv;
   const uint32_t gb = (vec << d0) + (tv >> (ls - lc)), cg = tv & (groups - 1u);
   const size_t base = ((size_t)gb << (ln - d0)) + ((size_t)cg << lc);
   const uint32_t cmask = (1u << lc) - 1u, half = FUSE_ELEMS >> 1;
   auto gidx = [&](uint32_t e) -> size_t { return base + ((size_t)(e >> lc) << ls) + (e & cmask); };
   for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
     const size_t g0 = gidx(k), g1 = gidx(k + half);
-    if (pre)
-      tw_in2(pre, (uint32_t)(g0 & (size_t)(n - 1)), (uint32_t)(g1 & (size_t)(n - 1)), src[g0], src[g1], x[k], x[k + half]);
-    else {
-      x[k] = ld30(src + g0);
-      x[k + half] = ld30(src + g1);
-    }
+    io_load2(io, src, g0, g1, (uint32_t)(g0 & (size_t)(n - 1)), (uint32_t)(g1 & (size_t)(n - 1)), x[k], x[k + half]);
   }
   __syncthreads();
   const TwTile f{(uint32_t)lc, (uint32_t)ls, cg << lc};
@@ -559,15 +625,7 @@ k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec,
   }
   for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
     const size_t g0 = gidx(k), g1 = gidx(k + half);
-    if (post) {
-      Fr o0, o1;
-      tw_out2(post, (uint32_t)(g0 & (size_t)(n - 1)), (uint32_t)(g1 & (size_t)(n - 1)), x[k], x[k + half], o0, o1);
-      data[g0] = o0;
-      data[g1] = o1;
-    } else {
-      st30(data + g0, x[k]);
-      st30(data + g1, x[k + half]);
-    }
+    io_store2(io, data, g0, g1, (uint32_t)(g0 & (size_t)(n - 1)), (uint32_t)(g1 & (size_t)(n - 1)), x[k], x[k + half]);
   }
 }
 
@@ -662,12 +720,34 @@ static int build_matset(dvp_ecfft* c, int sl, int to_even, MatSet** out, hipStre
   return DVP_OK;
 }
 
+// host-side description of an extend's folded-in pointwise stages (ExtIo above; SM is picked at run time)
+struct ExtIoSpec {
+  int sm = 0;
+  const Fr30* pre = nullptr;   // replaces the input twist (a table that already contains it)
+  int lshift = 0;
+  const Fr30* post = nullptr;  // replaces the output twist
+  Fr* out = nullptr;
+  const Fr30* tb = nullptr;
+  const Fr30* tc = nullptr;
+  const Fr* aux = nullptr;
+  int ashift = 0, aoff = 0, lh = 0;
+};
+constexpr int EXT_TOP_MAX = 9;  // == FUSE_LOG - 2 (asserted in extend_io): the layers one k_extend_top launch covers
+// can an extend of vectors of n values carry an ExtIoSpec?  Its first and last launch must be the LDS kernels (k_extend_top /
+// k_extend_fused): 2 <= n <= 2^(FUSE_LOG + EXT_TOP_MAX); the combine (sm 3) pairs two vectors inside one k_extend_fused block
+static bool ext_io_ok(uint32_t n, int sm) { return n >= 2 && (sm == 3 ? n <= 1024u : n <= (1u << (11 + EXT_TOP_MAX))); }
+static int extend_io(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, uint32_t batch, hipStream_t st, const ExtIoSpec* io);
+
 // in-place extend of `batch` vectors of n = (N>>sl)/2 values
-int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) { return extend_from(c, sl, to_even, data, data, batch, st); }
+int extend_inplace(dvp_ecfft* c, int sl, int to_even, Fr* data, uint32_t batch, hipStream_t st) { return extend_io(c, sl, to_even, data, data, batch, st, nullptr); }
 // the same out of place: `src` is read by the first pass only and left untouched (the prover keeps a, b, c on D for its K scalars;
 // a copy of 3 x 32 MB before every extend was one more HBM round trip)
 int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, uint32_t batch, hipStream_t st) {
+  return extend_io(c, sl, to_even, src_in, data, batch, st, nullptr);
+}
+static int extend_io(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, uint32_t batch, hipStream_t st, const ExtIoSpec* io) {
   uint32_t n = (c->n_leaves >> sl) >> 1;
+  if (io && !ext_io_ok(n, io->sm)) return DVP_EINVAL;
   if (n <= 1) {
     if (src_in != data && n == 1) DVP_HIP(hipMemcpyAsync(data, src_in, (size_t)batch * sizeof(Fr), hipMemcpyDeviceToDevice, st));
     return DVP_OK;
@@ -681,12 +761,26 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   // The first launch multiplies its input by the source twist, the last one its output by the destination twist (see "TWISTED
   // butterflies" above); a pass knows which it is from `first` / the `last` flag of its caller.
   bool first = true;
-  auto pre_of = [&]() { const Fr30* r = first ? ms->win : nullptr; first = false; return r; };
+  auto pre_of = [&]() { const Fr30* r = first ? (io && io->pre ? io->pre : ms->win) : nullptr; first = false; return r; };
+  const Fr30* wout = io && io->post ? io->post : ms->wout;
+  const int sm_last = io ? io->sm : 0;
+  // the ExtIo of one LDS-kernel launch: `pre` set = it is the first one (and reads with the caller's stride), `last` = it carries the
+  // output side (twist alone, or the caller's folded-in store)
+  auto fill = [&](auto& e, const Fr30* pre, bool last) {
+    e.pre = pre;
+    e.lshift = pre && io ? io->lshift : 0;
+    if (last) {
+      e.post = wout;
+      if (io) {
+        e.out = io->out; e.tb = io->tb; e.tc = io->tc; e.aux = io->aux; e.ashift = io->ashift; e.aoff = io->aoff; e.lh = io->lh;
+      }
+    }
+  };
   auto pass = [&](const Fr30* base, int d, bool dec, bool last) {
     const Fr30* tws = base + 2 * (size_t)(n - (n >> d));
     const int lh = ln - d - 1;
     const Fr30* pre = pre_of();
-    const Fr30* post = last ? ms->wout : nullptr;
+    const Fr30* post = last ? wout : nullptr;
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g(cdiv(nn >> 1, TPB)), b(TPB);
 #define DVP_BF(B) \
@@ -702,7 +796,7 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
     const Fr30* narrow = base + 2 * (size_t)(n - (n >> (d + 1)));
     const int lh2 = ln - d - 2;
     const Fr30* pre = pre_of();
-    const Fr30* post = last ? ms->wout : nullptr;
+    const Fr30* post = last ? wout : nullptr;
     const dim3 g(cdiv((size_t)(n >> 2) * batch, TPB)), b(TPB);
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g1(cdiv(nn >> 2, TPB));
@@ -720,7 +814,7 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
     const Fr30* t2 = base + 2 * (size_t)(n - (n >> (d + 2)));
     const int lh3 = ln - d - 3;
     const Fr30* pre = pre_of();
-    const Fr30* post = last ? ms->wout : nullptr;
+    const Fr30* post = last ? wout : nullptr;
     const dim3 g(cdiv((size_t)(n >> 3) * batch, TPB)), b(TPB);
     const uint32_t nn = batch <= 4 && batch >= 2 ? n : (uint32_t)((size_t)batch * n);
     const dim3 g1(cdiv(nn >> 3, TPB));
@@ -736,16 +830,26 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   // the top layers in groups of 3 (radix 8), then one group of 2 or 1; the recombine direction mirrors the decompose's grouping
   const int radix = (int)tune().ecfft_radix4;  // 0: one layer per pass, 1: two, 2: three, 3 (default): the top in one LDS-tiled launch
   // k_extend_top covers the last tl <= TOP_MAX top layers (the ones next to the fused bottom), whatever is above them goes in groups
-  constexpr int TOP_MIN = 4, TOP_MAX = FUSE_LOG - 2;  // >= 4 columns per tile row (128-byte lines); below 4 layers k_butterfly8 / 4 do as well
-  const int tl = (radix >= 3 && top >= TOP_MIN) ? (top < TOP_MAX ? top : TOP_MAX) : 0;
+  constexpr int TOP_MAX = FUSE_LOG - 2;  // >= 4 columns per tile row (128-byte lines); below 4 layers k_butterfly8 / 4 do as well
+  static_assert(TOP_MAX == EXT_TOP_MAX && FUSE_LOG == 11, "ext_io_ok restates these");
+  const int TOP_MIN = io ? 1 : 4;        // an extend with folded-in stages needs its first and last launch to be LDS kernels
+  const int tl = ((radix >= 3 || io) && top >= TOP_MIN) ? (top < TOP_MAX ? top : TOP_MAX) : 0;
   const int d0 = top - tl;  // layers 0 .. d0 - 1 in groups, d0 .. top - 1 tiled
   auto pass_top = [&](const Fr30* base, bool dec, bool last) {
-    const Fr30* pre = pre_of();
-    const Fr30* post = last ? ms->wout : nullptr;
     const uint32_t nn = (uint32_t)((size_t)batch * n);  // the batch vectors are contiguous: blocks of n >> d0 values all the way through
     const dim3 g(nn >> FUSE_LOG), b(FUSE_TPB);
-    if (dec) hipLaunchKernelGGL(k_extend_top<true>, g, b, 0, st, src, data, base, n, ln, d0, tl, batch, pre, post);
-    else hipLaunchKernelGGL(k_extend_top<false>, g, b, 0, st, src, data, base, n, ln, d0, tl, batch, pre, post);
+    if (dec) {
+      ExtIo<0> e;
+      fill(e, pre_of(), false);
+      hipLaunchKernelGGL((k_extend_top<true, 0>), g, b, 0, st, src, data, base, n, ln, d0, tl, batch, e);
+    } else {
+      (void)pre_of();
+#define DVP_TOP_LAST(SM_) \
+  do { ExtIo<SM_> e; fill(e, nullptr, last); hipLaunchKernelGGL((k_extend_top<false, SM_>), g, b, 0, st, src, data, base, n, ln, d0, tl, batch, e); } while (0)
+      const int sm = last ? sm_last : 0;
+      if (sm == 1) DVP_TOP_LAST(1); else if (sm == 2) DVP_TOP_LAST(2); else DVP_TOP_LAST(0);
+#undef DVP_TOP_LAST
+    }
     src = data;
   };
   std::vector<int> groups;
@@ -764,8 +868,14 @@ int extend_from(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, u
   }
   {
     size_t total = (size_t)batch * n;
-    hipLaunchKernelGGL(k_extend_fused, dim3(cdiv(total, FUSE_ELEMS)), dim3(FUSE_TPB), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total, pre_of(),
-                       top == 0 ? ms->wout : nullptr);
+    const Fr30* pre = pre_of();
+    const bool last = top == 0;
+#define DVP_FUSED(SM_) \
+  do { ExtIo<SM_> e; fill(e, pre, last); \
+       hipLaunchKernelGGL((k_extend_fused<SM_>), dim3(cdiv(total, FUSE_ELEMS)), dim3(FUSE_TPB), 0, st, src, data, ms->dec, ms->rec, n, ln, lb, total, e); } while (0)
+    const int sm = last ? sm_last : 0;
+    if (sm == 1) DVP_FUSED(1); else if (sm == 2) DVP_FUSED(2); else if (sm == 3) DVP_FUSED(3); else DVP_FUSED(0);
+#undef DVP_FUSED
     src = data;
   }
   {
@@ -883,6 +993,7 @@ static int ecfft_init(dvp_ecfft* c, uint32_t log_n, int shifted, uint32_t base_l
 }
 
 static void free_exit_tables(dvp_ecfft* c);
+static void free_enter_tables(dvp_ecfft* c);
 extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   if (!c) return;
   (void)hipFree(c->layers);
@@ -897,6 +1008,7 @@ extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   if (c->d_x0) (void)hipFree(c->d_x0);
   if (c->d_t) (void)hipFree(c->d_t);
   free_exit_tables(c);
+  free_enter_tables(c);
   delete c;
 }
 
@@ -957,25 +1069,83 @@ static int ensure_scratch(dvp_ecfft* c) {
 // enter: bottom-up over recursion depth k (sub-problem size sz = N>>k on the stride-2^k subtree).
 // All sub-problems of a depth share the subtree, so each depth is ONE batched extend
 // (batch 2*nsub, vectors of sz/2) plus one combine kernel.
+namespace dvp {
+// enter's combine tables of the stride-2^sl subtree (ExtIo SM 3): xe[i] = xnn[2i], t2[i] = wout[i] * xnn[2i + 1], multiplier-constant form
+__global__ void __launch_bounds__(256) k_enter_fuse_tables(const Fr* __restrict__ xnn, const Fr30* __restrict__ wout, Fr30* __restrict__ xe,
+                                                           Fr30* __restrict__ t2, uint32_t h) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h) return;
+  xe[i] = fr30_const(xnn[2 * i]);
+  // (w R') * (y R) / R' = w y R: the Montgomery form of the product, lazily reduced
+  t2[i] = fr30_const(fr30_canon(fr30_muladd(wout[i], fr30_from(xnn[2 * i + 1]), fr30_zero())));
+}
+}  // namespace dvp
+struct EnterTab {
+  Fr30* xe = nullptr;
+  Fr30* t2 = nullptr;
+};
+static std::map<dvp_ecfft*, std::map<int, EnterTab>> g_enter_tabs;  // per ctx, per stride level
+static std::mutex g_enter_mu;
+static int get_enter_tab(dvp_ecfft* c, int sl, EnterTab* out, hipStream_t st) {
+  {
+    std::lock_guard<std::mutex> g(g_enter_mu);
+    auto& m = g_enter_tabs[c];
+    auto it = m.find(sl);
+    if (it != m.end()) {
+      *out = it->second;
+      return DVP_OK;
+    }
+  }
+  const uint32_t h = (c->n_leaves >> sl) >> 1;
+  Fr* xnn;
+  DVP_TRY(get_xnn(c, sl, &xnn, st));
+  MatSet* ms;
+  DVP_TRY(build_matset(c, sl, 0, &ms, st));
+  EnterTab tb;
+  DVP_HIP(hipMalloc((void**)&tb.xe, (size_t)h * sizeof(Fr30)));
+  DVP_HIP(hipMalloc((void**)&tb.t2, (size_t)h * sizeof(Fr30)));
+  hipLaunchKernelGGL(k_enter_fuse_tables, dim3(cdiv(h, TPB)), dim3(TPB), 0, st, xnn, ms->wout, tb.xe, tb.t2, h);
+  DVP_HIP(hipGetLastError());
+  std::lock_guard<std::mutex> g(g_enter_mu);
+  g_enter_tabs[c][sl] = tb;
+  *out = tb;
+  return DVP_OK;
+}
+
 static int enter_core(dvp_ecfft* c, int sl0, const Fr* d_coeffs, Fr* d_out, hipStream_t st) {
   const uint32_t N = c->n_leaves, M = N >> sl0;
   DVP_TRY(ensure_scratch(c));
-  Fr* even = c->scratch;
   Fr* odd = c->scratch + M;
-  Fr* tmp = c->scratch + 2 * (size_t)M;
-  DVP_HIP(hipMemcpyAsync(even, d_coeffs, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  Fr* bufs[2] = {c->scratch, c->scratch + 2 * (size_t)M};
+  const bool fold = tune().ecfft_fold != 0;
+  const Fr* even = d_coeffs;  // read in place: the first level's extend and combine only read it
+  int nb = 0;
   for (int k = c->log_n - 1; k >= sl0; --k) {
     uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0);
-    DVP_HIP(hipMemcpyAsync(odd, even, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-    DVP_TRY(extend_inplace(c, k, 0, odd, 2 * nsub, st));
-    Fr* xnn;
-    DVP_TRY(get_xnn(c, k, &xnn, st));
-    Fr* dst = (k == sl0) ? d_out : tmp;
-    hipLaunchKernelGGL(k_enter_combine, dim3(cdiv(nsub * h, TPB)), dim3(TPB), 0, st, even, odd, xnn, dst, h, nsub * h);
-    DVP_HIP(hipGetLastError());
-    if (k != sl0) { Fr* t = even; even = tmp; tmp = t; }
+    Fr* dst = (k == sl0) ? d_out : bufs[nb];
+    if (fold && ext_io_ok(h, 3)) {
+      // the extend reads `even`, works in `odd`, and its last (= only: h <= 1024) launch recombines straight into dst
+      EnterTab tb;
+      DVP_TRY(get_enter_tab(c, k, &tb, st));
+      ExtIoSpec io;
+      io.sm = 3;
+      io.out = dst;
+      io.tb = tb.xe;
+      io.tc = tb.t2;
+      io.aux = even;
+      io.lh = 31 - __builtin_clz(h);
+      DVP_TRY(extend_io(c, k, 0, even, odd, 2 * nsub, st, &io));
+    } else {
+      DVP_TRY(extend_from(c, k, 0, even, odd, 2 * nsub, st));  // (h == 1: a copy)
+      Fr* xnn;
+      DVP_TRY(get_xnn(c, k, &xnn, st));
+      hipLaunchKernelGGL(k_enter_combine, dim3(cdiv(nsub * h, TPB)), dim3(TPB), 0, st, even, odd, xnn, dst, h, nsub * h);
+      DVP_HIP(hipGetLastError());
+    }
+    even = dst;
+    nb ^= 1;
   }
-  if (c->log_n == sl0) DVP_HIP(hipMemcpyAsync(d_out, even, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  if (c->log_n == sl0) DVP_HIP(hipMemcpyAsync(d_out, d_coeffs, sizeof(Fr), hipMemcpyDeviceToDevice, st));
   return DVP_OK;
 }
 
@@ -1032,6 +1202,31 @@ k_exit_post(const Fr* __restrict__ ev, const Fr* __restrict__ u0, const Fr* __re
   next[(size_t)(2 * c + 1) * h + i] = fr_mul(xinv[i], fr_sub(ev[(size_t)c * 2 * h + 2 * i], u));
 }
 
+// exit's folded tables of one stride level (ExtIo; all in the multiplier's constant form, indexed by the position i < h):
+//   P  = win * xinv                      first extend of a redc reads the even entries:      x = P[i] * ev[2 (c h + i)]
+//   R  = P * ctab[2i]                    ... or the previous redc's even half h0:            x = R[i] * h0[c h + i]
+//   nA = -(wout * xnn[2i+1] * z0inv)     its last pass stores h1 = B * ev_odd + nA * x       (B = z0inv; B2 = z0inv * ctab[2i+1] on h1)
+//   XI = xinv                            the level's last extend stores (u, XI * (ev_even - u))
+// win / wout are the twists of the even -> odd extend of this level (MatSet to_even = 0).
+__global__ void __launch_bounds__(256)
+k_exit_fuse_tables(const Fr30* __restrict__ win, const Fr30* __restrict__ wout, const Fr* __restrict__ xinv, const Fr* __restrict__ z0inv,
+                   const Fr* __restrict__ xnn, const Fr* __restrict__ ctab, Fr30* __restrict__ P, Fr30* __restrict__ R, Fr30* __restrict__ nA,
+                   Fr30* __restrict__ B, Fr30* __restrict__ B2, Fr30* __restrict__ XI, uint32_t h) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= h) return;
+  const Fr30 z = fr30_zero();
+  const Fr xi = xinv[i], zi = z0inv[i];
+  // (w R') * (y R) / R' = w y R: the Montgomery form of the product
+  const Fr p = fr30_canon(fr30_muladd(win[i], fr30_from(xi), z));
+  const Fr a = fr30_canon(fr30_muladd(wout[i], fr30_from(xnn[2 * i + 1]), z));
+  P[i] = fr30_const(p);
+  R[i] = fr30_const(fr_mul(p, ctab[2 * i]));
+  nA[i] = fr30_const(fr_neg(fr_mul(a, zi)));
+  B[i] = fr30_const(zi);
+  B2[i] = fr30_const(fr_mul(zi, ctab[2 * i + 1]));
+  XI[i] = fr30_const(xi);
+}
+
 // helpers for the z0z0 bootstrap
 __global__ void __launch_bounds__(256) k_neg_from_mont_even(const Fr* __restrict__ xnn, Fr* __restrict__ out, uint32_t h) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1080,6 +1275,7 @@ struct ExitTab {
   Fr* xinv = nullptr;   // h
   Fr* z0inv = nullptr;  // h
   Fr* ctab = nullptr;   // sz, <Z_0^2 mod X^h> on the subtree (Montgomery)
+  Fr30* fused = nullptr;  // 6 h: P | R | nA | B | B2 | XI (k_exit_fuse_tables); nullptr where the level is not folded (h == 1, or above the LDS kernels' reach)
 };
 static std::map<dvp_ecfft*, std::map<int, ExitTab>> g_exit_tabs;  // per ctx, per stride level
 static std::mutex g_exit_mu;
@@ -1140,6 +1336,15 @@ static int ensure_exit_tables(dvp_ecfft* c, int sl_min, hipStream_t st) {
       DVP_HIP(hipStreamSynchronize(st));  // DevBufs go out of scope
     }
     DVP_HIP(hipGetLastError());
+    if (ext_io_ok(h, 1)) {
+      MatSet* ms;
+      DVP_TRY(build_matset(c, sl, 0, &ms, st));
+      DVP_HIP(hipMalloc((void**)&tb.fused, (size_t)6 * h * sizeof(Fr30)));
+      Fr30* f = tb.fused;
+      hipLaunchKernelGGL(k_exit_fuse_tables, dim3(cdiv(h, TPB)), dim3(TPB), 0, st, ms->win, ms->wout, tb.xinv, tb.z0inv, xnn, tb.ctab, f, f + h, f + 2 * (size_t)h,
+                         f + 3 * (size_t)h, f + 4 * (size_t)h, f + 5 * (size_t)h, h);
+      DVP_HIP(hipGetLastError());
+    }
     std::lock_guard<std::mutex> g(g_exit_mu);
     g_exit_tabs[c][sl] = tb;
   }
@@ -1159,15 +1364,16 @@ static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStr
   DVP_TRY(ensure_exit_tables(c, sl0, st));
   DVP_TRY(ensure_scratch(c));
   Fr* S = c->scratch;
-  Fr* cur = S;                        // M
+  Fr* pp[2] = {S + 4 * (size_t)M, S};  // M each: the levels' outputs, in turn (the last level writes d_out itself)
   Fr* t0 = S + (size_t)M;             // M/2  (also g1)
   Fr* h1 = S + (size_t)M + M / 2;     // M/2
   Fr* h0 = S + 2 * (size_t)M;         // M/2
   Fr* r1 = S + 3 * (size_t)M;         // M
-  Fr* nxt = S + 4 * (size_t)M;        // M
-  DVP_HIP(hipMemcpyAsync(cur, d_evals, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+  const Fr* cur = d_evals;  // the first level reads the caller's vector in place
+  int w = 0;
   for (int k = sl0; k < c->log_n; ++k) {
     uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0), total = nsub * h;
+    Fr* nxt = k == c->log_n - 1 ? d_out : pp[w];
     ExitTab tb;
     {
       std::lock_guard<std::mutex> g(g_exit_mu);
@@ -1180,18 +1386,35 @@ static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStr
       hipLaunchKernelGGL(k_exit_pre, grid, blk, 0, st, ev, tb.xinv, t0, h, total);
       DVP_TRY(extend_inplace(c, k, 0, t0, nsub, st));
       hipLaunchKernelGGL(k_exit_mid, grid, blk, 0, st, ev, t0, xnn, tb.z0inv, h1, h, total);
-      DVP_HIP(hipMemcpyAsync(h0, h1, (size_t)total * sizeof(Fr), hipMemcpyDeviceToDevice, st));
-      DVP_TRY(extend_inplace(c, k, 1, h0, nsub, st));
+      DVP_TRY(extend_from(c, k, 1, h1, h0, nsub, st));  // (h == 1: a copy)
       return DVP_OK;
     };
-    DVP_TRY(redc(cur));
-    hipLaunchKernelGGL(k_exit_mulc, grid, blk, 0, st, h0, h1, tb.ctab, r1, h, total);
-    DVP_TRY(redc(r1));
-    hipLaunchKernelGGL(k_exit_post, grid, blk, 0, st, cur, h0, tb.xinv, nxt, h, total);
+    if (tb.fused && tune().ecfft_fold != 0) {
+      // four extends and nothing else (round 6): every pointwise stage rides in the first / last pass of an extend (ExtIo), the
+      // copy h1 -> h0 is the out-of-place first pass, and r1 = (ctab_even h0 | ctab_odd h1) is never written
+      const Fr30 *P = tb.fused, *R = P + h, *nA = P + 2 * (size_t)h, *B = P + 3 * (size_t)h, *B2 = P + 4 * (size_t)h, *XI = P + 5 * (size_t)h;
+      Fr* h1b = r1;  // the second redc's odd half (r1 itself is not needed any more)
+      const int lh = 31 - __builtin_clz(h);
+      ExtIoSpec a1;  // redc 1, even -> odd: t = xinv * ev_even in, h1 = z0inv * (ev_odd - xnn_odd * g1) out
+      a1.sm = 1; a1.pre = P; a1.lshift = 1; a1.post = nA; a1.out = h1; a1.tb = B; a1.aux = cur; a1.ashift = 1; a1.aoff = 1;
+      DVP_TRY(extend_io(c, k, 0, cur, t0, nsub, st, &a1));
+      DVP_TRY(extend_from(c, k, 1, h1, h0, nsub, st));  // odd -> even: h0
+      ExtIoSpec a2;  // redc 2 on r1 = (ctab_even h0 | ctab_odd h1), never materialised
+      a2.sm = 1; a2.pre = R; a2.post = nA; a2.out = h1b; a2.tb = B2; a2.aux = h1;
+      DVP_TRY(extend_io(c, k, 0, h0, t0, nsub, st, &a2));
+      ExtIoSpec b2;  // odd -> even: u; next level's (lo, hi) = (u, xinv * (ev_even - u))
+      b2.sm = 2; b2.out = nxt; b2.tb = XI; b2.aux = cur; b2.lh = lh;
+      DVP_TRY(extend_io(c, k, 1, h1b, h0, nsub, st, &b2));
+    } else {
+      DVP_TRY(redc(cur));
+      hipLaunchKernelGGL(k_exit_mulc, grid, blk, 0, st, h0, h1, tb.ctab, r1, h, total);
+      DVP_TRY(redc(r1));
+      hipLaunchKernelGGL(k_exit_post, grid, blk, 0, st, cur, h0, tb.xinv, nxt, h, total);
+    }
     DVP_HIP(hipGetLastError());
-    Fr* t = cur; cur = nxt; nxt = t;
+    cur = nxt;
+    w ^= 1;
   }
-  DVP_HIP(hipMemcpyAsync(d_out, cur, (size_t)M * sizeof(Fr), hipMemcpyDeviceToDevice, st));
   return DVP_OK;
 }
 
@@ -1249,8 +1472,19 @@ static void free_exit_tables(dvp_ecfft* c) {
     (void)hipFree(kv.second.xinv);
     (void)hipFree(kv.second.z0inv);
     (void)hipFree(kv.second.ctab);
+    if (kv.second.fused) (void)hipFree(kv.second.fused);
   }
   g_exit_tabs.erase(it);
+}
+static void free_enter_tables(dvp_ecfft* c) {
+  std::lock_guard<std::mutex> g(g_enter_mu);
+  auto it = g_enter_tabs.find(c);
+  if (it == g_enter_tabs.end()) return;
+  for (auto& kv : it->second) {
+    (void)hipFree(kv.second.xe);
+    (void)hipFree(kv.second.t2);
+  }
+  g_enter_tabs.erase(it);
 }
 
 // Parity-test read-out of the butterfly matrices extend() runs on (include/dvpari_internal.h): what the reference keeps

@@ -298,6 +298,55 @@ def test_enter_exit_roundtrip_2_20(dvp):
         assert from_limbs(ev[idx][None])[0] == (a * pow(L, j, o.P) + b * pow(L, k, o.P)) % o.P
 
 
+@pytest.mark.parametrize("log_n", [1, 2, 3, 6, 10, 11, 12, 13, 15])
+def test_enter_exit_folded_stages_vs_oracle_and_unfolded(dvp, nat, log_n):
+    """Round 6: enter / exit fold their pointwise stages (k_exit_pre / _mid / _mulc / _post, the h1 -> h0 copy, k_enter_combine for
+    sub-vectors up to 1024) into the first / last pass of their extends (ExtIo in ecfft.hip).  Every level shape is crossed here:
+    h = 1 (never folded), single-launch extends (h <= 2048), and extends with k_extend_top in front and behind (h >= 4096, incl. the
+    short-vector tile walk); folded and unfolded (DVP_ECFFT_FOLD=0) must both equal the oracle element for element, on enter
+    images and on evaluations that are no enter image."""
+    n = 1 << log_n
+    t = dvp.ec_fft.FFTree(n)
+    ot = co.FFTree(log_n)
+    c = rand_fr_np(n, 600 + log_n)
+    ev = rand_fr_np(n, 700 + log_n)
+    want_e, want_x = ot.enter(c), ot.exit(ev)
+    for fold in (1, 0, 1):
+        with nat.tune(DVP_ECFFT_FOLD=fold):
+            e = t.enter(c)
+            assert np.array_equal(e, want_e), fold
+            assert np.array_equal(t.exit(e), c), fold
+            assert np.array_equal(t.exit(ev), want_x), fold
+    ot.close()
+    t.close()
+
+
+def test_exit_enter_2_20_folded_equals_unfolded(dvp, nat):
+    """the same at BASELINE config #3's size, where the oracle takes minutes: both flavours give the same 2^20 values (the unfolded one
+    is what rounds 1-5 checked against the oracle up to 2^16 and by the exact round trip here)"""
+    import torch
+    n = 1 << 20
+    t = dvp.ec_fft.FFTree(n)
+    st = torch.cuda.current_stream().cuda_stream
+    d_in = torch.from_numpy(rand_fr_np(n, 2026).view(np.int64)).cuda()
+    outs = {}
+    for fold in (0, 1):
+        with nat.tune(DVP_ECFFT_FOLD=fold):
+            d_x, d_e = torch.empty_like(d_in), torch.empty_like(d_in)
+            t.exit_dev(d_in.data_ptr(), d_x.data_ptr(), st)
+            t.enter_dev(d_in.data_ptr(), d_e.data_ptr(), st)
+            torch.cuda.synchronize()
+            outs[fold] = (d_x, d_e)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # in place (d_out == d_in) is allowed by both entries
+    d_c = d_in.clone()
+    t.enter_dev(d_c.data_ptr(), d_c.data_ptr(), st)
+    assert torch.equal(d_c, outs[1][1])
+    t.exit_dev(d_c.data_ptr(), d_c.data_ptr(), st)
+    assert torch.equal(d_c, d_in)
+    t.close()
+
+
 def test_extend_consistent_with_enter(dvp):
     """evaluations of one polynomial (degree < m) on D and D' via enter on the 2m tree must be linked by extend."""
     t = dvp.ec_fft.FFTree(1 << 12)
