@@ -593,18 +593,22 @@ __global__ void __launch_bounds__(FUSE_TPB) __attribute__((amdgpu_waves_per_eu(F
 k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec, whole table */, uint32_t n, int ln, int d0, int tl,
              uint32_t batch, const ExtIo<SM> io) {
   __shared__ Fr30 x[FUSE_ELEMS];
-  const int lc = FUSE_LOG - tl, ls = ln - d0 - tl;        // log2 of the tile's columns and of the row distance
-  const uint32_t groups = 1u << (ls - lc);                // tiles per block of n >> d0 values
+  // SM 3 (enter's combine, last launch, d0 == 0): a tile takes its rows from vectors 2u AND 2u + 1 -- the rows of a vector are
+  // S = n >> tl apart and 2^tl S = n, so row 2^tl + r of the "unit" (2u, 2u + 1) is row r of vector 2u + 1: twice the rows, half the
+  // columns, and x[k], x[k + half] are the two vectors' values at the same position, which is what the combine pairs
+  constexpr int PR = SM == 3 ? 1 : 0;
+  const int lc = FUSE_LOG - tl - PR, ls = ln - d0 - tl;   // log2 of the tile's columns and of the row distance
+  const uint32_t groups = 1u << (ls - lc);                // tiles per block of n >> d0 values (per unit of two vectors with SM 3)
   // workgroup -> (vector, tile of that vector).  The same tile of the `batch` vectors reads the same constants (64 bytes per pair
   // and layer: as many bytes as the data), and consecutive workgroups go to the 8 XCDs in turn: eight tiles of vector 0, the same
   // eight of vector 1, .. -- so that the workgroups sharing constants land on the SAME XCD one dispatch round apart and the second
   // and third find them in its L2 (a tile-major order put them on three different XCDs: three fetches from memory)
   // (a vector of fewer than eight tiles -- the many short vectors of an enter / exit level -- is walked tile by tile)
-  const uint32_t tpv = n >> FUSE_LOG;  // tiles per vector
-  const uint32_t per8 = 8u * batch, grp8 = blockIdx.x / per8, rem = blockIdx.x - grp8 * per8;
+  const uint32_t tpv = (n << PR) >> FUSE_LOG;  // tiles per vector (per unit)
+  const uint32_t per8 = 8u * (batch >> PR), grp8 = blockIdx.x / per8, rem = blockIdx.x - grp8 * per8;
   const uint32_t vec = tpv >= 8u ? rem >> 3 : blockIdx.x / tpv, tv = tpv >= 8u ? ((grp8 << 3) | (rem & 7u)) : blockIdx.x - vec * tpv;
   const uint32_t gb = (vec << d0) + (tv >> (ls - lc)), cg = tv & (groups - 1u);
-  const size_t base = ((size_t)gb << (ln - d0)) + ((size_t)cg << lc);
+  const size_t base = ((size_t)gb << (ln - d0 + PR)) + ((size_t)cg << lc);
   const uint32_t cmask = (1u << lc) - 1u, half = FUSE_ELEMS >> 1;
   auto gidx = [&](uint32_t e) -> size_t { return base + ((size_t)(e >> lc) << ls) + (e & cmask); };
   for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
@@ -622,6 +626,19 @@ k_extend_top(const Fr* src, Fr* data, const Fr30* __restrict__ tw /* dec or rec,
     int L = tl - 1;
     if (tl & 1) { lds_bfly<false, TwTile>(x, tw_of(L), tl - L - 1 + lc, FUSE_ELEMS >> 1, f); --L; }
     for (; L >= 1; L -= 2) lds_bfly4<false, TwTile>(x, tw_of(L - 1), tw_of(L), tl - L - 1 + lc, FUSE_ELEMS >> 2, f);
+  }
+  if (SM == 3) {
+    for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
+      const size_t g0 = gidx(k), g1 = g0 + n;  // == gidx(k + half): the same position of vector 2u + 1
+      const uint32_t i = (uint32_t)(g0 & (size_t)(n - 1));
+      const Fr30 z = fr30_zero();
+      Fr30 a, ye, yo;
+      fr30_muladd_x2(io.post[i], x[k], z, io.tb[i], fr30_from(io.aux[g1]), fr30_from(io.aux[g0]), a, ye);
+      yo = fr30_muladd(io.tc[i], x[k + half], a);
+      io.out[g0 + i] = fr30_canon2(ye);  // unit u starts at u 2n = g0 - i: out[u 2n + 2i], out[u 2n + 2i + 1]
+      io.out[g0 + i + 1] = fr30_canon2(yo);
+    }
+    return;
   }
   for (uint32_t k = threadIdx.x; k < half; k += blockDim.x) {
     const size_t g0 = gidx(k), g1 = gidx(k + half);
@@ -735,7 +752,9 @@ struct ExtIoSpec {
 constexpr int EXT_TOP_MAX = 9;  // == FUSE_LOG - 2 (asserted in extend_io): the layers one k_extend_top launch covers
 // can an extend of vectors of n values carry an ExtIoSpec?  Its first and last launch must be the LDS kernels (k_extend_top /
 // k_extend_fused): 2 <= n <= 2^(FUSE_LOG + EXT_TOP_MAX); the combine (sm 3) pairs two vectors inside one k_extend_fused block
-static bool ext_io_ok(uint32_t n, int sm) { return n >= 2 && (sm == 3 ? n <= 1024u : n <= (1u << (11 + EXT_TOP_MAX))); }
+// (sm 3 inside one k_extend_fused block: n <= 1024; across the two vectors of a k_extend_top tile: n >= 4096.  n = 2048 -- one
+// vector per k_extend_fused block, no top -- keeps the separate k_enter_combine)
+static bool ext_io_ok(uint32_t n, int sm) { return n >= 2 && n <= (1u << (11 + EXT_TOP_MAX)) && (sm != 3 || n != 2048u); }
 static int extend_io(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* data, uint32_t batch, hipStream_t st, const ExtIoSpec* io);
 
 // in-place extend of `batch` vectors of n = (N>>sl)/2 values
@@ -847,7 +866,7 @@ static int extend_io(dvp_ecfft* c, int sl, int to_even, const Fr* src_in, Fr* da
 #define DVP_TOP_LAST(SM_) \
   do { ExtIo<SM_> e; fill(e, nullptr, last); hipLaunchKernelGGL((k_extend_top<false, SM_>), g, b, 0, st, src, data, base, n, ln, d0, tl, batch, e); } while (0)
       const int sm = last ? sm_last : 0;
-      if (sm == 1) DVP_TOP_LAST(1); else if (sm == 2) DVP_TOP_LAST(2); else DVP_TOP_LAST(0);
+      if (sm == 1) DVP_TOP_LAST(1); else if (sm == 2) DVP_TOP_LAST(2); else if (sm == 3) DVP_TOP_LAST(3); else DVP_TOP_LAST(0);
 #undef DVP_TOP_LAST
     }
     src = data;
@@ -1124,7 +1143,7 @@ static int enter_core(dvp_ecfft* c, int sl0, const Fr* d_coeffs, Fr* d_out, hipS
     uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0);
     Fr* dst = (k == sl0) ? d_out : bufs[nb];
     if (fold && ext_io_ok(h, 3)) {
-      // the extend reads `even`, works in `odd`, and its last (= only: h <= 1024) launch recombines straight into dst
+      // the extend reads `even`, works in `odd`, and its last launch recombines straight into dst
       EnterTab tb;
       DVP_TRY(get_enter_tab(c, k, &tb, st));
       ExtIoSpec io;
@@ -1136,10 +1155,10 @@ static int enter_core(dvp_ecfft* c, int sl0, const Fr* d_coeffs, Fr* d_out, hipS
       io.lh = 31 - __builtin_clz(h);
       DVP_TRY(extend_io(c, k, 0, even, odd, 2 * nsub, st, &io));
     } else {
-      DVP_TRY(extend_from(c, k, 0, even, odd, 2 * nsub, st));  // (h == 1: a copy)
+      if (h > 1) DVP_TRY(extend_from(c, k, 0, even, odd, 2 * nsub, st));  // (h == 1: a constant is its own extension)
       Fr* xnn;
       DVP_TRY(get_xnn(c, k, &xnn, st));
-      hipLaunchKernelGGL(k_enter_combine, dim3(cdiv(nsub * h, TPB)), dim3(TPB), 0, st, even, odd, xnn, dst, h, nsub * h);
+      hipLaunchKernelGGL(k_enter_combine, dim3(cdiv(nsub * h, TPB)), dim3(TPB), 0, st, even, h > 1 ? odd : even, xnn, dst, h, nsub * h);
       DVP_HIP(hipGetLastError());
     }
     even = dst;
@@ -1225,6 +1244,23 @@ k_exit_fuse_tables(const Fr30* __restrict__ win, const Fr30* __restrict__ wout, 
   B[i] = fr30_const(zi);
   B2[i] = fr30_const(fr_mul(zi, ctab[2 * i + 1]));
   XI[i] = fr30_const(xi);
+}
+
+// the deepest exit level (h = 1: two evaluations per sub-problem, every extend the identity) in one pass: what k_exit_pre / _mid /
+// _mulc / _pre / _mid / _post do with six launches and two copies.  out[2c] = u, out[2c + 1] = xinv (ev0 - u)
+__global__ void __launch_bounds__(256)
+k_exit_leaf(const Fr* __restrict__ ev, const Fr* __restrict__ xinv, const Fr* __restrict__ z0inv, const Fr* __restrict__ xnn,
+            const Fr* __restrict__ ctab, Fr* __restrict__ out, uint32_t nsub) {
+  uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nsub) return;
+  const Fr xi = xinv[0], zi = z0inv[0], xo = xnn[1], ce = ctab[0], co = ctab[1];
+  const Fr e0 = ev[2 * (size_t)c], e1 = ev[2 * (size_t)c + 1];
+  const Fr g1 = fr_mul(xi, e0);
+  const Fr h1 = fr_mul(zi, fr_sub(e1, fr_mul(xo, g1)));              // = h0
+  const Fr g2 = fr_mul(xi, fr_mul(ce, h1));
+  const Fr u = fr_mul(zi, fr_sub(fr_mul(co, h1), fr_mul(xo, g2)));
+  out[2 * (size_t)c] = u;
+  out[2 * (size_t)c + 1] = fr_mul(xi, fr_sub(e0, u));
 }
 
 // helpers for the z0z0 bootstrap
@@ -1405,6 +1441,8 @@ static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStr
       ExtIoSpec b2;  // odd -> even: u; next level's (lo, hi) = (u, xinv * (ev_even - u))
       b2.sm = 2; b2.out = nxt; b2.tb = XI; b2.aux = cur; b2.lh = lh;
       DVP_TRY(extend_io(c, k, 1, h1b, h0, nsub, st, &b2));
+    } else if (h == 1 && tune().ecfft_fold != 0) {
+      hipLaunchKernelGGL(k_exit_leaf, grid, blk, 0, st, cur, tb.xinv, tb.z0inv, xnn, tb.ctab, nxt, nsub);
     } else {
       DVP_TRY(redc(cur));
       hipLaunchKernelGGL(k_exit_mulc, grid, blk, 0, st, h0, h1, tb.ctab, r1, h, total);

@@ -172,11 +172,14 @@ k_bary3_partial(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, const F
                 Fr* __restrict__ partial /* [3][nb] Montgomery */) {
   __shared__ Fr sh[256];
   Fr s[3] = {fr_zero(), fr_zero(), fr_zero()};
+  // four products per element (round 6; eight before): barw (Montgomery) times the canonical dinv is the canonical product k, and
+  // fr_mul(k, y) of two canonical values is k y / R -- the sums carry one factor 1 / R, which the block's ONE thread that writes
+  // the partial takes back out (two products by R^2: x / R -> x -> x R, the Montgomery partial k_bary3_final expects)
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-    Fr k = fr_mul(barw_m[i], fr_to_mont(dinv[i]));  // Montgomery
-    s[0] = fr_add(s[0], fr_mul(k, fr_to_mont(E[i])));
-    s[1] = fr_add(s[1], fr_mul(k, fr_to_mont(E[(size_t)m + i])));
-    s[2] = fr_add(s[2], fr_mul(k, fr_to_mont(E[3 * (size_t)m + i])));
+    Fr k = fr_mul(barw_m[i], dinv[i]);
+    s[0] = fr_add(s[0], fr_mul(k, E[i]));
+    s[1] = fr_add(s[1], fr_mul(k, E[(size_t)m + i]));
+    s[2] = fr_add(s[2], fr_mul(k, E[3 * (size_t)m + i]));
   }
   for (int v = 0; v < 3; ++v) {
     sh[threadIdx.x] = s[v];
@@ -185,7 +188,7 @@ k_bary3_partial(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, const F
       if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
       __syncthreads();
     }
-    if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = fr_mul(fr_mul(sh[0], fr_r2()), fr_r2());
     __syncthreads();
   }
 }
@@ -247,10 +250,10 @@ k_bary3_partial_range(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, c
   __shared__ Fr sh[256];
   Fr s[3] = {fr_zero(), fr_zero(), fr_zero()};
   for (uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += gridDim.x * blockDim.x) {
-    Fr k = fr_mul(barw_m[i], fr_to_mont(dinv[i]));
-    s[0] = fr_add(s[0], fr_mul(k, fr_to_mont(E[i])));
-    s[1] = fr_add(s[1], fr_mul(k, fr_to_mont(E[(size_t)m + i])));
-    s[2] = fr_add(s[2], fr_mul(k, fr_to_mont(E[3 * (size_t)m + i])));
+    Fr k = fr_mul(barw_m[i], dinv[i]);  // (four products per element: see k_bary3_partial)
+    s[0] = fr_add(s[0], fr_mul(k, E[i]));
+    s[1] = fr_add(s[1], fr_mul(k, E[(size_t)m + i]));
+    s[2] = fr_add(s[2], fr_mul(k, E[3 * (size_t)m + i]));
   }
   for (int v = 0; v < 3; ++v) {
     sh[threadIdx.x] = s[v];
@@ -259,7 +262,7 @@ k_bary3_partial_range(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, c
       if ((int)threadIdx.x < o) sh[threadIdx.x] = fr_add(sh[threadIdx.x], sh[threadIdx.x + o]);
       __syncthreads();
     }
-    if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) partial[(size_t)v * gridDim.x + blockIdx.x] = fr_mul(fr_mul(sh[0], fr_r2()), fr_r2());
     __syncthreads();
   }
 }
