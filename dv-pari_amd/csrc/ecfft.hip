@@ -1013,6 +1013,7 @@ static int ecfft_init(dvp_ecfft* c, uint32_t log_n, int shifted, uint32_t base_l
 
 static void free_exit_tables(dvp_ecfft* c);
 static void free_enter_tables(dvp_ecfft* c);
+static void free_leaf8(dvp_ecfft* c);
 extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   if (!c) return;
   (void)hipFree(c->layers);
@@ -1028,6 +1029,7 @@ extern "C" void dvp_ecfft_destroy(dvp_ecfft* c) {
   if (c->d_t) (void)hipFree(c->d_t);
   free_exit_tables(c);
   free_enter_tables(c);
+  free_leaf8(c);
   delete c;
 }
 
@@ -1099,6 +1101,110 @@ __global__ void __launch_bounds__(256) k_enter_fuse_tables(const Fr* __restrict_
   t2[i] = fr30_const(fr30_canon(fr30_muladd(wout[i], fr30_from(xnn[2 * i + 1]), fr30_zero())));
 }
 }  // namespace dvp
+namespace dvp {
+// The three deepest levels of enter / exit (sub-problems of 8 values: h = 4, 2, 1) as ONE pass with a constant 8 x 8 matrix (round 6):
+// every sub-problem of a level lives on the same strided subtree, so enter on 8 coefficients is the Vandermonde matrix V[j][e] =
+// leaf_j^e of that subtree's 8 leaves and exit is its inverse -- 72 multiply-adds per sub-problem (8 x 8 plus one per output that
+// brings the lazy sum back below 2 p), one read and one write of the vector, where the recursion ran three levels of extends and
+// pointwise passes (enter 3 launches, exit 9).  Same field elements: the interpolating polynomial is unique.  The matrix is uniform
+// over the launch (scalar loads); a thread owns one sub-problem.
+__global__ void __launch_bounds__(256) k_leaf_matmul8(const Fr* __restrict__ in, Fr* __restrict__ out, const Fr30* __restrict__ mat /* [8][8] + one */,
+                                                      uint32_t nsub) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nsub) return;
+  Fr30 x[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = fr30_from(in[8 * (size_t)c + q]);
+  const Fr30 one = mat[64];
+#pragma unroll 1
+  for (int r = 0; r < 8; r += 2) {
+    Fr30 a0 = fr30_zero(), a1 = fr30_zero();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fr30_muladd_x2(mat[8 * r + q], x[q], a0, mat[8 * r + 8 + q], x[q], a1, a0, a1);
+    const Fr30 z = fr30_zero();
+    fr30_muladd_x2(one, a0, z, one, a1, z, a0, a1);  // sums of eight lazy products (< 8.1 p) -> below 1.02 p
+    out[8 * (size_t)c + r] = fr30_canon(a0);
+    out[8 * (size_t)c + r + 1] = fr30_canon(a1);
+  }
+}
+}  // namespace dvp
+// V and V^-1 on the 8 leaves of the stride-2^(log_n - 3) subtree, in the multiplier's constant form, + the constant 1 (k_leaf_matmul8)
+struct Leaf8 {
+  Fr30* enter = nullptr;  // 65 entries
+  Fr30* exit = nullptr;
+};
+static std::map<dvp_ecfft*, Leaf8> g_leaf8;
+static std::mutex g_leaf8_mu;
+static int get_leaf8(dvp_ecfft* c, Leaf8* out, hipStream_t st) {
+  std::lock_guard<std::mutex> g(g_leaf8_mu);
+  auto it = g_leaf8.find(c);
+  if (it != g_leaf8.end()) {
+    *out = it->second;
+    return DVP_OK;
+  }
+  if (c->log_n < 3) return DVP_EINVAL;
+  Fr leaf[8];
+  const int k8 = c->log_n - 3;
+  DVP_HIP(hipStreamSynchronize(st));
+  for (int j = 0; j < 8; ++j) DVP_HIP(hipMemcpy(&leaf[j], c->layer(0) + ((size_t)j << k8), sizeof(Fr), hipMemcpyDeviceToHost));
+  // Montgomery arithmetic on the host: V[j][e] = leaf_j^e, W = V^-1 by Gauss-Jordan (the leaves are distinct: V is invertible)
+  Fr V[8][8], A[8][8], W[8][8];
+  for (int j = 0; j < 8; ++j) {
+    V[j][0] = fr_one_mont();
+    for (int e = 1; e < 8; ++e) V[j][e] = fr_mul(V[j][e - 1], leaf[j]);
+    for (int e = 0; e < 8; ++e) {
+      A[j][e] = V[j][e];
+      W[j][e] = j == e ? fr_one_mont() : fr_zero();
+    }
+  }
+  for (int col = 0; col < 8; ++col) {
+    int piv = col;
+    while (piv < 8 && fr_is_zero(A[piv][col])) ++piv;
+    if (piv == 8) return DVP_EINVAL;
+    if (piv != col)
+      for (int e = 0; e < 8; ++e) {
+        Fr t = A[piv][e]; A[piv][e] = A[col][e]; A[col][e] = t;
+        t = W[piv][e]; W[piv][e] = W[col][e]; W[col][e] = t;
+      }
+    const Fr inv = fr_inv(A[col][col]);
+    for (int e = 0; e < 8; ++e) {
+      A[col][e] = fr_mul(A[col][e], inv);
+      W[col][e] = fr_mul(W[col][e], inv);
+    }
+    for (int r = 0; r < 8; ++r) {
+      if (r == col || fr_is_zero(A[r][col])) continue;
+      const Fr f = A[r][col];
+      for (int e = 0; e < 8; ++e) {
+        A[r][e] = fr_sub(A[r][e], fr_mul(f, A[col][e]));
+        W[r][e] = fr_sub(W[r][e], fr_mul(f, W[col][e]));
+      }
+    }
+  }
+  Fr30 he[65], hx[65];
+  for (int r = 0; r < 8; ++r)
+    for (int q = 0; q < 8; ++q) {
+      he[8 * r + q] = fr30_const(V[r][q]);
+      hx[8 * r + q] = fr30_const(W[r][q]);
+    }
+  he[64] = hx[64] = fr30_const(fr_one_mont());
+  Leaf8 t;
+  DVP_HIP(hipMalloc((void**)&t.enter, sizeof(he)));
+  DVP_HIP(hipMalloc((void**)&t.exit, sizeof(hx)));
+  DVP_HIP(hipMemcpy(t.enter, he, sizeof(he), hipMemcpyHostToDevice));
+  DVP_HIP(hipMemcpy(t.exit, hx, sizeof(hx), hipMemcpyHostToDevice));
+  g_leaf8[c] = t;
+  *out = t;
+  return DVP_OK;
+}
+static void free_leaf8(dvp_ecfft* c) {
+  std::lock_guard<std::mutex> g(g_leaf8_mu);
+  auto it = g_leaf8.find(c);
+  if (it == g_leaf8.end()) return;
+  (void)hipFree(it->second.enter);
+  (void)hipFree(it->second.exit);
+  g_leaf8.erase(it);
+}
+
 struct EnterTab {
   Fr30* xe = nullptr;
   Fr30* t2 = nullptr;
@@ -1139,7 +1245,18 @@ static int enter_core(dvp_ecfft* c, int sl0, const Fr* d_coeffs, Fr* d_out, hipS
   const bool fold = tune().ecfft_fold != 0;
   const Fr* even = d_coeffs;  // read in place: the first level's extend and combine only read it
   int nb = 0;
-  for (int k = c->log_n - 1; k >= sl0; --k) {
+  int k_first = c->log_n - 1;
+  if (fold && M >= 8) {  // levels log_n - 1 .. log_n - 3 in one pass (k_leaf_matmul8)
+    Leaf8 l8;
+    DVP_TRY(get_leaf8(c, &l8, st));
+    Fr* dst = (c->log_n - 3 == sl0) ? d_out : bufs[nb];
+    hipLaunchKernelGGL(k_leaf_matmul8, dim3(cdiv(M / 8, TPB)), dim3(TPB), 0, st, d_coeffs, dst, l8.enter, M / 8);
+    DVP_HIP(hipGetLastError());
+    even = dst;
+    nb ^= 1;
+    k_first = c->log_n - 4;
+  }
+  for (int k = k_first; k >= sl0; --k) {
     uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0);
     Fr* dst = (k == sl0) ? d_out : bufs[nb];
     if (fold && ext_io_ok(h, 3)) {
@@ -1407,7 +1524,9 @@ static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStr
   Fr* r1 = S + 3 * (size_t)M;         // M
   const Fr* cur = d_evals;  // the first level reads the caller's vector in place
   int w = 0;
-  for (int k = sl0; k < c->log_n; ++k) {
+  const bool leaf8 = tune().ecfft_fold != 0 && M >= 8;  // the levels below sz = 8 in one pass (k_leaf_matmul8)
+  const int k_end = leaf8 ? c->log_n - 3 : c->log_n;
+  for (int k = sl0; k < k_end; ++k) {
     uint32_t sz = N >> k, h = sz >> 1, nsub = 1u << (k - sl0), total = nsub * h;
     Fr* nxt = k == c->log_n - 1 ? d_out : pp[w];
     ExitTab tb;
@@ -1452,6 +1571,12 @@ static int exit_core(dvp_ecfft* c, int sl0, const Fr* d_evals, Fr* d_out, hipStr
     DVP_HIP(hipGetLastError());
     cur = nxt;
     w ^= 1;
+  }
+  if (leaf8) {
+    Leaf8 l8;
+    DVP_TRY(get_leaf8(c, &l8, st));
+    hipLaunchKernelGGL(k_leaf_matmul8, dim3(cdiv(M / 8, TPB)), dim3(TPB), 0, st, cur, d_out, l8.exit, M / 8);
+    DVP_HIP(hipGetLastError());
   }
   return DVP_OK;
 }
