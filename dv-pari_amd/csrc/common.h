@@ -79,6 +79,9 @@ struct Tune {
   long long msm_aff_bmax = 136; // DVP_MSM_AFF_BMAX: most slots (additions per shared inversion) a round thread owns (48 through round 4; msm.hip: AFF_BMAX)
   long long ecfft_radix4 = 3;   // DVP_ECFFT_RADIX4: the unfused top of an extend: 3 = up to nine layers in ONE LDS-tiled launch (k_extend_top; what is above them as under 2), 2 = three layers per pass (k_butterfly8, then k_butterfly4 / k_butterfly for what is left), 1 = two, 0 = one
   long long ecfft_fold = 1;     // DVP_ECFFT_FOLD: enter / exit fold their pointwise stages into the first / last pass of their extends (0 = the separate launches of rounds 1-5: the parity tests run both)
+  long long msm_accum_fast = 1;  // DVP_MSM_ACCUM_FAST: the fan-in-K reducer's first level without exceptional branches, exceptional tasks redone from a list (0 = the general kernel of rounds 1-5)
+  long long msm_tail_groups = 1; // DVP_MSM_TAIL_GROUPS: a one-shot MSM's W x c tail points are first summed in groups of 16 on many workgroups (k_tail_groups; 0 = the single-workgroup tail alone)
+  long long msm_accum_hex_max = -1;  // DVP_MSM_ACCUM_HEX_MAX: the fan-in reducer's LAST level uses a row of 16 lanes per task up to this many tasks (-1 = default, 0 = never)
   long long msm_accum_quad_max = 0;    // DVP_MSM_ACCUM_QUAD_MAX: reducer launches with at most this many tasks (upper bound) use a quad of lanes per task (0 = default)
   long long msm_bucket_pairs_max = 12;  // DVP_MSM_BUCKET_PAIRS_MAX: what the pair rounds leave goes through k_bucket_pairs / k_bucket_rest (one thread per bucket) when no bucket holds more points than this; above it, and with 0, through the fan-in-K reducer
   long long msm_sort_fused = 1;  // DVP_MSM_SORT_FUSED: level 1 of the signed flavour's sort recomputes the entry words from the scalars (0 = k_recode_signed writes them to HBM first)

@@ -241,6 +241,44 @@ GF_DEV Ld ld_add(const Ld& p, const Ld& q, const LT& L) {
   ld_add_ip(r, q, L);
   return r;
 }
+// ld_add_ip without the inlined doubling: returns false -- p untouched -- when p == q (both finite); the CALLER doubles, from a
+// copy it re-reads (as lam_add_ip's callers do): the doubling inside the addition kept all of p alive across it and cost the fan-in
+// reducer's quad flavour 364 B of scratch per lane
+template <class LT>
+GF_DEV bool ld_add_nodbl(Ld& p, const Ld& q, const LT& L) {
+  if (ld_is_inf(q)) return true;
+  if (ld_is_inf(p)) {
+    p.X = q.X; p.Y = q.Y; p.Z = q.Z;
+    return true;
+  }
+  Gf A1 = gf_mul(q.Y, gf_sqr(p.Z), L);
+  Gf A2 = gf_mul(p.Y, gf_sqr(q.Z), L);
+  Gf B1, E;
+  gf_mul2(q.X, q.Z, p.Z, L, B1, E);
+  Gf B2 = gf_mul(p.X, q.Z, L);
+  Gf C = gf_add(A1, A2);
+  Gf D = gf_add(B1, B2);
+  if (gf_is_zero(D)) {
+    if (gf_is_zero(C)) return false;
+    p.X = gf_one(); p.Y = gf_zero(); p.Z = gf_zero();
+    return true;
+  }
+  Gf Ds = gf_sqr(D);
+  Gf DB, DA;
+  gf_mul2(B1, A1, Ds, L, DB, DA);
+  Gf F, I;
+  gf_mul2(D, DB, E, L, F, I);
+  Gf G, H;
+  gf_mul2(Ds, C, F, L, G, H);
+  Gf Z3 = gf_sqr(F);
+  Gf X3 = gf_add(gf_add(gf_sqr(C), H), G);
+  I = gf_add(I, X3);
+  Gf J = gf_add(DA, X3);
+  p.Y = gf_add(gf_mul(I, H, L), gf_mul(J, Z3, L));
+  p.X = X3;
+  p.Z = Z3;
+  return true;
+}
 
 // ---- lambda-projective coordinates (Oliveira, Lopez, Aranha, Rodriguez-Henriquez 2013): (X, L, Z) with x = X / Z and
 // lambda = x + y / x = L / Z, kept in an Ld whose Y field holds L; Z == 0 is the point at infinity.  Full addition 11M + 2S against

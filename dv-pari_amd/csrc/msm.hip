@@ -782,6 +782,11 @@ constexpr unsigned EC_LDS_Q = (EC_TPB / 64) * GF_LDS_BYTES_PER_WAVE;
 constexpr uint32_t MERGE_HEX_MAX = 8192;    // additions per level up to which 16 lanes per addition win: one chip-full of rows at two waves per SIMD (measured: 0 / 4096 / 8192 -> 21.01 / 20.94 / 20.87 ms per proof)
 constexpr uint32_t MERGE_QUAD_MAX = 16384;  // additions per level up to which 4 lanes per addition win (measured: 35 us vs 41 us at 16384)
 
+// the multiplier flavours behind one name: init, and which lane of a group stores
+template <class LT> struct MergeMul;
+template <> struct MergeMul<GfLdsK> { static __device__ __forceinline__ GfLdsK init(char* l) { return gf_ldsk_init(l); } static __device__ __forceinline__ bool lead(const GfLdsK&) { return true; } };
+template <> struct MergeMul<GfLdsQ> { static __device__ __forceinline__ GfLdsQ init(char* l) { return gf_ldsq_init(l); } static __device__ __forceinline__ bool lead(const GfLdsQ& c) { return c.r == 0; } };
+template <> struct MergeMul<GfLdsH> { static __device__ __forceinline__ GfLdsH init(char* l) { return gf_ldsh_init(l); } static __device__ __forceinline__ bool lead(const GfLdsH& c) { return c.r == 0; } };
 // ---- segmented reduction by fan-in K ----------------------------------------------------------------
 // largest key with toff[key] <= tid (toff has nkeys+1 entries, toff[nkeys] = total > tid)
 __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t tid) {
@@ -797,6 +802,7 @@ __device__ __forceinline__ uint32_t find_key(const uint32_t* __restrict__ toff, 
 // of one rank of an 8-way split -- has fewer reducer tasks than the chip has lanes and its fan-in-K chains are pure
 // latency: 2.2x shorter per addition this way (the same trade k_merge<true> makes for the deep merge levels).
 constexpr uint32_t ACCUM_QUAD_MAX = 49152;  // tasks: 4 lanes each = one chip-full of 3 blocks per CU
+constexpr uint32_t ACCUM_HEX_MAX = 32768;   // tasks of the reducer's last level up to which 16 lanes per task win
 template <bool INDIRECT, bool QUAD>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
@@ -840,30 +846,111 @@ k_accum_affine(const Aff* __restrict__ bases, const uint32_t* __restrict__ items
   }
 }
 
-template <bool QUAD>
+// The same tasks without the exceptional branches (round 6; what k_bucket_pairs does for the fixed-base sizes): the first two entries
+// are two AFFINE points (ld_add_aff_aff: Z1 = 1, 5M + 3S instead of 8M + 5S), the others go through ld_madd_fast; a task that meets
+// an exceptional pair -- an infinity marker first, equal x -- goes on a list that k_accum_affine_rest redoes with the general
+// formulas.  The general kernel kept the accumulator's exceptional paths alive on every lane: 253 VGPRs and 312-444 B of scratch
+// per lane at two waves per SIMD.
+template <bool INDIRECT, bool QUAD>
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_accum_affine_fast(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
+                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
+                    Ld* __restrict__ out, uint32_t sign_mask, uint32_t* __restrict__ rest_n, uint32_t* __restrict__ rest) {
+  extern __shared__ char lds_raw[];
+  using LT = typename std::conditional<QUAD, GfLdsQ, GfLdsK>::type;
+  LT L = MergeMul<LT>::init(lds_raw);
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (QUAD) tid >>= 2;
+  if (tid >= toff[nkeys]) return;
+  const uint32_t key = find_key(toff, nkeys, tid);
+  const uint32_t j = tid - toff[key];
+  const uint32_t start = off[key] + j * K;
+  const uint32_t len = min(K, cnt[key] - j * K);
+  auto point = [&](uint32_t t) -> Aff {
+    if (!INDIRECT) return bases[start + t];
+    const uint32_t v = items[start + t];
+    Aff q = bases[v & ~sign_mask];
+    if (v & sign_mask) q.y = gf_add(q.y, q.x);
+    return q;
+  };
+  const Aff first = point(0);
+  bool ok = INDIRECT || !gf_is_zero(first.x);
+  Ld acc = ld_from_aff(first);
+  if (ok && len > 1) {
+    const Aff q = point(1);
+    ok = (INDIRECT || !gf_is_zero(q.x)) && !gf_eq(first.x, q.x);
+    if (ok) ld_add_aff_aff(first, q, acc, L);
+  }
+#pragma unroll 1
+  for (uint32_t t = 2; t < len && ok; ++t) {
+    const Aff q = point(t);
+    if (!INDIRECT && gf_is_zero(q.x)) continue;
+    ok = ld_madd_fast(acc, q, L);
+  }
+  if (!MergeMul<LT>::lead(L)) return;
+  if (ok)
+    out[tid] = acc;
+  else
+    rest[atomicAdd(rest_n, 1u)] = tid;
+}
+// the listed tasks again, general formulas (one thread per task)
+template <bool INDIRECT>
+__global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_accum_affine_rest(const Aff* __restrict__ bases, const uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt,
+                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K,
+                    Ld* __restrict__ out, uint32_t sign_mask, const uint32_t* __restrict__ rest_n, const uint32_t* __restrict__ rest) {
+  extern __shared__ char lds_raw[];
+  GfLdsK L = gf_ldsk_init(lds_raw);
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *rest_n) return;
+  const uint32_t tid = rest[r];
+  const uint32_t key = find_key(toff, nkeys, tid);
+  const uint32_t j = tid - toff[key];
+  const uint32_t start = off[key] + j * K;
+  const uint32_t len = min(K, cnt[key] - j * K);
+  auto point = [&](uint32_t t) -> Aff {
+    if (!INDIRECT) return bases[start + t];
+    const uint32_t v = items[start + t];
+    Aff q = bases[v & ~sign_mask];
+    if (v & sign_mask) q.y = gf_add(q.y, q.x);
+    return q;
+  };
+  const Aff first = point(0);
+  Ld acc = (!INDIRECT && gf_is_zero(first.x)) ? ld_infinity() : ld_from_aff(first);
+#pragma unroll 1
+  for (uint32_t t = 1; t < len; ++t) {
+    const Aff q = point(t);
+    if (!INDIRECT && gf_is_zero(q.x)) continue;
+    ld_madd_ip(acc, q, L);
+  }
+  out[tid] = acc;
+}
+
+// GROUP = lanes per task: 1, 4 (a quad) or 16 (a DPP row: the last level of a small MSM -- one or two additions per bucket, fewer
+// tasks than the chip has rows -- is pure latency, and the sixteen-lane product is ~290 instructions against the quad's ~450)
+template <int GROUP>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_accum_proj(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
              const uint32_t* __restrict__ toff, uint32_t nkeys, uint32_t K, Ld* __restrict__ out) {
   extern __shared__ char lds_raw[];
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (QUAD) tid >>= 2;
+  tid /= (uint32_t)GROUP;
   if (tid >= toff[nkeys]) return;
   uint32_t key = find_key(toff, nkeys, tid);
   uint32_t j = tid - toff[key];
   uint32_t start = off[key] + j * K;
   uint32_t len = min(K, cnt[key] - j * K);
   Ld acc = in[start];
-  if (QUAD) {
-    GfLdsQ L = gf_ldsq_init(lds_raw);
+  using LT = typename std::conditional<GROUP == 16, GfLdsH, typename std::conditional<GROUP == 4, GfLdsQ, GfLdsK>::type>::type;
+  LT L = MergeMul<LT>::init(lds_raw);
 #pragma unroll 1
-    for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
-    if (L.r == 0) out[tid] = acc;
-  } else {
-    GfLdsK L = gf_ldsk_init(lds_raw);
-#pragma unroll 1
-    for (uint32_t t = 1; t < len; ++t) ld_add_ip(acc, in[start + t], L);
-    out[tid] = acc;
+  for (uint32_t t = 1; t < len; ++t) {
+    if (!ld_add_nodbl(acc, in[start + t], L)) {  // acc == the entry: double a copy read back
+      acc = in[start + t];
+      acc = ld_dbl(acc, L);
+    }
   }
+  if (MergeMul<LT>::lead(L)) out[tid] = acc;
 }
 
 // ---- what the pair rounds leave, one thread per BUCKET (fixed-base sizes: the rounds stop with 1-4 points per bucket) ----
@@ -1419,10 +1506,6 @@ k_bucket_gather(const Ld* __restrict__ in, const uint32_t* __restrict__ cnt, con
 // k_tail converts what it reads back to Lopez-Dahab (1M) for its doublings.
 // GROUP = lanes per addition: 1 (wide levels, Karatsuba multiplier), 4 (a quad, <= MERGE_QUAD_MAX additions) or 16 (a DPP row,
 // <= MERGE_HEX_MAX additions: the deepest levels are pure latency and a lone wave pays per instruction, gf233.cuh)
-template <class LT> struct MergeMul;
-template <> struct MergeMul<GfLdsK> { static __device__ __forceinline__ GfLdsK init(char* l) { return gf_ldsk_init(l); } static __device__ __forceinline__ bool lead(const GfLdsK&) { return true; } };
-template <> struct MergeMul<GfLdsQ> { static __device__ __forceinline__ GfLdsQ init(char* l) { return gf_ldsq_init(l); } static __device__ __forceinline__ bool lead(const GfLdsQ& c) { return c.r == 0; } };
-template <> struct MergeMul<GfLdsH> { static __device__ __forceinline__ GfLdsH init(char* l) { return gf_ldsh_init(l); } static __device__ __forceinline__ bool lead(const GfLdsH& c) { return c.r == 0; } };
 template <int GROUP, bool FIRST>
 __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GROUP > 1 ? 1 : 2, 2))) k_merge(Ld* __restrict__ A, int j, uint32_t total /* nblocks*(j+1) */, Ld* __restrict__ save0 /* FIRST: where bucket 0 is kept as it was (or nullptr) */) {
   using LT = typename std::conditional<GROUP == 1, GfLdsK, typename std::conditional<GROUP == 4, GfLdsQ, GfLdsH>::type>::type;
@@ -1448,6 +1531,59 @@ __global__ void __launch_bounds__(EC_TPB) __attribute__((amdgpu_waves_per_eu(GRO
     lam_dbl_ip(l, L);
   }
   if (lead) A[base + s] = l;
+}
+
+// Round 6, one-shot MSMs (W windows x c points = 240 at 2^16 points): the Frobenius powers and the first four levels of the add tree
+// on MANY workgroups -- a workgroup takes 16 consecutive points, one row of 16 lanes each (the sixteen-lane product, ~290 instructions
+// against the quad's ~450), and leaves their sum in part[blockIdx.x]; k_tail then adds the <= 16 group sums (n_narrow == -4) and
+// converts.  The single-workgroup tail walked 120 + 60 + 30 + 15 additions in passes of 64 quads: 218 us of its own at 2^16 points.
+// The sum is the same group element in another order: the affine result and its encoding are unchanged bit for bit.
+__global__ void __launch_bounds__(EC_TPB) k_tail_groups(const Ld* __restrict__ A, int c, int W, int n_narrow, GfSqrTables T, Ld* __restrict__ buf /* 2 W c */,
+                                                        Ld* __restrict__ part) {
+  extern __shared__ char lds_raw[];
+  GfLdsH H = gf_ldsh_init(lds_raw);
+  const uint32_t cnt0 = (uint32_t)(W * c), g0 = blockIdx.x * 16u;
+  const uint32_t cntl = min(16u, cnt0 - g0);
+  Ld* in = buf + g0;
+  Ld* out = buf + cnt0 + g0;
+  {
+    const uint32_t row = threadIdx.x >> 4;
+    if (row < cntl) {  // whole rows together
+      const uint32_t tid = g0 + row;
+      const uint32_t w = tid / (uint32_t)c, t = tid - w * (uint32_t)c;
+      const int k = (int)(w * (uint32_t)c) - min((int)w, n_narrow) + (int)t;
+      Ld p = A[((size_t)w << c) + 1 + t];
+      lam_to_ld(p, H);  // lambda-projective (the merge tree's output) -> Lopez-Dahab: Y = X (L + X)
+      // the three coordinates' Frobenius powers side by side: the 16 lanes of the row hold the same point, lanes 0-4 / 5-9 / 10-15 take
+      // X / Y / Z through the table passes (a serial chain of L2 round trips each) and the row gathers them again
+      const uint32_t sel = H.r < 5u ? 0u : (H.r < 10u ? 1u : 2u);
+      Gf v = sel == 0u ? p.X : (sel == 1u ? p.Y : p.Z);
+      v = gf_sqr_n_fast(v, k, T);
+      const int lane0 = (int)(threadIdx.x & 63u) - (int)H.r;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        p.X.w[q] = (uint32_t)__shfl((int)v.w[q], lane0);
+        p.Y.w[q] = (uint32_t)__shfl((int)v.w[q], lane0 + 5);
+        p.Z.w[q] = (uint32_t)__shfl((int)v.w[q], lane0 + 10);
+      }
+      if (H.r == 0) in[row] = p;
+    }
+  }
+  __syncthreads();
+  uint32_t cnt = cntl;
+  while (cnt > 1) {
+    const uint32_t half = (cnt + 1) / 2;
+    const uint32_t i = threadIdx.x >> 4;
+    if (i < half) {
+      Ld a = in[2 * i];
+      if (2 * i + 1 < cnt) ld_add_ip(a, in[2 * i + 1], H);
+      if (H.r == 0) out[i] = a;
+    }
+    __syncthreads();
+    Ld* t = in; in = out; out = t;
+    cnt = half;
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = in[0];
 }
 
 // The whole Frobenius tail of an MSM in ONE single-workgroup launch: E[w*c+t] = tau^k(A[w*2^c + 1 + t]) with k = the first
@@ -1477,7 +1613,9 @@ __global__ void __launch_bounds__(EC_TPB) k_tail(const Ld* __restrict__ A, int c
   const uint32_t cnt0 = (uint32_t)(W * c);
   Ld* in = buf;
   Ld* out = buf + cnt0;
-  if (n_narrow == -3) {
+  if (n_narrow == -4) {
+    // the cnt0 points are in buf already (the group sums of k_tail_groups, Frobenius powers applied): only the tree and the conversion
+  } else if (n_narrow == -3) {
     // signed aligned windows: t doublings of A[1 + t], one point per quad of lanes (a serial chain of <= c - 1 doublings at
     // 3 products + 5 squarings each); the last point is bucket 0 (the digits of magnitude 2^(c-1); saved at buf[2 cnt0] before
     // the merge turned slot 0 into the total)
@@ -1883,7 +2021,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       if (attr_err == hipSuccess)
         attr_err = hipFuncSetAttribute((const void*)k_scatter_local2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, FX_STAGE2_LDS);
       const void* ec[] = {(const void*)k_accum_affine<true, false>, (const void*)k_accum_affine<false, false>, (const void*)k_accum_affine<true, true>,
-                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<false>, (const void*)k_accum_proj<true>, (const void*)k_merge<1, false>, (const void*)k_merge<4, false>, (const void*)k_merge<16, false>, (const void*)k_merge<1, true>, (const void*)k_merge<4, true>, (const void*)k_merge<16, true>,
+                          (const void*)k_accum_affine<false, true>, (const void*)k_accum_proj<1>, (const void*)k_accum_proj<4>, (const void*)k_accum_proj<16>,
+                          (const void*)k_accum_affine_fast<true, false>, (const void*)k_accum_affine_fast<false, false>, (const void*)k_accum_affine_fast<true, true>,
+                          (const void*)k_accum_affine_fast<false, true>, (const void*)k_accum_affine_rest<true>, (const void*)k_accum_affine_rest<false>,
+                          (const void*)k_tail_groups, (const void*)k_merge<1, false>, (const void*)k_merge<4, false>, (const void*)k_merge<16, false>, (const void*)k_merge<1, true>, (const void*)k_merge<4, true>, (const void*)k_merge<16, true>,
                           (const void*)k_affine_round<true, false>, (const void*)k_affine_round<false, false>, (const void*)k_affine_round<true, true>,
                           (const void*)k_affine_round<false, true>, (const void*)k_sum_points, (const void*)k_tail<false>, (const void*)k_tail<true>,
                           (const void*)k_bucket_pairs, (const void*)k_bucket_rest};
@@ -1974,8 +2115,11 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_rp = carve(pipelined ? (size_t)ra_plan * 2 * ((size_t)p.nkeys + 1) * 4 : 16);  // (counts, offsets) of rounds 1 .. ra_plan
   size_t o_bsum2 = carve(((size_t)((ra_plan > 0 ? ra_plan : 1) + 1) * ((size_t)p.nkeys / SCAN_BLK + 1) + 8) * 4);  // scan scratch of the side stream: a row of block sums per round
   size_t o_bkt = carve((size_t)p.nkeys * sizeof(Ld));
-  size_t o_rest = carve(((size_t)p.nkeys + 1) * 4);  // k_bucket_pairs' list of buckets with more than two entries
-  size_t o_tail = carve(((size_t)2 * p.W * p.c + 1) * sizeof(Ld));
+  // k_bucket_pairs' list of buckets that met an exceptional pair (<= nkeys), or k_accum_affine_fast's list of such TASKS (chunks of K entries)
+  const size_t rest_cap = (size_t)p.nkeys + 2 + p.e_max / (size_t)(p.K > 0 ? p.K : 1);
+  size_t o_rest = carve(rest_cap * 4);
+  const uint32_t tail_groups = ((uint32_t)(p.W * p.c) + 15u) / 16u;  // k_tail_groups: workgroups of 16 points
+  size_t o_tail = carve(((size_t)2 * p.W * p.c + 1 + 2 * (size_t)tail_groups) * sizeof(Ld));
   DVP_TRY(g_ws.ensure(o, g_ws_need[cur_dev]));
   char* base = (char*)g_ws.p;
   auto* err = (unsigned long long*)(base + o_err);
@@ -2291,10 +2435,23 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
     size_t tmax = cap / p.K + nk + 1;
     const size_t accum_quad_max = tn.msm_accum_quad_max > 0 ? (size_t)tn.msm_accum_quad_max : ACCUM_QUAD_MAX;
+    const size_t accum_hex_max = tn.msm_accum_hex_max >= 0 ? (size_t)tn.msm_accum_hex_max : ACCUM_HEX_MAX;
     // tmax is an upper bound on the tasks (the real count sits on the device); quads when even the bound fits one chip-full
+    // (the rest list holds task numbers: tmax of them at most; the bucket-pair list's room is nk entries and tmax can exceed it, so
+    // the fast flavour runs only where the list is sure to fit.  Tune::msm_accum_fast = 0: the general kernel of rounds 1-5)
+    const bool accum_fast = tn.msm_accum_fast != 0 && tmax <= rest_cap;
 #define DVP_ACCUM_AFFINE(IND)                                                                                                                  \
   do {                                                                                                                                         \
-    if (tmax <= accum_quad_max)                                                                                                                \
+    if (accum_fast) {                                                                                                                          \
+      if (tmax <= accum_quad_max)                                                                                                              \
+        hipLaunchKernelGGL((k_accum_affine_fast<IND, true>), dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, pts_in, items, pc[cur], \
+                           po[cur], po[nxt], nk, p.K, bufA, sign_mask, rest_n, rest_list);                                                    \
+      else                                                                                                                                     \
+        hipLaunchKernelGGL((k_accum_affine_fast<IND, false>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur],      \
+                           po[cur], po[nxt], nk, p.K, bufA, sign_mask, rest_n, rest_list);                                                    \
+      hipLaunchKernelGGL((k_accum_affine_rest<IND>), dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, pts_in, items, pc[cur], po[cur],       \
+                         po[nxt], nk, p.K, bufA, sign_mask, rest_n, rest_list);                                                                \
+    } else if (tmax <= accum_quad_max)                                                                                                         \
       hipLaunchKernelGGL((k_accum_affine<IND, true>), dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, pts_in, items, pc[cur], po[cur], \
                          po[nxt], nk, p.K, bufA, sign_mask);                                                                                   \
     else                                                                                                                                       \
@@ -2315,10 +2472,14 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       nxt = (cur + 1) % 3;
       DVP_TRY(scan_exclusive_div(pc[cur], p.K, pc[nxt], po[nxt], nk, bsum, st));
       tmax = cap / p.K + nk + 1;
-      if (tmax <= accum_quad_max)
-        hipLaunchKernelGGL(k_accum_proj<true>, dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
+      // the LAST level of a small MSM (every bucket ends with one task of at most K partial sums, typically one or two): rows of 16
+      // lanes when the tasks fit ACCUM_HEX_MAX (measured at 2^16 points, round 6)
+      if (left <= p.K && tmax <= accum_hex_max)
+        hipLaunchKernelGGL(k_accum_proj<16>, dim3(cdiv(16 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
+      else if (tmax <= accum_quad_max)
+        hipLaunchKernelGGL(k_accum_proj<4>, dim3(cdiv(4 * tmax, EC_TPB)), dim3(EC_TPB), EC_LDS_Q, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
       else
-        hipLaunchKernelGGL(k_accum_proj<false>, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
+        hipLaunchKernelGGL(k_accum_proj<1>, dim3(cdiv(tmax, EC_TPB)), dim3(EC_TPB), EC_LDS, st, in, pc[cur], po[cur], po[nxt], nk, p.K, outb);
       cap = tmax;
       cur = nxt;
       Ld* t = in; in = outb; outb = t;
@@ -2343,11 +2504,17 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   const int w_tail = fx ? 1 : p.W;  // fixed-base mode has a single bucket set
   uint32_t cntT = (uint32_t)(w_tail * p.c);
   Ld* ta = tail;  // 2 * cntT entries: the two halves of k_tail's ping-pong
-  (void)cntT;
   if (sign_mask && tn.msm_hex_max != 0)  // c points: one row of 16 lanes each
     hipLaunchKernelGGL(k_tail<true>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, -3, Tsq, ta, (uint32_t*)d_out_xy, (uint32_t*)d_out_inf,
                        (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, err, d_err_defer);
-  else
+  else if (!sign_mask && cntT > 32 && tn.msm_tail_groups != 0) {
+    // many points (the one-shot MSM's W x c): group sums on cdiv(cntT, 16) workgroups first, then the single-workgroup tail on those
+    Ld* part = tail + 2 * (size_t)cntT + 1;
+    const int nparts = (int)cdiv(cntT, 16);
+    hipLaunchKernelGGL(k_tail_groups, dim3(nparts), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, fx ? 0 : p.n_narrow, Tsq, ta, part);
+    hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, nparts, 1, -4, Tsq, part, (uint32_t*)d_out_xy,
+                       (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, err, d_err_defer);
+  } else
     hipLaunchKernelGGL(k_tail<false>, dim3(1), dim3(EC_TPB), EC_LDS_Q, st, bkt, p.c, w_tail, sign_mask ? -3 : (fx ? 0 : p.n_narrow), Tsq, ta, (uint32_t*)d_out_xy,
                        (uint32_t*)d_out_inf, (uint8_t*)d_out_enc, d_out_enc ? dvp_codec_get_rule() : 0, err, d_err_defer);
   ps_tail.stop();
