@@ -1934,8 +1934,11 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   // 2^15 .. 2^17 points are latency all the way (config #2: ~45 dependent launches): with the round-4 chains (lambda-projective merge,
   // 16 lanes per product in the deep levels and the tail) two merge levels fewer beat the model's window -- tools/small_msm_sweep.py,
   // c = 10 / K = 8 against the model's c = 12 / K = 4: 1.43 against 1.63 ms at 2^16, 1.82 against 2.02 ms at 2^17 (2^14 and 2^18: no difference)
-  const bool small_latency = !fixed && n >= ((size_t)1 << 15) && n <= ((size_t)1 << 17);
+  // Round 6 (tools/small_msm_ck.py, after the tail's group sums and the reducer's cheaper levels): the same holds at 2^18 (c = 10 / K = 8:
+  // 2.04 against 2.21 ms), and 2^19 points want c = 13 where the model says 14 (3.17 against 3.43 ms); 2^14 and 2^20 are flat
+  const bool small_latency = !fixed && n >= ((size_t)1 << 15) && n <= ((size_t)1 << 18);
   if (small_latency) p.c = 10;
+  if (!fixed && n > ((size_t)1 << 18) && n <= ((size_t)1 << 19)) p.c = 13;
   if (tune().msm_c >= 2 && tune().msm_c <= 15) p.c = (int)tune().msm_c;
   p.W = windows(p.c, &p.n_narrow);
   p.nkeys = (uint32_t)p.W << p.c;
@@ -1954,6 +1957,7 @@ static MsmPlan msm_plan(size_t n, const MsmFixedCtx* fx) {
   // 5-10 % faster with three additions per task than with seven (tools/small_msm_sweep.py)
   if (!fixed && n <= ((size_t)1 << 18)) K = 4;
   if (small_latency) K = 8;
+  if (!fixed && n > ((size_t)1 << 18) && n <= ((size_t)1 << 19)) K = 8;
   // fixed-base mode: the reducer only sees what the pair rounds leave (<= ~20 entries in the fullest buckets) and is pure
   // chain latency there: two levels of <= 7 additions beat one of <= 15 (2^20 prove: 24.26 against 24.58 ms)
   if (fixed) K = 8;
