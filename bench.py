@@ -129,6 +129,8 @@ def headline(full, detail_path=None):
                                     "vs_baseline", "dtype", "data")}
     out["config"] = _pick(cfg, ("workload", "log2_constraints", "n_wires", "msm_pairs_per_proof", "witness", "entry", "proofs_in_flight",
                                 "ms_per_step_one_shot_msm", "cold_call_s"))
+    if isinstance(cfg.get("msm_windows"), dict):
+        out["config"]["msm_windows"] = {k: _pick(v, ("c_bits", "windows", "table_gb")) for k, v in cfg["msm_windows"].items()}
     if isinstance(cfg.get("sharding"), str):
         out["config"]["sharding"] = cfg["sharding"][:120]
     out["roofline"] = {"kernel": str(roof.get("kernel", ""))[:64], "bound": roof.get("bound"), "achieved": roof.get("achieved"), "peak": roof.get("peak"),

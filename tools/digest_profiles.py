@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "refresh")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 
 
 def one(pattern):
@@ -26,7 +26,8 @@ def last_json_line(path):
     return json.loads(lines[-1])
 
 
-shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench_prove2p20.json"))
+shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, f"{tag}_bench_prove2p20.json"))  # the ONE line (<= 6 KB)
+shutil.copy(os.path.join(SRC, "bench_detail.json"), os.path.join(DST, f"{tag}_bench_detail.json"))  # its sidecar: everything the run measured
 shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, f"{tag}_bench_prove2p20_under_rocprof.json"))
 shutil.copy(one("stats/**/*kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_prove2p20_kernel_stats.csv"))
 try:
@@ -70,7 +71,7 @@ def avg(ds, key):
 
 fetch = round0_dispatches("pmc_fetch")
 write = round0_dispatches("pmc_write")
-b = last_json_line(os.path.join(SRC, "bench.json"))
+b = json.load(open(os.path.join(SRC, "bench_detail.json")))  # (the line itself carries the headline only since round 6)
 alg = b["roofline"]["algorithmic_bytes_per_launch"]
 f_kb, w_kb = avg(fetch, "FETCH_SIZE"), avg(write, "WRITE_SIZE")
 traffic = {

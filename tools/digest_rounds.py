@@ -20,7 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "refresh")
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r05"
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r06"
 DST = os.path.join(ROOT, "profiles")
 N_CU, N_SIMD = 256, 1024
 
@@ -49,10 +49,12 @@ def last_proof(seq):
 def by_round():
     tcc, tcc2, wr, sq = (dispatches(n) for n in ("pmc_tcc", "pmc_tcc2", "pmc_wr", "pmc_sq"))
     bench = None
-    for cand in ("pmc_sq.json", "pmc_tcc.json"):
+    for cand in ("pmc_sq_detail.json", "bench_detail.json", "pmc_sq.json", "pmc_tcc.json"):
         try:
-            lines = [l for l in open(os.path.join(SRC, cand)).read().splitlines() if l.startswith("{")]
-            bench = json.loads(lines[-1])
+            txt = open(os.path.join(SRC, cand)).read()
+            bench = json.loads(txt) if cand.endswith("_detail.json") else json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+            if "msm_windows" not in bench.get("config", {}):
+                continue
             break
         except Exception:
             continue
@@ -170,8 +172,17 @@ def configs():
             open(os.path.join(DST, f"{TAG}_{dst}.log"), "w").writelines(keep)
 
 
+def config3_steady():
+    for src, dst in (("ecfft20_steady.txt", "config3_ecfft_2p20_steady_state.txt"), ("ecfft20_steady_enter_kernel_stats.csv", "config3_ecfft_2p20_steady_enter_kernel_stats.csv"),
+                     ("ecfft20_steady_exit_kernel_stats.csv", "config3_ecfft_2p20_steady_exit_kernel_stats.csv")):
+        if os.path.exists(os.path.join(SRC, src)):
+            shutil.copy(os.path.join(SRC, src), os.path.join(DST, f"{TAG}_{dst}"))
+
+
 if __name__ == "__main__":
     want = sys.argv[3:] or ["by_round", "gather64", "configs"]
+    if "configs" in want:
+        config3_steady()
     for fn in [f for f in (by_round, gather64, configs) if f.__name__ in want]:
         try:
             fn()

@@ -17,4 +17,9 @@ for name, (a, b) in (("enter", (marks[-3], marks[-2])), ("exit", (marks[-2], mar
         a_[0] += 1; a_[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     for k, (cnt, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"   {k:40s} {cnt:4d} {ns / 1e3:9.1f} us  avg {ns / cnt / 1e3:7.1f}")
+    with open(os.path.join(d, f"steady_{name}_kernel_stats.csv"), "w", newline="") as fo:  # one steady-state call, no bootstrap launches
+        w = csv.writer(fo)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for k, (cnt, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, cnt, ns, f"{ns / cnt:.1f}", f"{100.0 * ns / busy:.2f}"])
     print("   in order (us):", " ".join(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.0f}" for r in seg))

@@ -10,6 +10,7 @@ rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
 python3 tools/profile_stamp.py > $OUT/source_sha16.txt   # which kernel sources these profiles are taken at (bench.py compares)
 DVP_BENCH_WRITE_PROFILE=1 timeout -k 10 600 python3 bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+cp $ROOT/gpurun_out/bench_detail.json $OUT/bench_detail.json   # the sidecar of that line (everything the run measured)
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
@@ -22,6 +23,7 @@ echo "pmc fetch done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --in-flight 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write done"
 timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o q --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --extras ubench > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err || echo "pmc sq pass failed (see pmc_sq.err)"
+cp $ROOT/gpurun_out/bench_detail.json $OUT/pmc_sq_detail.json || true
 echo "pmc sq done"
 # request-level view of the same launches (resolves FETCH_SIZE's request-size ambiguity): read requests of the L2's memory side, how many
 # of them are 32-byte ones, and the L2 hit / miss split.  Counter names differ between ROCm builds: the list is saved first.

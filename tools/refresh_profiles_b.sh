@@ -11,6 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/refresh_b
 rm -rf $OUT && mkdir -p $OUT
 cd $ROOT
+mkdir -p $ROOT/scratch
 G=$ROOT/scratch/gather64
 [ -x $G ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o $G tools/ubench/gather64.hip
 timeout -k 10 120 $G 3 > $OUT/gather64_rates.log 2>&1
@@ -26,6 +27,11 @@ done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/ecfft20 -o e --output-format csv -- python3 $ROOT/tools/ecfft_bench.py 20 > $OUT/ecfft20.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/sparse22 -o s --output-format csv -- python3 $ROOT/tools/sparse_bench.py 22 8 > $OUT/sparse22.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/setup20 -o s --output-format csv -- python3 $ROOT/tools/setup_time.py 20 > $OUT/setup20.log 2>&1
+# config #3 again as ONE steady-state enter and ONE steady-state exit (the table bootstrap runs before the markers): per-launch durations
+bash $ROOT/tools/ecfft_trace.sh > $OUT/ecfft20_steady.txt 2>&1 || echo "steady-state ecfft trace failed"
+cp $ROOT/gpurun_out/ecfft_trace/steady_enter_kernel_stats.csv $OUT/ecfft20_steady_enter_kernel_stats.csv || true
+cp $ROOT/gpurun_out/ecfft_trace/steady_exit_kernel_stats.csv $OUT/ecfft20_steady_exit_kernel_stats.csv || true
+cd /tmp
 echo "config stats done"
 python3 - <<PY
 import glob, os
