@@ -43,4 +43,4 @@ PY
 for d in g64_tcc g64_tcc2 g64_fetch ecfft20 sparse22 setup20; do rm -rf $OUT/$d; done
 ls -la $OUT
 cat $OUT/g64_tcc_digest.txt
-tail -2 $OUT/ecfft20.log $OUT/sparse22.log; tail -8 $OUT/setup20.log
+for f in $OUT/ecfft20.log $OUT/sparse22.log; do tail -n 2 $f; done; tail -n 8 $OUT/setup20.log
