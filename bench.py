@@ -162,7 +162,7 @@ def headline(full, detail_path=None):
     if by:
         out["roofline_by_config"] = by
     out.update(_pick(full, ("hbm_resident_gb", "tables_gb", "ms_per_step_host_witness", "msm_mpoints_per_s", "host_waits_per_proof", "scaling_measured",
-                            "rccl_ranks", "backend", "ms_per_step_ranks", "ms_per_step_inproc", "inproc_error", "replicas")))
+                            "rccl_ranks", "backend", "ms_per_step_ranks", "ms_per_step_inproc", "inproc_error", "replicas", "replicas_error")))
     tif = full.get("throughput_two_in_flight")
     if isinstance(tif, dict) and "constraints_per_s" in tif:
         out["throughput_two_in_flight"] = _pick(tif, ("ms_per_proof", "constraints_per_s"))
@@ -395,23 +395,40 @@ def main():
         # the OTHER way to use N GPUs (what DESIGN 7 recommends for throughput): N independent provers, one per rank, no data-path
         # collective -- measured here, outside the timed loop, between two barriers; max over ranks
         if os.environ.get("DVP_BENCH_NO_REPLICAS") != "1":
-            own_proof = pv.prove_dev(assignment.data_ptr(), stream)  # rebuilds this rank's full fixed-base tables (untimed)
-            assert own_proof == proof, "a rank's own proof differs from the sharded one"
+            # an extra: a failure on any rank is reported in the line (replicas_error), never raised -- every rank keeps taking part in
+            # the barriers and the all-gather below whatever happened to its own proofs
+            rep_err = 0.0
             k_rep = max(2, min(args.steps, 10))
+            try:
+                own_proof = pv.prove_dev(assignment.data_ptr(), stream)  # rebuilds this rank's full fixed-base tables (untimed)
+                if own_proof != proof:
+                    rep_err = 2.0
+            except Exception as ex:
+                log(f"[bench] rank {rank}: replicas leg: {ex!r}")
+                rep_err = 1.0
             dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(k_rep):
-                pv.prove_dev(assignment.data_ptr(), stream)
-            torch.cuda.synchronize()
+            if not rep_err:
+                try:
+                    for _ in range(k_rep):
+                        pv.prove_dev(assignment.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                except Exception as ex:
+                    log(f"[bench] rank {rank}: replicas leg: {ex!r}")
+                    rep_err = 1.0
             own_rep = time.perf_counter() - t1
             dist.barrier()
-            t = torch.tensor([time.perf_counter() - t1, own_rep], dtype=torch.float64, device=dev)
+            t = torch.tensor([time.perf_counter() - t1, own_rep, rep_err], dtype=torch.float64, device=dev)
             allt = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(allt, t)
-            rep_elapsed = max(float(x[0].item()) for x in allt)
-            dist_info["replicas"] = {"n": world, "proofs_each": k_rep, "constraints_per_s": m * k_rep * world / rep_elapsed,
-                                     "ms_per_proof_each": [float(x[1].item()) / k_rep * 1e3 for x in allt]}
+            bad_ranks = [r_ for r_, x in enumerate(allt) if float(x[2].item()) != 0.0]
+            if bad_ranks:
+                dist_info["replicas_error"] = {"ranks": bad_ranks, "codes": [float(allt[r_][2].item()) for r_ in bad_ranks]}
+            else:
+                rep_elapsed = max(float(x[0].item()) for x in allt)
+                dist_info["replicas"] = {"n": world, "proofs_each": k_rep, "constraints_per_s": m * k_rep * world / rep_elapsed,
+                                         "ms_per_proof_each": [float(x[1].item()) / k_rep * 1e3 for x in allt]}
     if world > 1:
         # release this rank's GPU before the in-library measurement: every rank drops its prover and leaves the group
         del gpu_backend
