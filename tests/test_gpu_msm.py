@@ -261,6 +261,13 @@ def test_bucket_reduction_exceptional_pairs(dvp):
                     assert np_to_pt(*fb.run(s)) == exp, (c, aff_min, pairs_max)
                     assert np_to_pt(*fb.run(s[lo:hi], lo, hi)) == exp_part, (c, aff_min, pairs_max)
                     assert gpu_msm(dvp, s, bases) == exp, (c, aff_min, pairs_max)
+                if pairs_max == 0:
+                    # round 6: the reducer's first level without exceptional branches + its rest list (k_accum_affine_fast / _rest), its last
+                    # level on rows of 16 lanes, ld_add_nodbl's doubling from a copy, the one-shot tail's group sums -- each switched off in turn
+                    for knob in ("DVP_MSM_ACCUM_FAST", "DVP_MSM_ACCUM_HEX_MAX", "DVP_MSM_TAIL_GROUPS"):
+                        with dvp.tune(DVP_MSM_AFF_MIN=aff_min, DVP_MSM_BUCKET_PAIRS_MAX=0, DVP_MSM_C=c, **{knob: 0}):
+                            assert np_to_pt(*fb.run(s)) == exp, (c, aff_min, knob)
+                            assert gpu_msm(dvp, s, bases) == exp, (c, aff_min, knob)
         fb.close()
 
 
