@@ -118,6 +118,33 @@ def test_bench_self_launch_rehearsal(dvp):
     assert rep["n"] == n and rep["constraints_per_s"] > 0 and len(rep["ms_per_proof_each"]) == n
 
 
+def test_bench_replicas_mode_rehearsal(dvp):
+    """`python bench.py --gpus N --replicas`: N independent provers, one whole proof per rank and step, no data-path collective --
+    the throughput mode DESIGN 7 recommends for N GPUs.  Rehearsed with two ranks on cuda:0 over gloo: the line says weak scaling,
+    `value` is the aggregate of the ranks, and no sharded-mode keys (shard plan, in-library leg) are produced."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, DVP_BENCH_SHARE_GPU="1", DVP_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--replicas", "--steps", "3", "--warmup", "1", "--log-m", "12"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 6000
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["rccl_ranks"] == 2 and "replicas" in d["config"]["sharding"]
+    rep = d["replicas"]
+    assert rep["n"] == 2 and len(rep["ms_per_proof_each"]) == 2
+    # value = the ranks' proofs together over the slowest rank's time: between one and two ranks' own rates
+    own = [(1 << 12) / (ms * 1e-3) for ms in rep["ms_per_proof_each"]]
+    assert 0.5 * min(own) < d["value"] <= 2.05 * max(own), (d["value"], own)
+    assert "ms_per_step_inproc" not in d and "replicas_error" not in d
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert "shard_plan" not in full
+
+
 @pytest.mark.parametrize("world", [2])
 def test_two_ranks_over_rccl_same_bytes(dvp, world):
     if _n_gpus(dvp) < world:
