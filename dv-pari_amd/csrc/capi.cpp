@@ -73,6 +73,7 @@ static void tune_from_env(Tune& t) {
   t.msm_accum_fast = geti("DVP_MSM_ACCUM_FAST", t.msm_accum_fast);
   t.msm_tail_groups = geti("DVP_MSM_TAIL_GROUPS", t.msm_tail_groups);
   t.msm_accum_hex_max = geti("DVP_MSM_ACCUM_HEX_MAX", t.msm_accum_hex_max);
+  t.gf_inv_tabs = geti("DVP_GF_INV_TABS", t.gf_inv_tabs);
   t.msm_ws_slots = geti("DVP_MSM_WS_SLOTS", t.msm_ws_slots);
   t.msm_gate_min = geti("DVP_MSM_GATE_MIN", t.msm_gate_min);
   t.msm_aff_tpb = geti("DVP_MSM_AFF_TPB", t.msm_aff_tpb);
@@ -101,7 +102,7 @@ static long long* tune_slot(const char* name) {
   dvp::Tune& t = dvp::tune();
   struct { const char* n; long long* v; } tab[] = {
       {"DVP_MSM_C", &t.msm_c}, {"DVP_MSM_K", &t.msm_k}, {"DVP_MSM_FIXED_C", &t.msm_fixed_c}, {"DVP_FX_HI", &t.fx_hi},
-      {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_HEX_MAX", &t.msm_hex_max}, {"DVP_MSM_ROUND_PIPELINE", &t.msm_round_pipeline}, {"DVP_MSM_SORT_FUSED", &t.msm_sort_fused}, {"DVP_MSM_BUCKET_PAIRS_MAX", &t.msm_bucket_pairs_max}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax}, {"DVP_MSM_AFF_BMIN", &t.msm_aff_bmin}, {"DVP_ECFFT_RADIX4", &t.ecfft_radix4}, {"DVP_ECFFT_FOLD", &t.ecfft_fold}, {"DVP_MSM_ACCUM_FAST", &t.msm_accum_fast}, {"DVP_MSM_TAIL_GROUPS", &t.msm_tail_groups}, {"DVP_MSM_ACCUM_HEX_MAX", &t.msm_accum_hex_max}, {"DVP_MSM_WS_SLOTS", &t.msm_ws_slots}, {"DVP_MSM_GATE_MIN", &t.msm_gate_min}, {"DVP_MSM_AFF_TPB", &t.msm_aff_tpb}, {"DVP_CACHE_REPLICAS", &t.cache_replicas},
+      {"DVP_MSM_PROJ", &t.msm_proj}, {"DVP_MSM_AFF_MIN", &t.msm_aff_min}, {"DVP_MSM_HEX_MAX", &t.msm_hex_max}, {"DVP_MSM_ROUND_PIPELINE", &t.msm_round_pipeline}, {"DVP_MSM_SORT_FUSED", &t.msm_sort_fused}, {"DVP_MSM_BUCKET_PAIRS_MAX", &t.msm_bucket_pairs_max}, {"DVP_MSM_AFF_BMAX", &t.msm_aff_bmax}, {"DVP_MSM_AFF_BMIN", &t.msm_aff_bmin}, {"DVP_ECFFT_RADIX4", &t.ecfft_radix4}, {"DVP_ECFFT_FOLD", &t.ecfft_fold}, {"DVP_MSM_ACCUM_FAST", &t.msm_accum_fast}, {"DVP_MSM_TAIL_GROUPS", &t.msm_tail_groups}, {"DVP_MSM_ACCUM_HEX_MAX", &t.msm_accum_hex_max}, {"DVP_GF_INV_TABS", &t.gf_inv_tabs}, {"DVP_MSM_WS_SLOTS", &t.msm_ws_slots}, {"DVP_MSM_GATE_MIN", &t.msm_gate_min}, {"DVP_MSM_AFF_TPB", &t.msm_aff_tpb}, {"DVP_CACHE_REPLICAS", &t.cache_replicas},
       {"DVP_MSM_QUAD_MAX", &t.msm_quad_max}, {"DVP_MSM_ACCUM_QUAD_MAX", &t.msm_accum_quad_max}, {"DVP_MSM_FIXED_MIN", &t.msm_fixed_min}, {"DVP_HORNER_MAX_PUB", &t.horner_max_pub}, {"DVP_FR_BI_SHAPE", &t.fr_bi_shape},
       {"DVP_MSM_ALIGNED_SIGNED", &t.msm_aligned_signed}, {"DVP_PROVE_HOST_TRANSCRIPT", &t.prove_host_transcript}};
   for (auto& e : tab)

@@ -82,6 +82,7 @@ struct Tune {
   long long msm_accum_fast = 1;  // DVP_MSM_ACCUM_FAST: the fan-in-K reducer's first level without exceptional branches, exceptional tasks redone from a list (0 = the general kernel of rounds 1-5)
   long long msm_tail_groups = 1; // DVP_MSM_TAIL_GROUPS: a one-shot MSM's W x c tail points are first summed in groups of 16 on many workgroups (k_tail_groups; 0 = the single-workgroup tail alone)
   long long msm_accum_hex_max = -1;  // DVP_MSM_ACCUM_HEX_MAX: the fan-in reducer's LAST level uses a row of 16 lanes per task up to this many tasks (-1 = default, 0 = never)
+  long long gf_inv_tabs = 1;     // DVP_GF_INV_TABS: squaring runs of the GF(2^233) inversion taken as table passes beyond the three long ones: 0 = none (rounds 1-5), 1 = the run of 14, 2 = the runs of 14 and 7
   long long msm_accum_quad_max = 0;    // DVP_MSM_ACCUM_QUAD_MAX: reducer launches with at most this many tasks (upper bound) use a quad of lanes per task (0 = default)
   long long msm_bucket_pairs_max = 12;  // DVP_MSM_BUCKET_PAIRS_MAX: what the pair rounds leave goes through k_bucket_pairs / k_bucket_rest (one thread per bucket) when no bucket holds more points than this; above it, and with 0, through the fan-in-K reducer
   long long msm_sort_fused = 1;  // DVP_MSM_SORT_FUSED: level 1 of the signed flavour's sort recomputes the entry words from the scalars (0 = k_recode_signed writes them to HBM first)

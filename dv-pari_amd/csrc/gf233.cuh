@@ -707,6 +707,11 @@ struct GfSqrTables {
   const Gf* t58;
   const Gf* t116;
   const Gf* th;  // the half-trace (also GF(2)-linear): th[pos][byte] = H(byte * z^(8 pos))
+  // round 6: the runs of 14 and 7 squarings of the chain as table passes too (nullptr = plain squarings; Tune::gf_inv_tabs).  A plain
+  // squaring is ~215 VALU instructions, a table pass ~430 + eight round trips to the L2: 14 squarings -> one pass takes 2.6 k of the
+  // ~16 k instructions of an inversion, which every pair-round thread pays once per round whatever its slot count
+  const Gf* t14;
+  const Gf* t7;
 };
 // Round 5: the lookups of one word of a (four bytes: eight 16-byte loads) are issued together and xored in afterwards, with 3-input
 // xors.  The first version walked the bytes in a rolled loop -- load, wait, xor, thirty times: thirty dependent round trips to the L2 per
@@ -780,8 +785,8 @@ GF_DEV Gf gf_inv_fast(const Gf& a, const GfSqrTables& T, const LT& L) {
   Gf b3 = gf_mul(gf_sqr(b2), b1, L);
   Gf b6 = gf_mul(gf_sqr_n(b3, 3), b3, L);
   Gf b7 = gf_mul(gf_sqr(b6), b1, L);
-  Gf b14 = gf_mul(gf_sqr_n(b7, 7), b7, L);
-  Gf b28 = gf_mul(gf_sqr_n(b14, 14), b14, L);
+  Gf b14 = gf_mul(T.t7 ? gf_sqr_tab(b7, T.t7, L) : gf_sqr_n(b7, 7), b7, L);
+  Gf b28 = gf_mul(T.t14 ? gf_sqr_tab(b14, T.t14, L) : gf_sqr_n(b14, 14), b14, L);
   Gf b29 = gf_mul(gf_sqr(b28), b1, L);
   Gf b58 = gf_mul(gf_sqr_tab(b29, T.t29, L), b29, L);
   Gf b116 = gf_mul(gf_sqr_tab(b58, T.t58, L), b58, L);

@@ -1021,20 +1021,19 @@ k_bucket_rest(const Aff* __restrict__ pts, const uint32_t* __restrict__ cnt, con
 
 // ---- multi-squaring tables for the fast inversion (gf233.cuh) ----------------------------------------
 __global__ void __launch_bounds__(256)
-k_build_sqr_tables(Gf* __restrict__ t29, Gf* __restrict__ t58, Gf* __restrict__ t116, Gf* __restrict__ th) {
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;  // 4 * 30 * 256 entries
-  if (tid >= 4 * 30 * 256) return;
+k_build_sqr_tables(Gf* __restrict__ tabs /* t29 | t58 | t116 | th | t14 | t7, 30 x 256 entries each */) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= 6 * 30 * 256) return;
   uint32_t which = tid / (30 * 256), e = tid - which * 30 * 256, pos = e >> 8, byte = e & 255;
   Gf v = gf_zero();
   v.w[pos >> 2] = byte << (8 * (pos & 3));
   if (pos == 29) v.w[7] &= 0x1FFu;  // bits >= 233 never occur in a reduced element
   if (which == 3) {
-    th[e] = gf_halftrace(v);
+    tabs[tid] = gf_halftrace(v);
     return;
   }
-  int k = which == 0 ? 29 : which == 1 ? 58 : 116;
-  v = gf_sqr_n(v, k);
-  (which == 0 ? t29 : which == 1 ? t58 : t116)[e] = v;
+  const int k = which == 0 ? 29 : which == 1 ? 58 : which == 2 ? 116 : which == 4 ? 14 : 7;
+  tabs[tid] = gf_sqr_n(v, k);
 }
 static std::mutex g_sqr_mu;
 static Gf* g_sqr_tab[16] = {nullptr};
@@ -1045,8 +1044,8 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
   std::lock_guard<std::mutex> g(g_sqr_mu);
   if (!g_sqr_tab[dev]) {
     Gf* t;
-    DVP_HIP(hipMalloc((void**)&t, (size_t)4 * 30 * 256 * sizeof(Gf)));
-    hipLaunchKernelGGL(k_build_sqr_tables, dim3(cdiv(4 * 30 * 256, 256)), dim3(256), 0, st, t, t + 30 * 256, t + 2 * 30 * 256, t + 3 * 30 * 256);
+    DVP_HIP(hipMalloc((void**)&t, (size_t)6 * 30 * 256 * sizeof(Gf)));
+    hipLaunchKernelGGL(k_build_sqr_tables, dim3(cdiv(6 * 30 * 256, 256)), dim3(256), 0, st, t);
     DVP_HIP(hipGetLastError());
     DVP_HIP(hipStreamSynchronize(st));
     g_sqr_tab[dev] = t;
@@ -1055,6 +1054,9 @@ int gf_sqr_tables(GfSqrTables* out, hipStream_t st) {
   out->t58 = g_sqr_tab[dev] + 30 * 256;
   out->t116 = g_sqr_tab[dev] + 2 * 30 * 256;
   out->th = g_sqr_tab[dev] + 3 * 30 * 256;
+  const long long tabs = tune().gf_inv_tabs;  // 0: the three long runs only (rounds 1-5), 1: + the run of 14, 2: + the run of 7
+  out->t14 = tabs >= 1 ? g_sqr_tab[dev] + 4 * 30 * 256 : nullptr;
+  out->t7 = tabs >= 2 ? g_sqr_tab[dev] + 5 * 30 * 256 : nullptr;
   return DVP_OK;
 }
 
