@@ -181,7 +181,8 @@ k_bary3_partial(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, const F
     s[1] = fr_add(s[1], fr_mul(k, E[(size_t)m + i]));
     s[2] = fr_add(s[2], fr_mul(k, E[3 * (size_t)m + i]));
   }
-  for (int v = 0; v < 3; ++v) {
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {  // (unrolled: a runtime index put s[] / res[] into 112 B of scratch per lane)
     sh[threadIdx.x] = s[v];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -197,7 +198,8 @@ __global__ void __launch_bounds__(256) k_bary3_final(const Fr* __restrict__ part
   __shared__ Fr sh[256];
   Fr res[3];
   const Fr neg_z_alpha_m = *neg_z_alpha_m_p;
-  for (int v = 0; v < 3; ++v) {
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {  // (unrolled: a runtime index put s[] / res[] into 112 B of scratch per lane)
     Fr s = fr_zero();
     for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[(size_t)v * nb + i]);
     sh[threadIdx.x] = s;
@@ -255,7 +257,8 @@ k_bary3_partial_range(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, c
     s[1] = fr_add(s[1], fr_mul(k, E[(size_t)m + i]));
     s[2] = fr_add(s[2], fr_mul(k, E[3 * (size_t)m + i]));
   }
-  for (int v = 0; v < 3; ++v) {
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {  // (unrolled: a runtime index put s[] / res[] into 112 B of scratch per lane)
     sh[threadIdx.x] = s[v];
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -271,7 +274,8 @@ k_bary3_partial_range(const Fr* __restrict__ E, const Fr* __restrict__ barw_m, c
 __global__ void __launch_bounds__(256)
 k_bary3_record(const Fr* __restrict__ partial, uint32_t nb, const unsigned long long* __restrict__ hit, Fr* __restrict__ rec) {
   __shared__ Fr sh[256];
-  for (int v = 0; v < 3; ++v) {
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {  // (unrolled: a runtime index put s[] / res[] into 112 B of scratch per lane)
     Fr s = fr_zero();
     for (uint32_t i = threadIdx.x; i < nb; i += 256) s = fr_add(s, partial[(size_t)v * nb + i]);
     sh[threadIdx.x] = s;
@@ -298,7 +302,8 @@ k_bary3_from_records(const Fr* __restrict__ recs /* n x 4 Fr */, uint32_t n, Fr 
   if (threadIdx.x != 0) return;
   Fr res[3];
   unsigned long long h = ~0ull;
-  for (int v = 0; v < 3; ++v) {
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {  // (unrolled: a runtime index put s[] / res[] into 112 B of scratch per lane)
     Fr s = fr_zero();
     for (uint32_t r = 0; r < n; ++r) s = fr_add(s, recs[(size_t)r * 4 + v]);
     res[v] = fr_mul(s, neg_z_alpha_m);
