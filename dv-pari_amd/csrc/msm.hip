@@ -1333,13 +1333,19 @@ k_affine_round(const Aff* __restrict__ pts, const uint2* __restrict__ desc, cons
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nthr) return;
   const uint2 none = make_uint2(AFF_NONE, AFF_NONE);
+  // (round 6: the load is unconditional from a clamped index and the VALUE is selected.  Returning `none` from the early exits made
+  // hipcc select between two ADDRESSES -- &desc[sk] and a private copy of `none`: 16 B of scratch per lane and, worse, a FLAT load per
+  // descriptor, which counts on lgkmcnt beside the multiplier's LDS reads)
   auto ld_desc = [&](int k) -> uint2 {
-    if (k < 0 || k >= B) return none;
     const uint32_t sk = (uint32_t)k * nthr + tid;
-    if (sk >= total) return none;
-    if (FIRST) return desc[sk];
-    const uint32_t d = ((const uint32_t*)desc)[sk], a = d & ~DESC_PAIR;  // later rounds: one word per slot
-    return make_uint2(a, (d & DESC_PAIR) ? a + 1 : AFF_NONE);
+    const bool ok = k >= 0 && k < B && sk < total;
+    if (FIRST) {
+      uint2 v = none;
+      if (ok) v = desc[sk];
+      return v;
+    }
+    const uint32_t d = ((const uint32_t*)desc)[ok ? sk : 0u], a = d & ~DESC_PAIR;  // later rounds: one word per slot
+    return make_uint2(ok ? a : AFF_NONE, (ok && (d & DESC_PAIR)) ? a + 1 : AFF_NONE);
   };
   const Gf one = gf_one();
   // pass 1: denominators and running product (x-coordinates only; y is touched when x1 == x2)
