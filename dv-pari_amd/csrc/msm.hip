@@ -196,7 +196,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* t
 }
 
 // PAD2: every count is rounded up to even first (fixed-base sort: buckets then start at even positions of the sorted
-// item list, so the list read as uint2 pairs IS the first pair round's descriptor array, see k_pad_odd_buckets)
+// item list, so the list read as uint2 pairs IS the first pair round's descriptor array, see k_post_sort)
 template <bool PAD2>
 __global__ void __launch_bounds__(SCAN_TPB) k_scan_local(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
                                                          uint32_t* __restrict__ bsum, uint32_t m) {
@@ -264,6 +264,21 @@ __global__ void __launch_bounds__(SCAN_TPB) k_scan_add(uint32_t* __restrict__ ou
     if (base + k < m) out[base + k] += add;
 }
 
+// Short inputs (<= SCAN_FOLD_NB blocks of 1 024 values: the bucket arrays of a small MSM) fold the scan of the block sums into the last
+// launch: every block adds up the raw sums of the blocks in front of it itself (a uniform loop over <= 64 words) -- two dependent
+// launches per scan instead of three (round 6: a one-shot MSM of 2^16 points scans its 24 576 counts four times)
+constexpr uint32_t SCAN_FOLD_NB = 64;
+__global__ void __launch_bounds__(SCAN_TPB) k_scan_add_fold(uint32_t* __restrict__ out, const uint32_t* __restrict__ bsum_raw, uint32_t m,
+                                                           uint32_t* __restrict__ total_out) {
+  uint32_t add = 0;
+  for (uint32_t b = 0; b < blockIdx.x; ++b) add += bsum_raw[b];
+  const uint32_t base = blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_EPT;
+#pragma unroll
+  for (int k = 0; k < SCAN_EPT; ++k)
+    if (base + k < m) out[base + k] += add;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = add + bsum_raw[blockIdx.x];
+}
+
 // out[0..m) = exclusive scan of in[0..m); out[m] = total
 static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st, bool pad2 = false) {
   uint32_t nb = cdiv(m, SCAN_BLK);
@@ -271,8 +286,12 @@ static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_
     hipLaunchKernelGGL(k_scan_local<true>, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
   else
     hipLaunchKernelGGL(k_scan_local<false>, dim3(nb), dim3(SCAN_TPB), 0, st, in, out, bsum, m);
-  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
-  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
+  if (nb <= SCAN_FOLD_NB)
+    hipLaunchKernelGGL(k_scan_add_fold, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m, out + m);
+  else {
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
+  }
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
@@ -281,8 +300,12 @@ static int scan_exclusive(const uint32_t* in, uint32_t* out, uint32_t m, uint32_
 static int scan_exclusive_div(const uint32_t* in, uint32_t K, uint32_t* vout, uint32_t* out, uint32_t m, uint32_t* bsum, hipStream_t st) {
   uint32_t nb = cdiv(m, SCAN_BLK);
   hipLaunchKernelGGL(k_scan_local_div, dim3(nb), dim3(SCAN_TPB), 0, st, in, K, vout, out, bsum, m);
-  hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
-  hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
+  if (nb <= SCAN_FOLD_NB)
+    hipLaunchKernelGGL(k_scan_add_fold, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m, out + m);
+  else {
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(SCAN_TPB), 0, st, bsum, nb, out + m);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_TPB), 0, st, out, bsum, m);
+  }
   DVP_HIP(hipGetLastError());
   return DVP_OK;
 }
@@ -1083,12 +1106,25 @@ constexpr uint32_t DESC_PAIR = 0x80000000u;
 // even); an odd bucket's spare slot gets AFF_NONE.  The list read as uint2 pairs is then exactly the descriptor array of
 // the first pair round -- (a, b) table indices, b = NONE for the odd leftover -- so that round needs no descriptor
 // kernel and no scan: its output offsets are the item offsets halved (k_round0_offsets).
+// the three per-key passes between the sort and the first pair round of an MSM whose bookkeeping is not done by the all-rounds scan (small
+// one-shot MSMs) as ONE launch (round 6): the NONE behind every odd bucket, the first round's counts and offsets, the largest bucket
 __global__ void __launch_bounds__(256)
-k_pad_odd_buckets(uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t nkeys) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nkeys) return;
-  const uint32_t c = cnt[k];
-  if (c & 1) items[off[k] + c] = AFF_NONE;
+k_post_sort(uint32_t* __restrict__ items, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off /* nkeys + 1, even */, uint32_t nkeys,
+            uint32_t* __restrict__ ocnt, uint32_t* __restrict__ ooff /* nkeys + 1 */, uint32_t* __restrict__ d_max) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t m = 0;
+  if (k <= nkeys) {
+    const uint32_t o = off[k];
+    ooff[k] = o >> 1;
+    if (k < nkeys) {
+      const uint32_t c = cnt[k];
+      if (c & 1) items[o + c] = AFF_NONE;
+      ocnt[k] = (c + 1) >> 1;
+      m = c;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(d_max, m);
 }
 __global__ void __launch_bounds__(256)
 k_round0_offsets(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off /* nkeys + 1, even */, uint32_t nkeys,
@@ -1487,12 +1523,6 @@ k_bucket_gather_items(const Aff* __restrict__ bases, const uint32_t* __restrict_
     r = ld_from_aff(q);
   }
   A[k] = r;
-}
-__global__ void __launch_bounds__(256) k_max_u32(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
-  uint32_t m = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = max(m, v[i]);
-  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // dense bucket array: A[key] = the single remaining item of key, or infinity
@@ -2089,7 +2119,7 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
   size_t o_cnt2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_off2 = carve(((size_t)p.nkeys + 1) * 4);
   size_t o_bsum = carve(((size_t)p.nkeys / SCAN_BLK + 8) * 4);
-  size_t o_items = carve((p.e_max + (size_t)p.nkeys + 2) * 4);  // odd buckets are padded to even (k_pad_odd_buckets)
+  size_t o_items = carve((p.e_max + (size_t)p.nkeys + 2) * 4);  // odd buckets are padded to even (k_post_sort)
   const size_t sort_cells = fx ? ((size_t)(fx_nblk + FX_NP + 1) << fb.lo) : ((size_t)p.W * cdiv(n, SORT_CHUNK) << p.c);
   size_t o_hist16 = carve(sort_cells * 2);
   size_t o_choff = carve(sort_cells * 4);
@@ -2292,7 +2322,6 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
                          chunk_off, hist16, items);
     else
       hipLaunchKernelGGL(k_scatter_local2, dim3(gmax), dim3(SORT_TPB), (1u << fb.lo) * 4, st, plo, pid, pstart, cstart, fb, off, chunk_off, items);
-    if (!sort_done_by_mscan) hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   } else {
     const uint32_t nchunks = cdiv(n, SORT_CHUNK), nb = 1u << p.c;
     hipLaunchKernelGGL(k_hist_local, dim3(nchunks, p.W), dim3(SORT_TPB), (nb >> 1) * 4, st, digits, (uint32_t)n, p.c, hist16);
@@ -2300,17 +2329,20 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
     DVP_TRY(prepare_rounds());  // needs the counts only
     if (!sort_done_by_mscan) DVP_TRY(scan_exclusive(cnt, off, nk, bsum, st, /*pad2=*/true));
     hipLaunchKernelGGL(k_scatter_local, dim3(nchunks, p.W), dim3(SORT_TPB), nb * 4, st, digits, (uint32_t)n, p.c, off, chunk_off, items);
-    if (!sort_done_by_mscan) hipLaunchKernelGGL(k_pad_odd_buckets, dim3(cdiv(nk, 256)), dim3(256), 0, st, items, cnt, off, nk);
   }
   ps_sort.stop();
   // ---- bucket accumulation: batched-affine pair rounds while a round still carries >= aff_min additions,
   // then the projective fan-in-K reducer on what is left (it has a short critical path and balances skew)
-  if (!sort_done_by_mscan) {
-    hipLaunchKernelGGL(k_max_u32, dim3(64), dim3(256), 0, st, cnt, nk, d_max);  // (d_max: zeroed by the previous MSM's tail kernel)
-    DVP_TRY(read_max());
-  }
   uint32_t* pc[3] = {cnt, ntask, cnt2};
   uint32_t* po[3] = {off, toff, off2};
+  bool r0_offsets_ready = false;
+  if (!sort_done_by_mscan) {
+    // odd buckets' NONE, the first round's counts / offsets (into the ring's next pair, where k_round0_offsets would put them) and the
+    // largest bucket in one launch (d_max: zeroed by the previous MSM's tail kernel)
+    hipLaunchKernelGGL(k_post_sort, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, items, cnt, off, nk, pc[1], po[1], d_max);
+    r0_offsets_ready = true;
+    DVP_TRY(read_max());
+  }
   int cur = 0;  // index of the live (cnt, off) pair
   const Aff* bases0 = fx ? fx->table : (const Aff*)d_bases;
   const Aff* pts_in = bases0;
@@ -2368,9 +2400,10 @@ static int msm_core(const void* d_scalars, const void* d_bases, const void* d_in
       return DVP_OK;
     }
     const int nxt = (cur + 1) % 3;
-    if (r == 0)
-      hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
-    else
+    if (r == 0) {
+      if (!(r0_offsets_ready && cur == 0))
+        hipLaunchKernelGGL(k_round0_offsets, dim3(cdiv(nk + 1, 256)), dim3(256), 0, st, pc[cur], po[cur], nk, pc[nxt], po[nxt]);
+    } else
       DVP_TRY(bookkeep(r, pc[cur], po[cur], pc[nxt], po[nxt], gdesc, st, bsum));
     DVP_TRY(launch_round(r, po[nxt] + nk, r == 0 ? (const uint2*)items : (const uint2*)(const void*)gdesc));
     cur = nxt;
